@@ -1,0 +1,143 @@
+"""Synthetic SDR streams (there is no SDR hardware on the GPU box).
+
+Recipe of SURVEY.md section 8(d): complex white noise (sigma 1e-5 per
+component, far below the -90 dBW detection threshold) plus rectangular tone
+pulses ``A*exp(2j*pi*(f*t+phi))``.  A pulse amplitude is chosen from a target
+peak PSD via the processing gain of the window,
+``P_peak[dBW] = 20*log10(A) + 10*log10((sum w)^2 / (fs * sum w^2))``.
+
+Two generators:
+
+* :func:`make_stream` -- NumPy (PCG64), bit-reproducible from the seed; used
+  for fixtures and parity tests.
+* :func:`make_batch_device` -- torch, generates ``[S, B]`` complex64 directly
+  in HBM for throughput runs (not bit-reproducible across devices; parity on
+  such data is always checked by copying sample streams back to the host).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+NOISE_SIGMA = 1e-5
+
+
+@dataclass
+class Pulse:
+    start: int  # first sample
+    length: int  # samples
+    freq: float  # Hz offset from centre
+    amp: float
+    phase: float = 0.0
+
+
+@dataclass
+class StreamSpec:
+    n_samples: int
+    sample_rate: float
+    pulses: List[Pulse] = field(default_factory=list)
+    noise_sigma: float = NOISE_SIGMA
+    dc: complex = 0j
+
+
+def window_gain_db(window: np.ndarray, sample_rate: float) -> float:
+    """PSD of a bin-centred unit-amplitude tone, in dB (G)."""
+    w = np.asarray(window, dtype=np.float64)
+    return 10.0 * math.log10(w.sum() ** 2 / (sample_rate * (w * w).sum()))
+
+
+def amp_for_peak_dbw(peak_dbw: float, window: np.ndarray, sample_rate: float) -> float:
+    return 10.0 ** ((peak_dbw - window_gain_db(window, sample_rate)) / 20.0)
+
+
+def make_stream(spec: StreamSpec, seed: int) -> np.ndarray:
+    """complex64 IQ of one stream.  Noise reals are drawn first, then imags
+    (the order the golden-vector script pins)."""
+    rng = np.random.default_rng(seed)
+    n = spec.n_samples
+    x = np.empty(n, dtype=np.complex128)
+    x.real = rng.standard_normal(n)
+    x.imag = rng.standard_normal(n)
+    x *= spec.noise_sigma
+    if spec.dc:
+        x += spec.dc
+    for p in spec.pulses:
+        a = max(0, p.start)
+        b = min(n, p.start + p.length)
+        if b <= a:
+            continue
+        t = np.arange(a, b, dtype=np.float64) / spec.sample_rate
+        x[a:b] += p.amp * np.exp(2j * np.pi * (p.freq * t + p.phase))
+    return x.astype(np.complex64)
+
+
+def random_pulses(
+    rng: np.random.Generator,
+    n_samples: int,
+    sample_rate: float,
+    window: np.ndarray,
+    n_pulses: int,
+    dur_ms: Sequence[float] = (15.0, 15.0),
+    peak_dbw: Sequence[float] = (-80.0, -60.0),
+    keep_clear_tail: Optional[int] = None,
+) -> List[Pulse]:
+    """``n_pulses`` pulses with uniform start/frequency/level.  With
+    ``keep_clear_tail`` the last that many samples stay pulse-free (so no run
+    straddles the buffer end unless a test wants it)."""
+    pulses = []
+    for _ in range(n_pulses):
+        dur = rng.uniform(dur_ms[0], dur_ms[1]) * 1e-3
+        length = int(round(dur * sample_rate))
+        hi = n_samples - length - (keep_clear_tail or 0)
+        start = int(rng.integers(0, max(1, hi)))
+        freq = float(rng.uniform(-0.45, 0.45) * sample_rate)
+        amp = amp_for_peak_dbw(float(rng.uniform(*peak_dbw)), window, sample_rate)
+        pulses.append(Pulse(start, length, freq, amp, float(rng.uniform(0, 1))))
+    return pulses
+
+
+def make_batch_device(
+    n_streams: int,
+    n_samples: int,
+    sample_rate: float,
+    window: np.ndarray,
+    pulses_per_stream: Sequence[int] = (4, 8),
+    dur_ms: Sequence[float] = (15.0, 15.0),
+    peak_dbw: Sequence[float] = (-80.0, -60.0),
+    seed: int = 0,
+    device="cuda",
+    chunk_streams: int = 64,
+):
+    """``[S, B]`` complex64 batch generated in device memory with torch.
+
+    Noise comes from a seeded ``torch.Generator`` on the device; pulses are
+    drawn on the host (NumPy, seeded per stream) and added on the device, a
+    pulse at a time (they are sparse).  Pulses never touch the last segment
+    of a buffer, so nothing straddles the end.
+    """
+    import torch
+
+    dev = torch.device(device)
+    out = torch.empty((n_streams, n_samples), dtype=torch.complex64, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    real_view = torch.view_as_real(out)  # [S, B, 2] float32
+    for s0 in range(0, n_streams, chunk_streams):
+        s1 = min(n_streams, s0 + chunk_streams)
+        real_view[s0:s1].normal_(0.0, NOISE_SIGMA, generator=gen)
+    nperseg = len(window)
+    two_pi = 2.0 * math.pi
+    for s in range(n_streams):
+        rng = np.random.default_rng([seed, s])
+        k = int(rng.integers(pulses_per_stream[0], pulses_per_stream[1] + 1))
+        for p in random_pulses(
+            rng, n_samples, sample_rate, window, k, dur_ms, peak_dbw, keep_clear_tail=2 * nperseg
+        ):
+            t = torch.arange(p.start, p.start + p.length, device=dev, dtype=torch.float64)
+            ph = two_pi * (p.freq * t / sample_rate + p.phase)
+            tone = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64) * p.amp
+            out[s, p.start : p.start + p.length] += tone
+    return out
