@@ -1,0 +1,186 @@
+/*
+ * rt_analyze.h -- C-ABI of the MI355X-native signal-analysis path.
+ *
+ * This library replaces ONE path of Nature40/pyradiotracking: the per-buffer
+ * callback SignalAnalyzer.process_samples (reference
+ * radiotracking/analyze.py:192-268) -- STFT power (analyze.py:234-241, i.e.
+ * scipy.signal.spectrogram), plateau extraction with look-back into the
+ * previous buffer (analyze.py:330-452) and the shadow filter
+ * (analyze.py:282-328) -- batched over many independent streams resident in
+ * HBM.  The reference is pure Python and has no FFI of its own; these entry
+ * points are what a ctypes binding inside the reference's SignalAnalyzer
+ * would call (see INTEGRATION.md for that binding).
+ *
+ * Conventions
+ *   - plain C types only; every function returns an rt_status (0 = ok, <0 =
+ *     error) except where noted; no exception crosses the boundary.
+ *   - one handle = one GPU + one HIP stream + the per-stream carried state
+ *     (the look-back tail that replaces `_spectrogram_last`, analyze.py:268).
+ *     A handle is not thread-safe.
+ *   - IQ is complex64 (interleaved float32 I,Q), stream-major:
+ *     sample b of stream s at iq[s * stream_stride + b].
+ *   - results are integer cell coordinates plus float32 linear powers; the
+ *     float64 / datetime part of a Signal (frequency, ts, duration, dB) is
+ *     derived on the host from them (pyradiotracking_amd/analyze.py), so it is
+ *     bit-exact by construction.
+ */
+#ifndef RT_ANALYZE_H
+#define RT_ANALYZE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_E_INVALID = -1,      /* bad argument / configuration                     */
+    RT_E_UNSUPPORTED = -2,  /* e.g. nperseg not in {256,512,1024,2048,4096}     */
+    RT_E_NO_DEVICE = -3,    /* no usable GPU / HIP failure at create            */
+    RT_E_HIP = -4,          /* HIP runtime error (see rt_last_error)            */
+    RT_E_CAPACITY = -5,     /* record capacity exceeded (results truncated)     */
+    RT_E_ONE_SEGMENT = -6,  /* exactly one segment: the reference raises
+                               IndexError there (analyze.py:354, times[1])      */
+    RT_E_NOMEM = -7
+} rt_status;
+
+/* how the batch is analysed */
+typedef enum rt_mode {
+    RT_MODE_AUTO = 0,   /* fused sparse path; falls back to dense on overflow   */
+    RT_MODE_DENSE = 1,  /* materialise the power spectrogram (any input)        */
+    RT_MODE_SPARSE = 2  /* fused sparse path only; overflow -> RT_E_CAPACITY    */
+} rt_mode;
+
+/*
+ * Analyzer configuration.  Mirrors the derived parameters of
+ * SignalAnalyzer.__init__ (analyze.py:101-117) plus batch geometry.
+ */
+typedef struct rt_config {
+    int32_t device;             /* HIP device ordinal                                    */
+    int32_t n_streams;          /* S: independent streams analysed per call              */
+    int32_t nperseg;            /* fft_nperseg (analyze.py:111); 256*{1,2,4,8,16}         */
+    int32_t mode;               /* rt_mode                                               */
+    int64_t max_samples;        /* largest per-stream buffer length B accepted           */
+    double sample_rate;         /* fs (analyze.py:101)                                   */
+    const float *window;        /* host pointer, nperseg float32 coefficients: the
+                                   window cast to the IQ dtype as SciPy does
+                                   (scipy/signal/_spectral_py.py:2083-2084)              */
+    float scale;                /* 1/(fs*sum(w*w)) in float32 (_spectral_py.py:2087)     */
+    float threshold;            /* signal_threshold, linear (analyze.py:115)             */
+    float snr_threshold;        /* snr_threshold, linear (analyze.py:116)                */
+    float calibration_db;       /* only used to order maxima in the shadow filter        */
+    double min_duration_s;      /* signal_min_duration (analyze.py:113)                  */
+    double max_duration_s;      /* signal_max_duration (analyze.py:114)                  */
+    int32_t hot_capacity;       /* sparse path: candidate cells kept per stream and call
+                                   (0 = default 8192)                                    */
+    int32_t record_capacity;    /* records kept per stream and call (0 = default 1024)   */
+    int32_t segs_per_chunk;     /* segments per lane-group chunk (0 = default)           */
+    int32_t flags;              /* RT_FLAG_*                                             */
+    void *hip_stream;           /* hipStream_t to launch on, or NULL for an own stream   */
+} rt_config;
+
+#define RT_FLAG_TIMING 1u /* record HIP events around the kernels of each call */
+
+/*
+ * One extracted plateau, before it becomes a Signal (analyze.py:442-449).
+ * `start` may be negative: it then indexes the previous buffer from its end,
+ * exactly like the reference's negative `start` (analyze.py:383-388, 422-423).
+ */
+typedef struct rt_record {
+    int32_t stream;   /* stream index within the batch                                   */
+    int32_t fi;       /* frequency bin, fftfreq order (analyze.py:357)                   */
+    int32_t start;    /* first cell of `data` (analyze.py:437-440)                       */
+    int32_t end;      /* one past the last cell                                          */
+    float max_p;      /* max(data), linear                                               */
+    float mean_p;     /* mean(data), linear                                              */
+    float std_db;     /* std(10*log10(data)), population                                 */
+    float row_mean;   /* mean of the bin's row over the whole buffer (`freq_avg`, :375)  */
+    int32_t shadowed; /* 1 if filter_shadow_signals drops it (analyze.py:315-328)        */
+    int32_t reserved;
+} rt_record;
+
+typedef struct rt_handle rt_handle;
+
+int rt_abi_version(void);
+
+/* Create an analyzer for `cfg` on cfg->device.  Allocates all device scratch. */
+int rt_create(const rt_config *cfg, rt_handle **out);
+
+void rt_destroy(rt_handle *h);
+
+/* Forget the carried look-back state (== `_spectrogram_last = None`, analyze.py:128). */
+int rt_reset(rt_handle *h);
+
+/*
+ * Analyse one buffer per stream: the body of process_samples (analyze.py:234-251,
+ * 268).  `iq_dev` is a DEVICE pointer to S*stream_stride complex64; n_samples =
+ * len(buffer) (<= max_samples); stream_stride in samples (>= n_samples).
+ * Asynchronous: enqueues on the handle's stream.  Results via rt_fetch.
+ */
+int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride);
+
+/* Same with IQ in host memory (copied to an internal device buffer first). */
+int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride);
+
+/*
+ * Wait for the last rt_process / rt_extract and copy its records, ordered by
+ * (stream, fi, start) -- the reference's emission order per stream
+ * (analyze.py:357, 364).  Records carry the shadow verdict; none is removed.
+ * *n_out receives the number of records available; at most `cap` are written.
+ */
+int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out);
+
+/*
+ * extract_signals + filter_shadow_signals on a caller-supplied power
+ * spectrogram (analyze.py:330-452 with explicit arguments): `spec_dev` is a
+ * DEVICE pointer to [S][n_seg][n_bins] float32 (segment-major, the memory
+ * layout SciPy's result has under its [F,T] view).  `last_dev` is the previous
+ * spectrogram in the same layout with n_seg_last segments, or NULL
+ * (`_spectrogram_last is None`).  n_bins is free (not tied to nperseg).
+ * Does not touch the carried state.  Results via rt_fetch.
+ */
+int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bins,
+               const float *last_dev, int32_t n_seg_last);
+
+/*
+ * Debug / test entry: STFT power only.  Writes [S][T][nperseg] float32 to
+ * `spec_dev` (device), T = n_samples / nperseg.  Synchronous.
+ */
+int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride,
+                   float *spec_dev);
+
+/* Per-call figures of the last rt_process (valid after rt_fetch). */
+typedef struct rt_call_info {
+    int32_t n_seg;            /* T of the call                                           */
+    int32_t mode_used;        /* RT_MODE_DENSE or RT_MODE_SPARSE                          */
+    int32_t fell_back;        /* 1 if the sparse path overflowed and dense re-ran        */
+    int32_t reserved;
+    int64_t n_hot;            /* candidate cells emitted by the sparse scan              */
+    int64_t n_records;        /* records produced                                        */
+    float ms_stft;            /* RT_FLAG_TIMING: STFT/scan kernel, HIP events, ms        */
+    float ms_detect;          /* RT_FLAG_TIMING: detect kernel(s), ms                    */
+    float ms_total;           /* RT_FLAG_TIMING: first launch to last launch, ms         */
+    float reserved2;
+} rt_call_info;
+
+int rt_get_call_info(rt_handle *h, rt_call_info *info);
+
+/* Message of the last error on this handle (or of the last failed rt_create if h == NULL). */
+const char *rt_last_error(rt_handle *h);
+
+/* Plain device-memory helpers so that a host without its own HIP binding
+ * (ctypes-only integration) can stage IQ: thin hipMalloc/hipFree/hipMemcpy. */
+int rt_dev_alloc(int32_t device, size_t bytes, void **out);
+int rt_dev_free(int32_t device, void *ptr);
+int rt_dev_upload(int32_t device, void *dst_dev, const void *src_host, size_t bytes);
+int rt_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t bytes);
+int rt_device_count(int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ANALYZE_H */

@@ -1,0 +1,445 @@
+"""Host-side mirror of the reference's ``SignalAnalyzer`` for the analysis path.
+
+Same constructor keywords, same method names, same ``Signal`` records on the
+same kind of queue as ``radiotracking/analyze.py:20-452`` -- but the arithmetic
+of ``process_samples`` (STFT power, plateau extraction with look-back, shadow
+verdicts) runs in the gfx950 HIP kernels behind ``librt_analyze.so``.  This
+module only derives parameters, stages buffers and turns the integer/float32
+records the kernels return into ``Signal`` objects (float64 / datetime parts
+are computed here with the reference's own expressions, so they are bit-exact
+by construction).
+
+Not mirrored (out of scope): opening an RTL-SDR, the
+SIGALRM watchdog, ``StateMessage`` heartbeats, process lifecycle.
+
+Two entry levels:
+
+* :class:`SignalAnalyzer` -- one stream, drop-in for the reference class.
+* :class:`BatchSignalAnalyzer` -- ``S`` independent streams per call, IQ
+  resident in HBM (``[S, B]`` complex64); this is what ``bench.py`` drives.
+"""
+from __future__ import annotations
+
+import datetime
+import logging
+import time
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import pytz
+import scipy.fft
+import scipy.signal
+
+from . import Signal, dB, from_dB
+from . import _native
+
+logger = logging.getLogger(__name__)
+
+
+def window_coefficients(fft_window, nperseg: int) -> np.ndarray:
+    """What ``scipy.signal.spectrogram`` makes of its ``window`` argument
+    (scipy/signal/_spectral_py.py:2239-2263): names/tuples go through
+    ``get_window`` (periodic), arrays are taken as coefficients."""
+    if isinstance(fft_window, (str, tuple)):
+        return scipy.signal.get_window(fft_window, nperseg)
+    win = np.asarray(fft_window)
+    if win.ndim != 1:
+        raise ValueError("window must be 1-D")
+    if win.shape[0] != nperseg:
+        raise ValueError("value specified for nperseg is different from length of window")
+    return win
+
+
+def stft_constants(fft_window, nperseg: int, sample_rate):
+    """float32 window and PSD scale exactly as SciPy forms them for complex64
+    input (_spectral_py.py:2083-2087): the window is cast to complex64 and
+    ``scale = 1/(fs * sum(win*win))`` is evaluated in that dtype."""
+    win = window_coefficients(fft_window, nperseg).astype(np.complex64)
+    scale = 1.0 / (sample_rate * (win * win).sum())
+    return np.ascontiguousarray(win.real, dtype=np.float32), np.float32(scale.real)
+
+
+class _RecordDecoder:
+    """rt_record arrays -> Signal field columns (analyze.py:360, 420-449)."""
+
+    def __init__(self, nperseg: int, sample_rate, center_freq, calibration_db: float):
+        self.nperseg = nperseg
+        self.sample_rate = sample_rate
+        self.center_freq = center_freq
+        self.calibration_db = calibration_db
+        self.freqs = scipy.fft.fftfreq(nperseg, 1 / sample_rate)  # _spectral_py.py:2113
+
+    def times(self, k: np.ndarray) -> np.ndarray:
+        # element k of  arange(N/2, B - N/2 + 1, N) / float(fs)   (_spectral_py.py:2136)
+        return (self.nperseg / 2 + np.asarray(k, dtype=np.float64) * self.nperseg) / float(self.sample_rate)
+
+    def decode(self, rec: np.ndarray):
+        start = rec["start"].astype(np.int64)
+        end = rec["end"].astype(np.int64)
+        t_end = self.times(end)
+        t_start = np.where(start < 0, -self.times(np.abs(start)), self.times(np.maximum(start, 0)))
+        duration_s = t_end - t_start
+        cal = self.calibration_db
+        with np.errstate(divide="ignore", invalid="ignore"):
+            max_dbw = dB(rec["max_p"]) - cal  # float32, analyze.py:442
+            avg_dbw = dB(rec["mean_p"]) - cal  # :444
+            noise_dbw = dB(rec["row_mean"])  # :446
+            snr_db = dB(rec["mean_p"] / rec["row_mean"])  # :447
+        frequency = self.freqs[rec["fi"]] + self.center_freq  # :360
+        return t_start, duration_s, frequency, max_dbw, avg_dbw, rec["std_db"], noise_dbw, snr_db
+
+    def signals(self, rec: np.ndarray, device_names: Sequence[str], ts_starts: Sequence[datetime.datetime]) -> List[Signal]:
+        t_start, duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = self.decode(rec)
+        out = []
+        streams = rec["stream"]
+        for i in range(len(rec)):
+            s = int(streams[i])
+            ts = ts_starts[s] + datetime.timedelta(seconds=float(t_start[i]))  # :434
+            out.append(
+                Signal(
+                    device_names[s],
+                    ts.astimezone(pytz.utc),  # :449
+                    frequency[i],
+                    datetime.timedelta(seconds=float(duration_s[i])),  # :428
+                    max_dbw[i],
+                    avg_dbw[i],
+                    std_db[i],
+                    noise_dbw[i],
+                    snr_db[i],
+                )
+            )
+        return out
+
+
+class BatchSignalAnalyzer:
+    """``S`` independent analyzers sharing one configuration, one GPU.
+
+    ``process_batch`` is the batched body of the reference callback
+    (analyze.py:231-251, 268) for one buffer of every stream.  Per-stream
+    carried state (the look-back tail replacing ``_spectrogram_last``) lives in
+    HBM inside the native handle.
+    """
+
+    def __init__(
+        self,
+        devices: Sequence[str],
+        calibration_db: float = 0.0,
+        sample_rate: int = 300000,
+        center_freq: int = 150150000,
+        fft_nperseg: int = 256,
+        fft_window="hamming",
+        signal_min_duration_ms: float = 8,
+        signal_max_duration_ms: float = 40,
+        signal_threshold_dbw: float = -90.0,
+        snr_threshold_db: float = 5.0,
+        sdr_callback_length: Optional[int] = None,
+        gpu: int = 0,
+        mode: str = "auto",
+        hot_capacity: int = 0,
+        record_capacity: int = 0,
+        segs_per_chunk: int = 0,
+        timing: bool = False,
+        hip_stream: Optional[int] = None,
+        **kwargs,
+    ):
+        self.devices = [str(d) for d in devices]
+        self.calibration_db = calibration_db
+        self.sample_rate = sample_rate
+        self.center_freq = center_freq
+        if sdr_callback_length is None:  # analyze.py:108-109
+            sdr_callback_length = sample_rate
+        self.sdr_callback_length = int(sdr_callback_length)
+        self.fft_nperseg = fft_nperseg
+        self.fft_window = fft_window
+        self.signal_min_duration = signal_min_duration_ms / 1000  # :113
+        self.signal_max_duration = signal_max_duration_ms / 1000  # :114
+        self.signal_threshold = from_dB(signal_threshold_dbw + calibration_db)  # :115
+        self.snr_threshold = from_dB(snr_threshold_db)  # :116
+
+        win32, scale32 = stft_constants(fft_window, fft_nperseg, sample_rate)
+        self._native = _native.NativeAnalyzer(
+            n_streams=len(self.devices),
+            nperseg=fft_nperseg,
+            max_samples=self.sdr_callback_length,
+            sample_rate=sample_rate,
+            window_f32=win32,
+            scale=float(scale32),
+            # thresholds are compared against float32 data in float32
+            threshold=float(np.float32(self.signal_threshold)),
+            snr_threshold=float(np.float32(self.snr_threshold)),
+            calibration_db=calibration_db,
+            min_duration_s=self.signal_min_duration,
+            max_duration_s=self.signal_max_duration,
+            device=gpu,
+            mode={"auto": _native.RT_MODE_AUTO, "dense": _native.RT_MODE_DENSE, "sparse": _native.RT_MODE_SPARSE}[mode],
+            hot_capacity=hot_capacity,
+            record_capacity=record_capacity,
+            segs_per_chunk=segs_per_chunk,
+            timing=timing,
+            hip_stream=hip_stream,
+        )
+        self._decoder = _RecordDecoder(fft_nperseg, sample_rate, center_freq, calibration_db)
+        self.gpu = gpu
+
+    # -- native plumbing ----------------------------------------------------
+    @property
+    def native(self) -> "_native.NativeAnalyzer":
+        return self._native
+
+    def reset(self):
+        """``_spectrogram_last = None`` for every stream."""
+        self._native.reset()
+
+    def close(self):
+        self._native.close()
+
+    def enqueue(self, iq, n_samples: Optional[int] = None, stream_stride: Optional[int] = None):
+        """Start analysing one buffer per stream (asynchronous).
+
+        ``iq``: a CUDA/HIP torch tensor ``[S, B]`` complex64, a raw device
+        pointer (int, with ``n_samples``), or a host ndarray ``[S, B]``.
+        """
+        if isinstance(iq, int):
+            if n_samples is None:
+                raise ValueError("n_samples is required with a raw device pointer")
+            self._native.process_device(iq, n_samples, stream_stride)
+            return
+        if isinstance(iq, np.ndarray):
+            self._native.process_host(iq)
+            return
+        # torch tensor
+        if iq.dim() == 1:
+            iq = iq[None, :]
+        if not iq.is_cuda:
+            self._native.process_host(iq.numpy())
+            return
+        if str(iq.dtype) != "torch.complex64":
+            raise TypeError("device IQ must be complex64")
+        if iq.shape[0] != len(self.devices) or iq.stride(1) != 1:
+            raise ValueError("device IQ must be [S, B] with unit sample stride")
+        self._keep = iq
+        self._native.process_device(iq.data_ptr(), iq.shape[1], iq.stride(0) if iq.shape[0] > 1 else iq.shape[1])
+
+    def fetch_records(self) -> np.ndarray:
+        """Wait for the enqueued call; structured array of ``rt_record``."""
+        return self._native.fetch()
+
+    def process_batch(self, iq, ts_starts: Union[datetime.datetime, Sequence[datetime.datetime]], filtered: bool = True):
+        """One buffer per stream -> per-stream lists of ``Signal``.
+
+        ``filtered=True`` returns what the reference puts on its queue
+        (after ``filter_shadow_signals``); ``False`` returns the list
+        ``extract_signals`` would have produced."""
+        self.enqueue(iq)
+        rec = self.fetch_records()
+        if isinstance(ts_starts, datetime.datetime):
+            ts_starts = [ts_starts] * len(self.devices)
+        if filtered:
+            rec = rec[rec["shadowed"] == 0]
+        sigs = self._decoder.signals(rec, self.devices, ts_starts)
+        per_stream: List[List[Signal]] = [[] for _ in self.devices]
+        for r, sig in zip(rec["stream"], sigs):
+            per_stream[int(r)].append(sig)
+        return per_stream
+
+
+class SignalAnalyzer:
+    """Drop-in for ``radiotracking.analyze.SignalAnalyzer`` on the analysis path.
+
+    Constructor keywords are the reference's (analyze.py:62-83; unknown ones are
+    swallowed like its ``**kwargs``) plus ``gpu`` (HIP device ordinal).  The
+    object is *not* a ``multiprocessing.Process`` and opens no SDR: feed it
+    buffers through :meth:`process_samples` exactly as ``read_samples_async``
+    would (analyze.py:157).
+    """
+
+    def __init__(
+        self,
+        device: str,
+        calibration_db: float = 0.0,
+        sample_rate: int = 300000,
+        center_freq: int = 150150000,
+        gain: float = 49.6,
+        fft_nperseg: int = 256,
+        fft_window="hamming",
+        signal_min_duration_ms: float = 8,
+        signal_max_duration_ms: float = 40,
+        signal_threshold_dbw: float = -90.0,
+        snr_threshold_db: float = 5.0,
+        verbose: int = 0,
+        sdr_max_restart: int = 3,
+        sdr_timeout_s: int = 2,
+        state_update_s: int = 60,
+        sdr_callback_length: Optional[int] = None,
+        signal_queue=None,
+        last_data_ts=None,
+        gpu: int = 0,
+        mode: str = "auto",
+        **kwargs,
+    ):
+        self.device = device
+        self.calibration_db = calibration_db
+        try:
+            self.device_index = int(device)  # analyze.py:89-91
+        except ValueError:
+            self.device_index = None  # serial-number lookup needs pyrtlsdr: out of scope
+        self.sample_rate = sample_rate
+        self.center_freq = center_freq
+        try:
+            self.gain = float(gain)
+        except ValueError:
+            self.gain = gain
+        if sdr_callback_length is None:
+            sdr_callback_length = sample_rate
+        self.fft_nperseg = fft_nperseg
+        self.fft_window = fft_window
+        self.signal_min_duration = signal_min_duration_ms / 1000
+        self.signal_max_duration = signal_max_duration_ms / 1000
+        self.signal_threshold = from_dB(signal_threshold_dbw + calibration_db)
+        self.snr_threshold = from_dB(snr_threshold_db)
+        self.sdr_callback_length = sdr_callback_length
+        self.verbose = verbose
+        self.sdr_max_restart = sdr_max_restart
+        self.sdr_timeout_s = sdr_timeout_s
+        self.state_update_s = state_update_s
+        self.signal_queue = signal_queue
+        self.last_data_ts = last_data_ts
+
+        self._spectrogram_last = None  # only used by extract_signals() called directly
+        self._ts = None
+        self._batch = BatchSignalAnalyzer(
+            [device],
+            calibration_db=calibration_db,
+            sample_rate=sample_rate,
+            center_freq=center_freq,
+            fft_nperseg=fft_nperseg,
+            fft_window=fft_window,
+            signal_min_duration_ms=signal_min_duration_ms,
+            signal_max_duration_ms=signal_max_duration_ms,
+            signal_threshold_dbw=signal_threshold_dbw,
+            snr_threshold_db=snr_threshold_db,
+            sdr_callback_length=sdr_callback_length,
+            gpu=gpu,
+            mode=mode,
+        )
+        self._decoder = self._batch._decoder
+
+    # -- the callback (analyze.py:192-268) -----------------------------------
+    def process_samples(self, buffer: np.ndarray, context=None):
+        """Analyse one buffer; detected signals go to ``signal_queue`` in the
+        reference's order.  complex128 buffers (what pyrtlsdr delivers) are
+        analysed in complex64 -- the GPU path is single precision."""
+        ts_recv = datetime.datetime.now()
+        buffer_len_dt = datetime.timedelta(seconds=len(buffer) / self.sample_rate)  # :205
+        if self.last_data_ts is not None:
+            self.last_data_ts.value = datetime.datetime.timestamp(ts_recv)  # :214
+        if not self._ts:  # :218-221
+            self._ts = ts_recv
+        else:
+            self._ts += buffer_len_dt
+        clock_drift = (ts_recv - self._ts).total_seconds()
+        if clock_drift > 2 * buffer_len_dt.total_seconds():  # :226
+            logger.warning(
+                f"SDR {self.device} total clock drift ({clock_drift:.5f} s) is larger than two blocks, "
+                "signal detection is degraded."
+            )
+        ts_start = self._ts - buffer_len_dt  # :231
+        filtered = self.analyze_buffer(buffer, ts_start)
+        [self.consume_signal(s) for s in filtered]  # :251
+        return None
+
+    def analyze_buffer(self, buffer: np.ndarray, ts_start: datetime.datetime, filtered: bool = True) -> List[Signal]:
+        """analyze.py:234-248 and :268 with an explicit ``ts_start``."""
+        bench_start = time.time()
+        buf = np.ascontiguousarray(buffer, dtype=np.complex64).reshape(1, -1)
+        if buf.shape[1] > self._batch.sdr_callback_length:
+            raise ValueError("buffer longer than sdr_callback_length")
+        out = self._batch.process_batch(buf, [ts_start], filtered=filtered)[0]
+        logger.info(
+            f"SDR {self.device} recv {len(buffer)}, {len(out)} signals, "
+            f"compute: {(time.time() - bench_start) * 1000:.1f} ms"
+        )
+        return out
+
+    def reset(self):
+        self._batch.reset()
+        self._spectrogram_last = None
+        self._ts = None
+
+    # -- the reference's public helpers ---------------------------------------
+    def consume_signal(self, signal: Signal):
+        """analyze.py:270-280."""
+        logger.debug(f"SDR {self.device} received {signal}")
+        if self.signal_queue is not None:
+            self.signal_queue.put(signal)
+
+    def extract_signals(self, freqs: np.ndarray, times: np.ndarray, spectrogram: np.ndarray, ts_start: datetime.datetime) -> List[Signal]:
+        """analyze.py:330-452 on an explicit ``[F, T]`` power spectrogram (any
+        ``F``), with ``self._spectrogram_last`` as the previous one.  Runs the
+        dense detect kernel (``rt_extract``).  The time axis must be the one
+        SciPy produces for ``fft_nperseg`` / ``sample_rate`` (hop = nperseg/fs);
+        ``freqs`` is used as given."""
+        spec = np.asarray(spectrogram)
+        n_bins, n_seg = spec.shape
+        if n_seg == 0:
+            return []
+        if n_seg >= 2:
+            hop = self._decoder.times(np.array([1]))[0] - self._decoder.times(np.array([0]))[0]
+            if not np.isclose(times[1] - times[0], hop, rtol=1e-9, atol=0.0):
+                raise ValueError("times does not match fft_nperseg / sample_rate")
+        nat = self._batch.native
+        seg_major = np.ascontiguousarray(spec.T, dtype=np.float32)
+        d_spec = _native.DeviceBuffer(self._batch.gpu, max(4, seg_major.nbytes))
+        d_spec.upload(seg_major)
+        d_last = None
+        n_last = 0
+        if self._spectrogram_last is not None:
+            last = np.ascontiguousarray(np.asarray(self._spectrogram_last).T, dtype=np.float32)
+            n_last = last.shape[0]
+            d_last = _native.DeviceBuffer(self._batch.gpu, max(4, last.nbytes))
+            d_last.upload(last)
+        try:
+            nat.extract_device(d_spec.ptr, n_seg, n_bins, d_last.ptr if d_last else None, n_last)
+            rec = nat.fetch()
+        finally:
+            d_spec.free()
+            if d_last:
+                d_last.free()
+        self._last_records = rec
+        t_start, duration_s, _f, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = self._decoder.decode(rec)
+        out = []
+        for i in range(len(rec)):
+            ts = ts_start + datetime.timedelta(seconds=float(t_start[i]))
+            out.append(
+                Signal(
+                    self.device,
+                    ts.astimezone(pytz.utc),
+                    freqs[rec["fi"][i]] + self.center_freq,
+                    datetime.timedelta(seconds=float(duration_s[i])),
+                    max_dbw[i],
+                    avg_dbw[i],
+                    std_db[i],
+                    noise_dbw[i],
+                    snr_db[i],
+                )
+            )
+        return out
+
+    @staticmethod
+    def is_shadow_of(sig: Signal, signals: List[Signal]) -> Union[None, int]:
+        """analyze.py:283-313 on ``Signal`` objects (pure datetime/float
+        comparisons on the host).  ``process_samples`` does not use this: its
+        verdicts come from the detect kernel (``rt_record.shadowed``)."""
+        for i, other in enumerate(signals):
+            if sig.ts > other.ts + other.duration:
+                continue
+            if sig.ts + sig.duration < other.ts:
+                continue
+            if other.max > sig.max:
+                return i
+        return None
+
+    def filter_shadow_signals(self, signals: List[Signal]) -> List[Signal]:
+        """analyze.py:315-328 for a caller-supplied list (see ``is_shadow_of``)."""
+        verdict = [SignalAnalyzer.is_shadow_of(s, signals) for s in signals]
+        return [s for s, v in zip(signals, verdict) if v is None]

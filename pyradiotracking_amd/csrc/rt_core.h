@@ -1,0 +1,257 @@
+// rt_core.h -- scalar decision logic of the analysis path, shared by the HIP
+// kernels (device) and by the host-side unit-test harness (rt_hostcheck.cpp).
+//
+// Everything here is a restatement of reference arithmetic that must be
+// decided bit-identically on the GPU:
+//   * segment-centre times            scipy/signal/_spectral_py.py:2136-2137
+//   * the "above" predicate            radiotracking/analyze.py:370, 378 (T10)
+//   * start-of-plateau walk incl. look-back into the previous buffer
+//                                      analyze.py:382-398 (T11-T13)
+//   * duration gate in float64         analyze.py:420-433 (T14)
+//   * plateau statistics               analyze.py:442-447 (T15)
+//   * timedelta microsecond rounding   CPython Modules/_datetimemodule.c
+//                                      (delta_new / accum), used by the shadow
+//                                      filter analyze.py:300-311 (T16)
+#ifndef RT_CORE_H
+#define RT_CORE_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+// Geometry/thresholds of one detect pass (one spectrogram of T columns).
+struct DetectParams {
+    int32_t n_seg;        // T: columns of the current spectrogram
+    int32_t n_seg_last;   // columns of the previous one, or -1 if there is none
+    int32_t tail_cols;    // K: how many trailing columns of the previous one are readable
+    int32_t stride;       // probe stride max(1, int(min_d / hop))         (analyze.py:354, 364)
+    int32_t nperseg;      // N (for the time axis only)
+    float thr;            // signal_threshold (linear)
+    float snr;            // snr_threshold (linear)
+    float cal_db;         // calibration (only to order maxima in the shadow filter)
+    double fs;
+    double min_d;         // seconds
+    double max_d;         // seconds
+};
+
+// times[k] of scipy: arange(N/2, B - N/2 + 1, N) / float(fs)
+RT_HD double seg_time(int32_t k, int32_t nperseg, double fs) {
+    return ((double)nperseg * 0.5 + (double)k * (double)nperseg) / fs;
+}
+
+// stride = max(1, int(min_d / (times[1] - times[0])))
+RT_HD int32_t probe_stride(int32_t nperseg, double fs, double min_d) {
+    double hop = seg_time(1, nperseg, fs) - seg_time(0, nperseg, fs);
+    double q = min_d / hop;
+    int32_t s = (q >= 2147483647.0) ? 2147483647 : (int32_t)q;  // int() truncates toward zero
+    return s < 1 ? 1 : s;
+}
+
+// `not (p < thr) and not (p / avg < snr)` in float32
+RT_HD bool cell_above(float p, float avg, float thr, float snr) {
+    if (p < thr) return false;
+    if (p / avg < snr) return false;
+    return true;
+}
+
+// A maximal run [b, e) of above-cells is visited by the strided probe iff it
+// contains a multiple of the stride (T9).  Returns that first probe or -1.
+RT_HD int32_t first_probe_in_run(int32_t b, int32_t e, int32_t stride) {
+    int32_t q = (b + stride - 1) / stride;
+    int64_t ti = (int64_t)q * stride;
+    return ti < e ? (int32_t)ti : -1;
+}
+
+// Outcome of the downward walk (analyze.py:382-398).
+struct StartWalk {
+    int32_t start;   // may be negative
+    bool too_long;   // ran past the readable tail: duration certainly exceeds max_d
+};
+
+// `prev(d)` returns the power of the previous buffer's column n_seg_last-d
+// (d >= 1, d <= tail_cols) for the bin at hand.
+template <class PrevCell>
+RT_HD StartWalk walk_start(const DetectParams &p, int32_t b, int32_t ti0, float avg, PrevCell prev) {
+    StartWalk w;
+    w.too_long = false;
+    const int32_t start_min = (p.n_seg_last < 0) ? 0 : (1 - p.n_seg_last);
+    if (ti0 <= start_min) {  // loop `while start > start_min` never runs
+        w.start = ti0;
+        return w;
+    }
+    // cells b..ti0 are above; b-1 (if >= 0) is not: the walk stops on it, or
+    // earlier on start_min without testing (T11).
+    int32_t s = b - 1;
+    if (s < start_min) s = start_min;
+    if (s >= 0 || b > 0) {
+        w.start = s;
+        return w;
+    }
+    // b == 0 and start_min < 0: continue into the previous buffer (T12)
+    s = -1;
+    for (;;) {
+        if (s == start_min) break;  // not tested
+        int32_t d = -s;
+        if (d > p.tail_cols) {
+            w.too_long = true;
+            break;
+        }
+        if (!cell_above(prev(d), avg, p.thr, p.snr)) break;
+        --s;
+    }
+    w.start = s;
+    return w;
+}
+
+// start_dt / duration in float64 exactly as analyze.py:420-427
+RT_HD double start_time(const DetectParams &p, int32_t start) {
+    return start < 0 ? -seg_time(-start, p.nperseg, p.fs) : seg_time(start, p.nperseg, p.fs);
+}
+RT_HD double run_duration(const DetectParams &p, int32_t start, int32_t end) {
+    return seg_time(end, p.nperseg, p.fs) - start_time(p, start);
+}
+RT_HD bool duration_ok(const DetectParams &p, double dur) {
+    if (dur < p.min_d) return false;
+    if (dur > p.max_d) return false;
+    return true;
+}
+
+// np.max / np.mean / np.std(dB(.)) over the cells of a plateau.  `cell(i)`,
+// i in [0, n), yields the i-th element of `data` (analyze.py:437-440).
+struct RunStats {
+    float max_p, mean_p, std_db;
+};
+
+RT_HD float db10(float v) { return 10.0f * log10f(v); }
+
+template <class Cell>
+RT_HD RunStats run_stats(int32_t n, Cell cell) {
+    RunStats r;
+    float mx = cell(0);
+    double sum = 0.0, sum_db = 0.0;
+    for (int32_t i = 0; i < n; ++i) {
+        float v = cell(i);
+        if (!(mx != mx)) {          // NaN sticks, as in np.max
+            if (v != v || v > mx) mx = v;
+        }
+        sum += (double)v;
+        sum_db += (double)db10(v);
+    }
+    const double mean_db = sum_db / (double)n;
+    double acc = 0.0;
+    for (int32_t i = 0; i < n; ++i) {
+        double d = (double)db10(cell(i)) - mean_db;
+        acc += d * d;
+    }
+    r.max_p = mx;
+    r.mean_p = (float)(sum / (double)n);
+    r.std_db = (float)sqrt(acc / (double)n);
+    return r;
+}
+
+// datetime.timedelta(seconds=x) -> whole microseconds, CPython's algorithm:
+// split off the integer seconds exactly, scale the fraction by 1e6 in double,
+// split again, round the leftover half-to-even against the parity of the sum.
+RT_HD int64_t timedelta_us(double seconds) {
+    double ip;
+    double frac = modf(seconds, &ip);
+    int64_t us = (int64_t)ip * 1000000LL;
+    if (frac == 0.0) return us;
+    double ip2;
+    double left = modf(1000000.0 * frac, &ip2);
+    us += (int64_t)ip2;
+    if (left != 0.0) {
+        double whole = round(left);
+        if (fabs(whole - left) == 0.5) {
+            int odd = (int)(us & 1LL);
+            whole = 2.0 * round((left + odd) * 0.5) - odd;
+        }
+        us += (int64_t)whole;
+    }
+    return us;
+}
+
+// A maximal run [b, e) of above-cells of the current buffer -> at most one
+// plateau (analyze.py:401-447 in run-based form).
+// `cur(t)` reads the bin's cell t >= 0, `prev(d)` the previous buffer's cell
+// n_seg_last - d, `emit(start, end, stats)` receives the result.
+template <class Cur, class Prev, class Emit>
+RT_HD void finish_run(const DetectParams &p, int32_t b, int32_t e, float avg, Cur cur, Prev prev, Emit emit) {
+    if (e == p.n_seg) return;  // laps into the next buffer (analyze.py:415)
+    const int32_t ti0 = first_probe_in_run(b, e, p.stride);
+    if (ti0 < 0) return;       // no strided probe lands in the run (T9)
+    const StartWalk sw = walk_start(p, b, ti0, avg, prev);
+    if (sw.too_long) return;
+    if (!duration_ok(p, run_duration(p, sw.start, e))) return;
+    const int32_t start = sw.start;
+    auto cell = [&](int32_t k) -> float {
+        const int32_t t = start + k;
+        return t < 0 ? prev(-t) : cur(t);
+    };
+    emit(start, e, run_stats(e - start, cell));
+}
+
+// Sequential scan of one bin's row of a dense spectrogram (analyze.py:357-450).
+// Returns false when no cell reaches the absolute threshold (row mean unused).
+template <class Cur, class Prev, class Emit>
+RT_HD bool scan_dense_row(const DetectParams &p, Cur cur, Prev prev, float *avg_out, Emit emit) {
+    const int32_t T = p.n_seg;
+    double sum = 0.0;
+    bool any = false;
+    for (int32_t t = 0; t < T; ++t) {
+        const float v = cur(t);
+        sum += (double)v;
+        any |= !(v < p.thr);
+    }
+    if (!any) return false;
+    const float avg = (float)sum / (float)T;  // np.mean(row) (analyze.py:375)
+    *avg_out = avg;
+    int32_t b = -1;
+    for (int32_t t = 0; t <= T; ++t) {
+        const bool ab = (t < T) && cell_above(cur(t), avg, p.thr, p.snr);
+        if (ab) {
+            if (b < 0) b = t;
+            continue;
+        }
+        if (b < 0) continue;
+        const int32_t rb = b;
+        b = -1;
+        finish_run(p, rb, t, avg, cur, prev, emit);
+    }
+    return true;
+}
+
+// is_shadow_of (analyze.py:300-311) on microsecond offsets from ts_start.
+RT_HD bool shadowed_by(int64_t ts_i, int64_t dur_i, float max_i, int64_t ts_j, int64_t dur_j, float max_j) {
+    if (ts_i > ts_j + dur_j) return false;
+    if (ts_i + dur_i < ts_j) return false;
+    return max_j > max_i;
+}
+
+// Position of record i in (fi, start) order and its shadow verdict against
+// the unfiltered list (analyze.py:325).  max is compared as the reference's
+// float32 dBW figure (analyze.py:442).
+template <class Rec>
+RT_HD void rank_and_shadow(int32_t i, int32_t n, const Rec *rec, const long long *ts_us, const long long *dur_us,
+                           float cal_db, int32_t *rank_out, int32_t *shadow_out) {
+    const int32_t fi = rec[i].fi, st = rec[i].start;
+    const float mx_i = db10(rec[i].max_p) - cal_db;
+    int32_t rank = 0, shadow = 0;
+    for (int32_t j = 0; j < n; ++j) {
+        if (rec[j].fi < fi || (rec[j].fi == fi && rec[j].start < st)) ++rank;
+        const float mx_j = db10(rec[j].max_p) - cal_db;
+        if (shadowed_by(ts_us[i], dur_us[i], mx_i, ts_us[j], dur_us[j], mx_j)) shadow = 1;
+    }
+    *rank_out = rank;
+    *shadow_out = shadow;
+}
+
+}  // namespace rt
+#endif

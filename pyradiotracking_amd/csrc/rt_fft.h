@@ -1,0 +1,128 @@
+// rt_fft.h -- in-register small DFTs (forward, exp(-2*pi*i*n*k/R)) used as the
+// radix passes of the segment FFT.  All indices are compile-time constants so
+// every value lives in a VGPR pair; nothing here touches memory.
+#ifndef RT_FFT_H
+#define RT_FFT_H
+
+#include <hip/hip_runtime.h>
+
+namespace rt {
+
+struct cf {
+    float x, y;
+};
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// multiply by -i  (forward-transform quarter turn): (x + iy)(-i) = y - ix
+__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
+__device__ __forceinline__ cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
+
+// 4-point DFT in place, natural order out.
+__device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3) {
+    cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
+    cf s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    a0 = cadd(s02, s13);
+    a2 = csub(s02, s13);
+    a1 = cadd(d02, d13);
+    a3 = csub(d02, d13);
+}
+
+__device__ __forceinline__ void dft2(cf &a0, cf &a1) {
+    cf s = cadd(a0, a1), d = csub(a0, a1);
+    a0 = s;
+    a1 = d;
+}
+
+#define RT_SQRT1_2 0.70710678118654752440f
+#define RT_COS_PI_8 0.92387953251128675613f
+#define RT_SIN_PI_8 0.38268343236508977173f
+
+// multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
+__device__ __forceinline__ cf mul_w8_1(cf a) { return cf{(a.x + a.y) * RT_SQRT1_2, (a.y - a.x) * RT_SQRT1_2}; }
+__device__ __forceinline__ cf mul_w8_3(cf a) { return cf{(a.y - a.x) * RT_SQRT1_2, -(a.x + a.y) * RT_SQRT1_2}; }
+
+// 8-point DFT, natural order in and out:  n = n0 + 2*n1, k = ka + 4*kb
+// (4-point DFTs over n1 for each n0, twiddle W8^(n0*ka), 2-point over n0).
+__device__ __forceinline__ void dft8(cf (&v)[8]) {
+    dft4(v[0], v[2], v[4], v[6]);  // n0 = 0 : Z0[ka] in v[0], v[2], v[4], v[6]
+    dft4(v[1], v[3], v[5], v[7]);  // n0 = 1 : Z1[ka]
+    v[3] = mul_w8_1(v[3]);         // ka = 1
+    v[5] = mul_mi(v[5]);           // ka = 2 : W8^2 = -i
+    v[7] = mul_w8_3(v[7]);         // ka = 3
+    // Y[ka + 4*kb] = Z0[ka] + (-1)^kb Z1[ka]
+    cf y0 = cadd(v[0], v[1]), y4 = csub(v[0], v[1]);
+    cf y1 = cadd(v[2], v[3]), y5 = csub(v[2], v[3]);
+    cf y2 = cadd(v[4], v[5]), y6 = csub(v[4], v[5]);
+    cf y3 = cadd(v[6], v[7]), y7 = csub(v[6], v[7]);
+    v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
+    v[4] = y4; v[5] = y5; v[6] = y6; v[7] = y7;
+}
+
+// 16-point DFT, natural order in and out:  n = n0 + 4*n1, k = ka + 4*kb.
+__device__ __forceinline__ void dft16(cf (&v)[16]) {
+    // 4-point DFTs over n1 for each n0: Z[n0][ka] lands in v[n0 + 4*ka]
+    dft4(v[0], v[4], v[8], v[12]);
+    dft4(v[1], v[5], v[9], v[13]);
+    dft4(v[2], v[6], v[10], v[14]);
+    dft4(v[3], v[7], v[11], v[15]);
+    // twiddles W16^(n0*ka)
+    const cf w1{RT_COS_PI_8, -RT_SIN_PI_8};   // W16^1
+    const cf w3{RT_SIN_PI_8, -RT_COS_PI_8};   // W16^3
+    v[5] = cmul(v[5], w1);                    // n0=1 ka=1 : W^1
+    v[9] = mul_w8_1(v[9]);                    // n0=1 ka=2 : W^2 = W8^1
+    v[13] = cmul(v[13], w3);                  // n0=1 ka=3 : W^3
+    v[6] = mul_w8_1(v[6]);                    // n0=2 ka=1 : W^2
+    v[10] = mul_mi(v[10]);                    // n0=2 ka=2 : W^4 = -i
+    v[14] = mul_w8_3(v[14]);                  // n0=2 ka=3 : W^6 = W8^3
+    v[7] = cmul(v[7], w3);                    // n0=3 ka=1 : W^3
+    v[11] = mul_w8_3(v[11]);                  // n0=3 ka=2 : W^6
+    {                                         // n0=3 ka=3 : W^9 = -W^1
+        cf t = cmul(v[15], w1);
+        v[15] = cf{-t.x, -t.y};
+    }
+    // 4-point DFTs over n0 for each ka: Y[ka + 4*kb] lands in v[4*ka + kb]
+    dft4(v[0], v[1], v[2], v[3]);
+    dft4(v[4], v[5], v[6], v[7]);
+    dft4(v[8], v[9], v[10], v[11]);
+    dft4(v[12], v[13], v[14], v[15]);
+    // transpose to natural order: out[ka + 4*kb] = v[4*ka + kb]
+    cf t;
+    t = v[1];  v[1] = v[4];   v[4] = t;
+    t = v[2];  v[2] = v[8];   v[8] = t;
+    t = v[3];  v[3] = v[12];  v[12] = t;
+    t = v[6];  v[6] = v[9];   v[9] = t;
+    t = v[7];  v[7] = v[13];  v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// R-point DFTs over groups of R consecutive registers (R in {2,4,8,16}):
+// 16/R independent transforms, natural order.
+template <int R>
+__device__ __forceinline__ void dft_groups(cf (&v)[16]) {
+    if constexpr (R == 16) {
+        dft16(v);
+    } else if constexpr (R == 8) {
+        cf a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = v[i]; b[i] = v[8 + i]; }
+        dft8(a);
+        dft8(b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = a[i]; v[8 + i] = b[i]; }
+    } else if constexpr (R == 4) {
+        dft4(v[0], v[1], v[2], v[3]);
+        dft4(v[4], v[5], v[6], v[7]);
+        dft4(v[8], v[9], v[10], v[11]);
+        dft4(v[12], v[13], v[14], v[15]);
+    } else if constexpr (R == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) dft2(v[i], v[i + 1]);
+    }
+}
+
+}  // namespace rt
+#endif

@@ -1,0 +1,84 @@
+// rt_hostcheck.cpp -- HOST build of the scalar decision logic in rt_core.h, for
+// unit tests only (tests/test_host_core.py).  It lets the CPU test-suite drive
+// the exact functions the detect kernels execute (predicate, start walk,
+// float64 duration gate, statistics, microsecond rounding, ordering + shadow
+// verdict) against the oracle and the golden vectors without a GPU.
+// It is NOT a fallback: the product library (rt_analyze.hip) never links or
+// loads this file, and there is no FFT/STFT here at all.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_analyze.h"
+#include "rt_core.h"
+
+using namespace rt;
+
+extern "C" {
+
+long long hc_timedelta_us(double seconds) { return (long long)timedelta_us(seconds); }
+
+int hc_probe_stride(int nperseg, double fs, double min_d) { return probe_stride(nperseg, fs, min_d); }
+
+double hc_seg_time(int k, int nperseg, double fs) { return seg_time(k, nperseg, fs); }
+
+int hc_tail_cols(int nperseg, double fs, double max_d) {
+    const double hop = seg_time(1, nperseg, fs) - seg_time(0, nperseg, fs);
+    return (int)(max_d / hop) + 2;
+}
+
+// extract_signals + filter_shadow_signals for ONE stream on a dense,
+// segment-major power map: spec[t*F + f].  last = previous map
+// [n_seg_last][F] or NULL; tail_cols limits how far back `last` may be read
+// (pass n_seg_last for the reference's unlimited look-back).
+// Returns the number of records (written up to cap, ordered by (fi, start)).
+int hc_extract(const float *spec, int n_seg, int n_bins, const float *last, int n_seg_last, int tail_cols,
+               int nperseg, double fs, float thr, float snr, float cal_db, double min_d, double max_d,
+               rt_record *out, int cap) {
+    DetectParams p;
+    p.n_seg = n_seg;
+    p.n_seg_last = last ? n_seg_last : -1;
+    p.tail_cols = last ? tail_cols : 0;
+    p.stride = probe_stride(nperseg, fs, min_d);
+    p.nperseg = nperseg;
+    p.thr = thr;
+    p.snr = snr;
+    p.cal_db = cal_db;
+    p.fs = fs;
+    p.min_d = min_d;
+    p.max_d = max_d;
+    std::vector<rt_record> rec;
+    std::vector<long long> ts, du;
+    for (int fi = 0; fi < n_bins; ++fi) {
+        auto cur = [&](int t) -> float { return spec[(size_t)t * n_bins + fi]; };
+        auto prev = [&](int d) -> float { return last[(size_t)(n_seg_last - d) * n_bins + fi]; };
+        float avg = 0.f;
+        auto emit = [&](int start, int end, const RunStats &st) {
+            rt_record r;
+            std::memset(&r, 0, sizeof r);
+            r.fi = fi;
+            r.start = start;
+            r.end = end;
+            r.max_p = st.max_p;
+            r.mean_p = st.mean_p;
+            r.std_db = st.std_db;
+            r.row_mean = avg;
+            rec.push_back(r);
+            ts.push_back(timedelta_us(start_time(p, start)));
+            du.push_back(timedelta_us(run_duration(p, start, end)));
+        };
+        scan_dense_row(p, cur, prev, &avg, emit);
+    }
+    const int n = (int)rec.size();
+    std::vector<rt_record> ordered(n);
+    for (int i = 0; i < n; ++i) {
+        int rank, shadow;
+        rank_and_shadow(i, n, rec.data(), ts.data(), du.data(), cal_db, &rank, &shadow);
+        ordered[rank] = rec[i];
+        ordered[rank].shadowed = shadow;
+    }
+    for (int i = 0; i < n && i < cap; ++i) out[i] = ordered[i];
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,529 @@
+// rt_kernels.h -- gfx950 kernels of the analysis path.
+//
+//   stft_scan<R3, MODE>   IQ -> windowed, detrended segment FFT -> power, fused
+//                         with per-bin partial row sums, the dense look-back
+//                         tail and either sparse candidate emission (MODE 0),
+//                         a dense spectrogram (MODE 1) or the spectrogram only
+//                         (MODE 2, debug).  Replaces scipy.signal.spectrogram
+//                         as called at radiotracking/analyze.py:234-241.
+//   detect_sparse         per stream: finish row means, sort candidates,
+//                         plateau extraction + statistics + shadow filter.
+//   detect_dense          the same on a dense spectrogram.
+//                         Both replace analyze.py:330-452 and :282-328.
+//
+// Segment FFT: N = 256*R3 points as radix passes 16 x 16 x R3 over a "lane
+// group" of LG = N/16 lanes holding 16 points each.  With n = a + LG*m and
+// k = k1 + 16*q1 + 256*q2:
+//   pass 1 (in-lane over m)          A[a][k1]  = sum_m x[a+LG*m] W16^(m k1),  times W_N^(a k1)
+//   exchange 1 (LDS, [k1][b][c], a = b + R3*c)
+//   pass 2 (in-lane over c)          B[b][k1][q1] = sum_c A[b+R3*c][k1] W16^(c q1), times W_LG^(b q1)
+//   exchange 2 (LDS, [k1][q1][b])    (R3 > 1 only)
+//   pass 3 (in-lane over b)          X[k1+16*q1+256*q2] = sum_b B[b][k1][q1] W_R3^(b q2)
+// For N = 256 a lane group is 16 lanes (four segments per wave64) and the whole
+// transform needs one LDS exchange; no barrier is needed while LG <= 64 because
+// a group then lives inside one wave.
+#ifndef RT_KERNELS_H
+#define RT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_analyze.h"
+#include "rt_core.h"
+#include "rt_fft.h"
+
+namespace rt {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int kRowF2 = 18;           // LDS exchange row stride in float2 (16 data + 2 pad = 144 B)
+
+struct StftParams {
+    const cf *iq;            // [S][stream_stride] complex64
+    int64_t stream_stride;   // samples
+    int32_t n_streams;
+    int32_t n_seg;           // T
+    int32_t segs_per_chunk;  // L
+    int32_t chunks;          // ceil(T / L) chunks per stream
+    int32_t blocks_per_stream;
+    int32_t tail_cols;       // K
+    const float *window;     // [N]
+    const cf *tw1;           // [LG][16]   W_N^(a*k1)
+    const cf *tw2;           // [R3][16]   W_LG^(b*q1)
+    float scale;
+    float thr;
+    float *psum;             // [S][chunks][N] partial row sums
+    float *tail;             // [S][K][N] trailing K columns (written)
+    float *spec;             // MODE 1/2: [S][T][N]
+    uint2 *hot;              // MODE 0: [S][hot_cap] (key = bin*T + t, bits of P)
+    uint32_t *hot_count;     // MODE 0: [S]
+    int32_t hot_cap;
+};
+
+template <int LG>
+__device__ __forceinline__ void group_sync() {
+    if constexpr (LG > 64) {
+        __syncthreads();
+    } else {
+        // a lane group lives inside one wave: DS operations of a wave execute
+        // in program order, only the compiler must not reorder across this.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// all-reduce (sum) over the LG lanes of a lane group
+template <int LG>
+__device__ __forceinline__ cf group_sum(cf v, cf *red /* [kBlock/64] LDS */) {
+#pragma unroll
+    for (int off = 1; off < (LG < 64 ? LG : 64); off <<= 1) {
+        v.x += __shfl_xor(v.x, off, 64);
+        v.y += __shfl_xor(v.y, off, 64);
+    }
+    if constexpr (LG > 64) {
+        const int wave = threadIdx.x >> 6;
+        constexpr int WPG = LG / 64;  // waves per group
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[wave] = v;
+        __syncthreads();
+        const int w0 = (wave / WPG) * WPG;
+        cf s{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < WPG; ++i) s = cadd(s, red[w0 + i]);
+        v = s;
+    }
+    return v;
+}
+
+// bin index of result register r in lane `lt` of a group after the last pass
+template <int R3>
+__device__ __forceinline__ int bin_of(int lt, int r) {
+    if constexpr (R3 == 1) {
+        return lt + 16 * r;  // k1 = lt, q1 = r
+    } else {
+        constexpr int G = 16 / R3;
+        const int k1 = lt / R3, qg = lt % R3;
+        const int u = r / R3, q2 = r % R3;
+        return k1 + 16 * (qg * G + u) + 256 * q2;
+    }
+}
+
+template <int R3, int MODE>
+__global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
+    constexpr int N = 256 * R3;
+    constexpr int LG = 16 * R3;
+    constexpr int GPW = kBlock / LG;  // lane groups per workgroup
+    constexpr int G = 16 / R3;
+
+    __shared__ __attribute__((aligned(16))) cf xch[kBlock * kRowF2];
+    __shared__ cf red[kBlock / 64];
+
+    const int tid = threadIdx.x;
+    const int g = tid / LG;
+    const int lt = tid % LG;
+    const int s = blockIdx.x / p.blocks_per_stream;
+    const int cb = blockIdx.x % p.blocks_per_stream;
+    const int chunk = cb * GPW + g;
+    const bool chunk_ok = chunk < p.chunks;
+    const int c0 = chunk * p.segs_per_chunk;
+    const int T = p.n_seg;
+    const int L = p.segs_per_chunk;
+
+    cf *gx = xch + g * LG * kRowF2;  // this group's exchange rows
+
+    // per-lane constants: window and pass twiddles
+    float w[16];
+    cf t1[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        w[m] = p.window[lt + LG * m];
+        t1[m] = p.tw1[lt * 16 + m];
+    }
+    cf t2[16];
+    if constexpr (R3 > 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t2[q] = p.tw2[(lt % R3) * 16 + q];
+    }
+
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
+
+    const cf *stream_iq = p.iq + (int64_t)s * p.stream_stride;
+    const int i_first = (MODE == 0) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
+
+    for (int i = i_first; i <= L; ++i) {
+        const int seg = c0 + L - i;
+        const bool halo = (i == 0);
+        const bool active = chunk_ok && seg < T;
+
+        cf v[16];
+        {
+            const cf *src = stream_iq + (int64_t)seg * N + lt;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = active ? src[LG * m] : cf{0.f, 0.f};
+        }
+
+        // detrend='constant': subtract the segment mean (scipy _signaltools.py:3926)
+        cf sum{0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sum = cadd(sum, v[m]);
+        sum = group_sum<LG>(sum, red);
+        const cf mean = cscale(sum, 1.0f / (float)N);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = cscale(csub(v[m], mean), w[m]);
+
+        // pass 1
+        dft16(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], t1[k]);
+
+        // exchange 1: element (a = lt, k1) -> row k1*R3 + b, column c
+        {
+            const int b = lt % R3, c = lt / R3;
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) gx[(k1 * R3 + b) * kRowF2 + c] = v[k1];
+        }
+        group_sync<LG>();
+        {
+            const float4 *row = reinterpret_cast<const float4 *>(gx + lt * kRowF2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float4 q = row[j];
+                v[2 * j] = cf{q.x, q.y};
+                v[2 * j + 1] = cf{q.z, q.w};
+            }
+        }
+
+        // pass 2
+        dft16(v);
+
+        if constexpr (R3 > 1) {
+#pragma unroll
+            for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], t2[q]);
+            group_sync<LG>();  // everyone has read exchange 1
+            {
+                const int k1 = lt / R3, b = lt % R3;
+#pragma unroll
+                for (int q1 = 0; q1 < 16; ++q1)
+                    gx[(k1 * R3 + q1 / G) * kRowF2 + (q1 % G) * R3 + b] = v[q1];
+            }
+            group_sync<LG>();
+            {
+                const float4 *row = reinterpret_cast<const float4 *>(gx + lt * kRowF2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float4 q = row[j];
+                    v[2 * j] = cf{q.x, q.y};
+                    v[2 * j + 1] = cf{q.z, q.w};
+                }
+            }
+            // pass 3
+            dft_groups<R3>(v);
+        }
+        group_sync<LG>();  // rows are free for the next segment
+
+        // |X|^2 * scale  (scipy _spectral_py.py:2126-2128)
+        float P[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[r] = (v[r].x * v[r].x + v[r].y * v[r].y) * p.scale;
+
+        if (active && !halo) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += P[r];
+            if constexpr (MODE != 0) {
+                float *dst = p.spec + ((int64_t)s * T + seg) * N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[bin_of<R3>(lt, r)] = P[r];
+            }
+            if constexpr (MODE != 2) {
+                const int col = seg - (T - p.tail_cols);
+                if (col >= 0) {
+                    float *dst = p.tail + ((int64_t)s * p.tail_cols + col) * N;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[bin_of<R3>(lt, r)] = P[r];
+                }
+            }
+        }
+
+        if constexpr (MODE == 0) {
+            uint32_t hot = 0;
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!(P[r] < p.thr)) hot |= (1u << r);
+            }
+            // a cell is kept if it is a candidate itself or directly precedes one (T11)
+            const uint32_t emit = (active && !halo) ? (hot | next_hot) : 0u;
+            if (emit) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (emit & (1u << r)) {
+                        const uint32_t slot = atomicAdd(&p.hot_count[s], 1u);
+                        if (slot < (uint32_t)p.hot_cap) {
+                            const uint32_t key = (uint32_t)bin_of<R3>(lt, r) * (uint32_t)T + (uint32_t)seg;
+                            p.hot[(int64_t)s * p.hot_cap + slot] = make_uint2(key, __float_as_uint(P[r]));
+                        }
+                    }
+                }
+            }
+            next_hot = hot;
+        }
+    }
+
+    if constexpr (MODE != 2) {
+        if (chunk_ok) {
+            float *dst = p.psum + ((int64_t)s * p.chunks + chunk) * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[bin_of<R3>(lt, r)] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// detection
+// ---------------------------------------------------------------------------
+struct DetectArgs {
+    DetectParams dp;
+    int32_t n_streams;
+    int32_t n_bins;            // F
+    // previous-buffer cells: prev[(s*prev_cols + (prev_cols - d))*F + f], d >= 1
+    const float *prev;
+    int32_t prev_cols;
+    // sparse inputs
+    const uint2 *hot;
+    const uint32_t *hot_count;
+    int32_t hot_cap;
+    const float *psum;         // [S][chunks][F]
+    int32_t chunks;
+    // dense input
+    const float *spec;         // [S][T][F]
+    // outputs
+    rt_record *records;        // pool
+    int64_t pool_cap;
+    int32_t rec_cap;           // per stream
+    int32_t *rec_offset;       // [S]
+    int32_t *rec_count;        // [S]
+    unsigned long long *counters;  // [0] records allocated, [1] hot total, [2] flags
+};
+
+constexpr unsigned long long kFlagHotOverflow = 1ull;
+constexpr unsigned long long kFlagRecOverflow = 2ull;
+constexpr unsigned long long kFlagInconsistent = 4ull;
+
+struct PrevCells {
+    const float *base;  // points at column prev_cols of this (stream, bin): base[-d*F]
+    int32_t F;
+    __device__ float operator()(int32_t d) const { return base[-(int64_t)d * F]; }
+};
+
+// LDS record staging shared by both detect kernels
+struct RecLds {
+    rt_record *rec;       // [rec_cap]
+    long long *ts_us;     // [rec_cap]
+    long long *dur_us;    // [rec_cap]
+    int *count;           // [1]
+};
+
+__device__ __forceinline__ void push_record(const DetectArgs &a, RecLds &l, int s, int fi, int start, int end,
+                                            const RunStats &st, float avg) {
+    const int idx = atomicAdd(l.count, 1);
+    if (idx < a.rec_cap) {
+        rt_record r;
+        r.stream = s;
+        r.fi = fi;
+        r.start = start;
+        r.end = end;
+        r.max_p = st.max_p;
+        r.mean_p = st.mean_p;
+        r.std_db = st.std_db;
+        r.row_mean = avg;
+        r.shadowed = 0;
+        r.reserved = 0;
+        l.rec[idx] = r;
+        l.ts_us[idx] = timedelta_us(start_time(a.dp, start));
+        l.dur_us[idx] = timedelta_us(run_duration(a.dp, start, end));
+    }
+}
+
+// order the stream's records by (fi, start), apply the shadow filter against
+// the unfiltered list (analyze.py:325) and publish them.
+__device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int *lds_base) {
+    __syncthreads();
+    int n = *l.count;
+    if (n > a.rec_cap) {
+        if (threadIdx.x == 0) atomicOr(&a.counters[2], kFlagRecOverflow);
+        n = a.rec_cap;
+    }
+    if (threadIdx.x == 0) {
+        long long base = (long long)atomicAdd(&a.counters[0], (unsigned long long)n);
+        if (base + n > a.pool_cap) {
+            atomicOr(&a.counters[2], kFlagRecOverflow);
+            base = -1;
+        }
+        *lds_base = (int)base;
+        a.rec_offset[s] = (int)base;
+        a.rec_count[s] = base < 0 ? 0 : n;
+    }
+    __syncthreads();
+    const int base = *lds_base;
+    if (base < 0) return;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int rank, shadow;
+        rank_and_shadow(i, n, l.rec, l.ts_us, l.dur_us, a.dp.cal_db, &rank, &shadow);
+        rt_record out = l.rec[i];
+        out.shadowed = shadow;
+        a.records[(int64_t)base + rank] = out;
+    }
+}
+
+__device__ __forceinline__ RecLds carve_rec_lds(unsigned char *&ptr, int rec_cap) {
+    RecLds l;
+    l.ts_us = reinterpret_cast<long long *>(ptr);
+    ptr += sizeof(long long) * rec_cap;
+    l.dur_us = reinterpret_cast<long long *>(ptr);
+    ptr += sizeof(long long) * rec_cap;
+    l.rec = reinterpret_cast<rt_record *>(ptr);
+    ptr += sizeof(rt_record) * rec_cap;
+    l.count = reinterpret_cast<int *>(ptr);
+    ptr += 16;
+    return l;
+}
+
+// One workgroup per stream.  Dynamic LDS: records | avg[F] | keys[cap2] | vals[cap2]
+__global__ __launch_bounds__(kBlock) void detect_sparse(const DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int F = a.n_bins;
+    const int T = a.dp.n_seg;
+
+    unsigned char *ptr = smem;
+    RecLds l = carve_rec_lds(ptr, a.rec_cap);
+    int *lds_base = l.count + 1;
+    float *avg = reinterpret_cast<float *>(ptr);
+    ptr += sizeof(float) * ((F + 3) & ~3);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(ptr);
+
+    const uint32_t n_raw = a.hot_count[s];
+    if (tid == 0) {
+        *l.count = 0;
+        atomicAdd(&a.counters[1], (unsigned long long)n_raw);
+    }
+    if (n_raw > (uint32_t)a.hot_cap) {
+        if (tid == 0) {
+            atomicOr(&a.counters[2], kFlagHotOverflow);
+            a.rec_offset[s] = 0;
+            a.rec_count[s] = 0;
+        }
+        return;
+    }
+    const int n = (int)n_raw;
+    if (n == 0) {
+        if (tid == 0) {
+            a.rec_offset[s] = 0;
+            a.rec_count[s] = 0;
+        }
+        return;
+    }
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    float *vals = reinterpret_cast<float *>(keys + n2);
+
+    // row means: np.mean(row) (analyze.py:375) from the scan's partial sums
+    for (int f = tid; f < F; f += kBlock) {
+        double sum = 0.0;
+        const float *ps = a.psum + (int64_t)s * a.chunks * F + f;
+        for (int c = 0; c < a.chunks; ++c) sum += (double)ps[(int64_t)c * F];
+        avg[f] = (float)sum / (float)T;
+    }
+    for (int i = tid; i < n2; i += kBlock) {
+        if (i < n) {
+            const uint2 e = a.hot[(int64_t)s * a.hot_cap + i];
+            keys[i] = e.x;
+            vals[i] = __uint_as_float(e.y);
+        } else {
+            keys[i] = 0xFFFFFFFFu;
+            vals[i] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    // bitonic sort by key (keys are unique: one entry per cell)
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += kBlock) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = ((i & k) == 0);
+                    const uint32_t ki = keys[i], kj = keys[ixj];
+                    if ((ki > kj) == up) {
+                        keys[i] = kj;
+                        keys[ixj] = ki;
+                        const float t = vals[i];
+                        vals[i] = vals[ixj];
+                        vals[ixj] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    const DetectParams &dp = a.dp;
+    for (int i = tid; i < n; i += kBlock) {
+        const uint32_t key = keys[i];
+        const int fi = (int)(key / (uint32_t)T);
+        const int b = (int)(key - (uint32_t)fi * (uint32_t)T);
+        const float av = avg[fi];
+        if (!cell_above(vals[i], av, dp.thr, dp.snr)) continue;
+        if (i > 0 && b > 0 && keys[i - 1] == key - 1 && cell_above(vals[i - 1], av, dp.thr, dp.snr)) continue;
+        // i starts a maximal run [b, e)
+        int j = i;
+        while (j + 1 < n && keys[j + 1] == keys[j] + 1 && (b + (j + 1 - i)) < T &&
+               cell_above(vals[j + 1], av, dp.thr, dp.snr))
+            ++j;
+        const int e = b + (j - i) + 1;
+        if (b > 0 && (i == 0 || keys[i - 1] != key - 1)) {
+            // the cell before a run must have been emitted by the scan (T11)
+            atomicOr(&a.counters[2], kFlagInconsistent);
+            continue;
+        }
+        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
+        auto cur = [&](int t) -> float { return vals[i + (t - b)]; };
+        auto emit = [&](int start, int end, const RunStats &st) { push_record(a, l, s, fi, start, end, st, av); };
+        finish_run(dp, b, e, av, cur, prev, emit);
+    }
+    publish_records(a, l, s, lds_base);
+}
+
+// One workgroup per stream, one thread per bin (strided), sequential in time:
+// the reference's row scan (analyze.py:357-450) in its run-based form.
+__global__ __launch_bounds__(kBlock) void detect_dense(const DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int F = a.n_bins;
+    const int T = a.dp.n_seg;
+    unsigned char *ptr = smem;
+    RecLds l = carve_rec_lds(ptr, a.rec_cap);
+    int *lds_base = l.count + 1;
+    if (tid == 0) *l.count = 0;
+    __syncthreads();
+
+    const DetectParams &dp = a.dp;
+    const float *sp = a.spec + (int64_t)s * T * F;
+    for (int fi = tid; fi < F; fi += kBlock) {
+        const float *row = sp + fi;
+        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
+        auto cur = [&](int t) -> float { return row[(int64_t)t * F]; };
+        float av = 0.f;
+        auto emit = [&](int start, int end, const RunStats &st) { push_record(a, l, s, fi, start, end, st, av); };
+        scan_dense_row(dp, cur, prev, &av, emit);
+    }
+    publish_records(a, l, s, lds_base);
+}
+
+}  // namespace rt
+#endif
