@@ -517,6 +517,7 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
         a.prev = last_dev;
         a.prev_cols = last_dev ? n_seg_last : 0;
         a.spec = spec_dev;
+        a.psum = nullptr;  // caller-supplied map: the kernel sums the rows itself
         if (h->timing) RT_HIP(h, hipEventRecord(h->ev[0], h->stream));
         if (h->timing) RT_HIP(h, hipEventRecord(h->ev[1], h->stream));
         hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kBlock), h->lds_dense, h->stream, a);

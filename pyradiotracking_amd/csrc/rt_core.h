@@ -200,8 +200,9 @@ RT_HD void finish_run(const DetectParams &p, int32_t b, int32_t e, float avg, Cu
 
 // Sequential scan of one bin's row of a dense spectrogram (analyze.py:357-450).
 // Returns false when no cell reaches the absolute threshold (row mean unused).
+// `row_sum` < 0 means "not known": the row is summed here.
 template <class Cur, class Prev, class Emit>
-RT_HD bool scan_dense_row(const DetectParams &p, Cur cur, Prev prev, float *avg_out, Emit emit) {
+RT_HD bool scan_dense_row(const DetectParams &p, Cur cur, Prev prev, double row_sum, float *avg_out, Emit emit) {
     const int32_t T = p.n_seg;
     double sum = 0.0;
     bool any = false;
@@ -211,6 +212,7 @@ RT_HD bool scan_dense_row(const DetectParams &p, Cur cur, Prev prev, float *avg_
         any |= !(v < p.thr);
     }
     if (!any) return false;
+    if (row_sum >= 0.0) sum = row_sum;
     const float avg = (float)sum / (float)T;  // np.mean(row) (analyze.py:375)
     *avg_out = avg;
     int32_t b = -1;

@@ -67,7 +67,7 @@ int hc_extract(const float *spec, int n_seg, int n_bins, const float *last, int 
             ts.push_back(timedelta_us(start_time(p, start)));
             du.push_back(timedelta_us(run_duration(p, start, end)));
         };
-        scan_dense_row(p, cur, prev, &avg, emit);
+        scan_dense_row(p, cur, prev, -1.0, &avg, emit);
     }
     const int n = (int)rec.size();
     std::vector<rt_record> ordered(n);

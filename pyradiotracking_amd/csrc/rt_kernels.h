@@ -520,7 +520,13 @@ __global__ __launch_bounds__(kBlock) void detect_dense(const DetectArgs a) {
         auto cur = [&](int t) -> float { return row[(int64_t)t * F]; };
         float av = 0.f;
         auto emit = [&](int start, int end, const RunStats &st) { push_record(a, l, s, fi, start, end, st, av); };
-        scan_dense_row(dp, cur, prev, &av, emit);
+        double row_sum = -1.0;
+        if (a.psum) {  // same partial sums (and bits) as the sparse path
+            row_sum = 0.0;
+            const float *ps = a.psum + (int64_t)s * a.chunks * F + fi;
+            for (int c = 0; c < a.chunks; ++c) row_sum += (double)ps[(int64_t)c * F];
+        }
+        scan_dense_row(dp, cur, prev, row_sum, &av, emit);
     }
     publish_records(a, l, s, lds_base);
 }
