@@ -46,6 +46,7 @@ def build_library(force=False, verbose=False):
         "--offload-arch=gfx950",
         "-shared",
         "-fPIC",
+        "-ffp-contract=off",
         "-Wno-unused-value",
         "-I" + os.path.join(REPO, "include"),
         "-o",

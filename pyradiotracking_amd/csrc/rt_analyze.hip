@@ -228,7 +228,7 @@ int enqueue_analysis(rt_handle *h, bool dense) {
     DetectArgs a = make_detect_args(h, c.n_seg, h->N, c.n_seg_last);
     a.prev = h->d_tail[c.tail_read];
     a.prev_cols = h->K;
-    a.chunks = sp.chunks;
+    a.chunks = sp.blocks_per_stream;
     a.spec = h->d_spec;
     if (dense)
         hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kBlock), h->lds_dense, h->stream, a);
@@ -330,6 +330,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->max_seg = (int)(cfg->max_samples / h->N);
     h->L = choose_chunk(h, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
+    const int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
     if ((int64_t)h->max_seg * h->N > 0xFFFFFFFFll) {
         delete h;
         return fail_create(RT_E_UNSUPPORTED, "max_samples too large for 32-bit cell keys");
@@ -380,7 +381,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     RT_CREATE_HIP(hipMemcpy(h->d_tw1, tw1.data(), sizeof(cf) * tw1.size(), hipMemcpyHostToDevice));
     RT_CREATE_HIP(hipMemcpy(h->d_tw2, tw2.data(), sizeof(cf) * tw2.size(), hipMemcpyHostToDevice));
 
-    const size_t psum_bytes = (size_t)S * h->max_chunks * N * sizeof(float);
+    const size_t psum_bytes = (size_t)S * max_blocks_per_stream * N * sizeof(float);
     const size_t tail_bytes = (size_t)S * h->K * N * sizeof(float);
     RT_CREATE_HIP(hipMalloc(&h->d_psum, std::max<size_t>(psum_bytes, 4)));
     RT_CREATE_HIP(hipMalloc(&h->d_tail[0], tail_bytes));

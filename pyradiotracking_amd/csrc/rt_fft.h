@@ -14,8 +14,10 @@ struct cf {
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+// Contraction is spelled out (the library is built with -ffp-contract=off) so
+// every instantiation of the scan kernel computes bit-identical spectra.
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-    return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    return cf{__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
 }
 // multiply by -i  (forward-transform quarter turn): (x + iy)(-i) = y - ix
 __device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }

@@ -51,7 +51,7 @@ struct StftParams {
     const cf *tw2;           // [R3][16]   W_LG^(b*q1)
     float scale;
     float thr;
-    float *psum;             // [S][chunks][N] partial row sums
+    float *psum;             // [S][blocks_per_stream][N] partial row sums (one row per workgroup)
     float *tail;             // [S][K][N] trailing K columns (written)
     float *spec;             // MODE 1/2: [S][T][N]
     uint2 *hot;              // MODE 0: [S][hot_cap] (key = bin*T + t, bits of P)
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
         // |X|^2 * scale  (scipy _spectral_py.py:2126-2128)
         float P[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[r] = (v[r].x * v[r].x + v[r].y * v[r].y) * p.scale;
+        for (int r = 0; r < 16; ++r) P[r] = __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y) * p.scale;
 
         if (active && !halo) {
 #pragma unroll
@@ -273,10 +273,21 @@ __global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
     }
 
     if constexpr (MODE != 2) {
-        if (chunk_ok) {
-            float *dst = p.psum + ((int64_t)s * p.chunks + chunk) * N;
+        // deterministic workgroup reduction of the lane groups' row sums: one
+        // partial row per workgroup (fixed summation order, no float atomics)
+        __syncthreads();
+        float *part = reinterpret_cast<float *>(xch);  // [GPW][N] floats = 16 KiB
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[bin_of<R3>(lt, r)] = acc[r];
+        for (int r = 0; r < 16; ++r) part[g * N + bin_of<R3>(lt, r)] = chunk_ok ? acc[r] : 0.f;
+        __syncthreads();
+        float *dst = p.psum + ((int64_t)s * p.blocks_per_stream + cb) * N;
+#pragma unroll
+        for (int j = 0; j < R3; ++j) {
+            const int bin = tid + kBlock * j;
+            float sum = 0.f;
+#pragma unroll
+            for (int gg = 0; gg < GPW; ++gg) sum += part[gg * N + bin];
+            dst[bin] = sum;
         }
     }
 }
@@ -295,8 +306,8 @@ struct DetectArgs {
     const uint2 *hot;
     const uint32_t *hot_count;
     int32_t hot_cap;
-    const float *psum;         // [S][chunks][F]
-    int32_t chunks;
+    const float *psum;         // [S][chunks][F] partial row sums
+    int32_t chunks;            // partial rows per stream
     // dense input
     const float *spec;         // [S][T][F]
     // outputs
