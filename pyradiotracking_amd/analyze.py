@@ -180,6 +180,7 @@ class BatchSignalAnalyzer:
         )
         self._decoder = _RecordDecoder(fft_nperseg, sample_rate, center_freq, calibration_db)
         self.gpu = gpu
+        self._hip_stream = hip_stream
 
     # -- native plumbing ----------------------------------------------------
     @property
@@ -218,6 +219,12 @@ class BatchSignalAnalyzer:
         if iq.shape[0] != len(self.devices) or iq.stride(1) != 1:
             raise ValueError("device IQ must be [S, B] with unit sample stride")
         self._keep = iq
+        if self._hip_stream is None:
+            # the handle launches on its own stream: whatever torch still has in flight on
+            # the producing stream must have landed before the scan kernel reads the IQ
+            import torch
+
+            torch.cuda.current_stream(iq.device).synchronize()
         self._native.process_device(iq.data_ptr(), iq.shape[1], iq.stride(0) if iq.shape[0] > 1 else iq.shape[1])
 
     def fetch_records(self) -> np.ndarray:

@@ -231,9 +231,9 @@ int enqueue_analysis(rt_handle *h, bool dense) {
     a.chunks = sp.blocks_per_stream;
     a.spec = h->d_spec;
     if (dense)
-        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kBlock), h->lds_dense, h->stream, a);
+        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->stream, a);
     else
-        hipLaunchKernelGGL(detect_sparse, dim3(h->cfg.n_streams), dim3(kBlock), h->lds_sparse, h->stream, a);
+        hipLaunchKernelGGL(detect_sparse, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_sparse, h->stream, a);
     RT_HIP(h, hipGetLastError());
     if (h->timing) RT_HIP(h, hipEventRecord(h->ev[2], h->stream));
     return enqueue_readback(h);
@@ -336,7 +336,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         return fail_create(RT_E_UNSUPPORTED, "max_samples too large for 32-bit cell keys");
     }
     h->lds_dense = rec_lds_bytes(h->rec_cap);
-    h->lds_sparse = rec_lds_bytes(h->rec_cap) + sizeof(float) * ((h->N + 3) & ~3) + (size_t)next_pow2(h->hot_cap) * 8;
+    h->lds_sparse = rec_lds_bytes(h->rec_cap) + sizeof(float) * ((h->N + 3) & ~3) + (size_t)next_pow2(h->hot_cap) * 9;
     if (h->lds_sparse > 160 * 1024 || h->lds_dense > 160 * 1024) {
         delete h;
         return fail_create(RT_E_INVALID, "hot_capacity/record_capacity do not fit the 160 KiB LDS of a CU");
@@ -521,7 +521,7 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
         a.psum = nullptr;  // caller-supplied map: the kernel sums the rows itself
         if (h->timing) RT_HIP(h, hipEventRecord(h->ev[0], h->stream));
         if (h->timing) RT_HIP(h, hipEventRecord(h->ev[1], h->stream));
-        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kBlock), h->lds_dense, h->stream, a);
+        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->stream, a);
         RT_HIP(h, hipGetLastError());
         if (h->timing) RT_HIP(h, hipEventRecord(h->ev[2], h->stream));
     }

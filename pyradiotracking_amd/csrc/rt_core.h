@@ -131,28 +131,50 @@ struct RunStats {
 
 RT_HD float db10(float v) { return 10.0f * log10f(v); }
 
+// Canonical summation order (so the wave-cooperative device code, the dense
+// kernel and the host check agree bit for bit): 64 interleaved partial sums
+// (cell k goes to partial k mod 64, in k order), folded by halving
+// (p[l] += p[l + off], off = 32, 16, ... 1).  Sums run in float64 over the
+// float32 values np.mean / np.std see; np.max propagates NaN.
+constexpr int kStatLanes = 64;
+
 template <class Cell>
 RT_HD RunStats run_stats(int32_t n, Cell cell) {
-    RunStats r;
-    float mx = cell(0);
-    double sum = 0.0, sum_db = 0.0;
-    for (int32_t i = 0; i < n; ++i) {
-        float v = cell(i);
-        if (!(mx != mx)) {          // NaN sticks, as in np.max
-            if (v != v || v > mx) mx = v;
+    double ps[kStatLanes], pd[kStatLanes];
+    float pm[kStatLanes];
+    bool any_nan = false;
+    for (int l = 0; l < kStatLanes; ++l) {
+        ps[l] = 0.0;
+        pd[l] = 0.0;
+        pm[l] = -INFINITY;
+    }
+    for (int32_t k = 0; k < n; ++k) {
+        const int l = k & (kStatLanes - 1);
+        const float v = cell(k);
+        ps[l] += (double)v;
+        pd[l] += (double)db10(v);
+        if (v != v) any_nan = true;
+        if (v > pm[l]) pm[l] = v;
+    }
+    for (int off = kStatLanes / 2; off > 0; off >>= 1)
+        for (int l = 0; l < off; ++l) {
+            ps[l] += ps[l + off];
+            pd[l] += pd[l + off];
+            if (pm[l + off] > pm[l]) pm[l] = pm[l + off];
         }
-        sum += (double)v;
-        sum_db += (double)db10(v);
+    const double mean_db = pd[0] / (double)n;
+    double pa[kStatLanes];
+    for (int l = 0; l < kStatLanes; ++l) pa[l] = 0.0;
+    for (int32_t k = 0; k < n; ++k) {
+        const double d = (double)db10(cell(k)) - mean_db;
+        pa[k & (kStatLanes - 1)] += d * d;
     }
-    const double mean_db = sum_db / (double)n;
-    double acc = 0.0;
-    for (int32_t i = 0; i < n; ++i) {
-        double d = (double)db10(cell(i)) - mean_db;
-        acc += d * d;
-    }
-    r.max_p = mx;
-    r.mean_p = (float)(sum / (double)n);
-    r.std_db = (float)sqrt(acc / (double)n);
+    for (int off = kStatLanes / 2; off > 0; off >>= 1)
+        for (int l = 0; l < off; ++l) pa[l] += pa[l + off];
+    RunStats r;
+    r.max_p = any_nan ? NAN : pm[0];
+    r.mean_p = (float)(ps[0] / (double)n);
+    r.std_db = (float)sqrt(pa[0] / (double)n);
     return r;
 }
 
@@ -179,18 +201,27 @@ RT_HD int64_t timedelta_us(double seconds) {
 }
 
 // A maximal run [b, e) of above-cells of the current buffer -> at most one
-// plateau (analyze.py:401-447 in run-based form).
-// `cur(t)` reads the bin's cell t >= 0, `prev(d)` the previous buffer's cell
-// n_seg_last - d, `emit(start, end, stats)` receives the result.
+// plateau (analyze.py:401-433 in run-based form): the
+// cheap decisions.  `prev(d)` reads the previous buffer's cell n_seg_last - d.
+// Returns true and the first cell of `data` if the run becomes a signal.
+template <class Prev>
+RT_HD bool gate_run(const DetectParams &p, int32_t b, int32_t e, float avg, Prev prev, int32_t *start_out) {
+    if (e == p.n_seg) return false;  // laps into the next buffer (analyze.py:415)
+    const int32_t ti0 = first_probe_in_run(b, e, p.stride);
+    if (ti0 < 0) return false;       // no strided probe lands in the run (T9)
+    const StartWalk sw = walk_start(p, b, ti0, avg, prev);
+    if (sw.too_long) return false;
+    if (!duration_ok(p, run_duration(p, sw.start, e))) return false;
+    *start_out = sw.start;
+    return true;
+}
+
+// gate + statistics for one run, sequentially (host check; the kernels gate
+// per thread and compute the statistics wave-cooperatively in the same order)
 template <class Cur, class Prev, class Emit>
 RT_HD void finish_run(const DetectParams &p, int32_t b, int32_t e, float avg, Cur cur, Prev prev, Emit emit) {
-    if (e == p.n_seg) return;  // laps into the next buffer (analyze.py:415)
-    const int32_t ti0 = first_probe_in_run(b, e, p.stride);
-    if (ti0 < 0) return;       // no strided probe lands in the run (T9)
-    const StartWalk sw = walk_start(p, b, ti0, avg, prev);
-    if (sw.too_long) return;
-    if (!duration_ok(p, run_duration(p, sw.start, e))) return;
-    const int32_t start = sw.start;
+    int32_t start;
+    if (!gate_run(p, b, e, avg, prev, &start)) return;
     auto cell = [&](int32_t k) -> float {
         const int32_t t = start + k;
         return t < 0 ? prev(-t) : cur(t);
@@ -198,11 +229,12 @@ RT_HD void finish_run(const DetectParams &p, int32_t b, int32_t e, float avg, Cu
     emit(start, e, run_stats(e - start, cell));
 }
 
-// Sequential scan of one bin's row of a dense spectrogram (analyze.py:357-450).
-// Returns false when no cell reaches the absolute threshold (row mean unused).
+// Sequential scan of one bin's row of a dense spectrogram (analyze.py:357-450):
+// calls on_run(b, e, avg) for every maximal run of above-cells.  Returns false
+// when no cell reaches the absolute threshold (the row mean is then unused).
 // `row_sum` < 0 means "not known": the row is summed here.
-template <class Cur, class Prev, class Emit>
-RT_HD bool scan_dense_row(const DetectParams &p, Cur cur, Prev prev, double row_sum, float *avg_out, Emit emit) {
+template <class Cur, class OnRun>
+RT_HD bool scan_dense_row(const DetectParams &p, Cur cur, double row_sum, float *avg_out, OnRun on_run) {
     const int32_t T = p.n_seg;
     double sum = 0.0;
     bool any = false;
@@ -225,7 +257,7 @@ RT_HD bool scan_dense_row(const DetectParams &p, Cur cur, Prev prev, double row_
         if (b < 0) continue;
         const int32_t rb = b;
         b = -1;
-        finish_run(p, rb, t, avg, cur, prev, emit);
+        on_run(rb, t, avg);
     }
     return true;
 }

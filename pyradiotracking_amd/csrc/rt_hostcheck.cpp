@@ -67,7 +67,11 @@ int hc_extract(const float *spec, int n_seg, int n_bins, const float *last, int 
             ts.push_back(timedelta_us(start_time(p, start)));
             du.push_back(timedelta_us(run_duration(p, start, end)));
         };
-        scan_dense_row(p, cur, prev, -1.0, &avg, emit);
+        auto on_run = [&](int b, int e, float av) {
+            avg = av;
+            finish_run(p, b, e, av, cur, prev, emit);
+        };
+        scan_dense_row(p, cur, -1.0, &avg, on_run);
     }
     const int n = (int)rec.size();
     std::vector<rt_record> ordered(n);

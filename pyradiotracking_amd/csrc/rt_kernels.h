@@ -295,6 +295,8 @@ __global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
 // ---------------------------------------------------------------------------
 // detection
 // ---------------------------------------------------------------------------
+constexpr int kDetBlock = 1024;  // 16 waves: one stream per workgroup
+
 struct DetectArgs {
     DetectParams dp;
     int32_t n_streams;
@@ -334,60 +336,8 @@ struct RecLds {
     rt_record *rec;       // [rec_cap]
     long long *ts_us;     // [rec_cap]
     long long *dur_us;    // [rec_cap]
-    int *count;           // [1]
+    int *count;           // [1] (+ scratch words)
 };
-
-__device__ __forceinline__ void push_record(const DetectArgs &a, RecLds &l, int s, int fi, int start, int end,
-                                            const RunStats &st, float avg) {
-    const int idx = atomicAdd(l.count, 1);
-    if (idx < a.rec_cap) {
-        rt_record r;
-        r.stream = s;
-        r.fi = fi;
-        r.start = start;
-        r.end = end;
-        r.max_p = st.max_p;
-        r.mean_p = st.mean_p;
-        r.std_db = st.std_db;
-        r.row_mean = avg;
-        r.shadowed = 0;
-        r.reserved = 0;
-        l.rec[idx] = r;
-        l.ts_us[idx] = timedelta_us(start_time(a.dp, start));
-        l.dur_us[idx] = timedelta_us(run_duration(a.dp, start, end));
-    }
-}
-
-// order the stream's records by (fi, start), apply the shadow filter against
-// the unfiltered list (analyze.py:325) and publish them.
-__device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int *lds_base) {
-    __syncthreads();
-    int n = *l.count;
-    if (n > a.rec_cap) {
-        if (threadIdx.x == 0) atomicOr(&a.counters[2], kFlagRecOverflow);
-        n = a.rec_cap;
-    }
-    if (threadIdx.x == 0) {
-        long long base = (long long)atomicAdd(&a.counters[0], (unsigned long long)n);
-        if (base + n > a.pool_cap) {
-            atomicOr(&a.counters[2], kFlagRecOverflow);
-            base = -1;
-        }
-        *lds_base = (int)base;
-        a.rec_offset[s] = (int)base;
-        a.rec_count[s] = base < 0 ? 0 : n;
-    }
-    __syncthreads();
-    const int base = *lds_base;
-    if (base < 0) return;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int rank, shadow;
-        rank_and_shadow(i, n, l.rec, l.ts_us, l.dur_us, a.dp.cal_db, &rank, &shadow);
-        rt_record out = l.rec[i];
-        out.shadowed = shadow;
-        a.records[(int64_t)base + rank] = out;
-    }
-}
 
 __device__ __forceinline__ RecLds carve_rec_lds(unsigned char *&ptr, int rec_cap) {
     RecLds l;
@@ -402,8 +352,111 @@ __device__ __forceinline__ RecLds carve_rec_lds(unsigned char *&ptr, int rec_cap
     return l;
 }
 
-// One workgroup per stream.  Dynamic LDS: records | avg[F] | keys[cap2] | vals[cap2]
-__global__ __launch_bounds__(kBlock) void detect_sparse(const DetectArgs a) {
+// phase 1: a gated run becomes a record without statistics; `cell_off` tells
+// phase 2 where the run's cells are (sparse: index offset into the sorted list)
+__device__ __forceinline__ void push_candidate(const DetectArgs &a, RecLds &l, int s, int fi, int start, int end,
+                                               float avg, int cell_off) {
+    const int idx = atomicAdd(l.count, 1);
+    if (idx < a.rec_cap) {
+        rt_record r;
+        r.stream = s;
+        r.fi = fi;
+        r.start = start;
+        r.end = end;
+        r.max_p = 0.f;
+        r.mean_p = 0.f;
+        r.std_db = 0.f;
+        r.row_mean = avg;
+        r.shadowed = 0;
+        r.reserved = cell_off;
+        l.rec[idx] = r;
+        l.ts_us[idx] = timedelta_us(start_time(a.dp, start));
+        l.dur_us[idx] = timedelta_us(run_duration(a.dp, start, end));
+    }
+}
+
+// phase 2: np.max / np.mean / np.std(dB(.)) of one plateau by one wave, in the
+// canonical order of rt::run_stats (64 interleaved partials, halving fold).
+template <class Cell>
+__device__ __forceinline__ RunStats run_stats_wave(int n, Cell cell) {
+    const int lane = threadIdx.x & 63;
+    double ps = 0.0, pd = 0.0;
+    float pm = -INFINITY;
+    int any_nan = 0;
+    for (int k = lane; k < n; k += 64) {
+        const float v = cell(k);
+        ps += (double)v;
+        pd += (double)db10(v);
+        if (v != v) any_nan = 1;
+        if (v > pm) pm = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ps += __shfl_xor(ps, off, 64);
+        pd += __shfl_xor(pd, off, 64);
+        const float o = __shfl_xor(pm, off, 64);
+        if (o > pm) pm = o;
+        any_nan |= __shfl_xor(any_nan, off, 64);
+    }
+    ps = __shfl(ps, 0, 64);
+    pd = __shfl(pd, 0, 64);
+    pm = __shfl(pm, 0, 64);
+    const double mean_db = pd / (double)n;
+    double pa = 0.0;
+    for (int k = lane; k < n; k += 64) {
+        const double d = (double)db10(cell(k)) - mean_db;
+        pa += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pa += __shfl_xor(pa, off, 64);
+    pa = __shfl(pa, 0, 64);
+    RunStats r;
+    r.max_p = any_nan ? NAN : pm;
+    r.mean_p = (float)(ps / (double)n);
+    r.std_db = (float)sqrt(pa / (double)n);
+    return r;
+}
+
+// order the stream's records by (fi, start), apply the shadow filter against
+// the unfiltered list (analyze.py:325) and publish them.
+__device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int n) {
+    int *lds_base = l.count + 1;
+    if (threadIdx.x == 0) {
+        long long base = (long long)atomicAdd(&a.counters[0], (unsigned long long)n);
+        if (base + n > a.pool_cap) {
+            atomicOr(&a.counters[2], kFlagRecOverflow);
+            base = -1;
+        }
+        *lds_base = (int)base;
+        a.rec_offset[s] = base < 0 ? 0 : (int)base;
+        a.rec_count[s] = base < 0 ? 0 : n;
+    }
+    __syncthreads();
+    const int base = *lds_base;
+    if (base < 0) return;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int rank, shadow;
+        rank_and_shadow(i, n, l.rec, l.ts_us, l.dur_us, a.dp.cal_db, &rank, &shadow);
+        rt_record out = l.rec[i];
+        out.shadowed = shadow;
+        out.reserved = 0;
+        a.records[(int64_t)base + rank] = out;
+    }
+}
+
+// clamp the candidate count after phase 1 (all threads), flag truncation
+__device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
+    __syncthreads();
+    int n = *l.count;
+    if (n > a.rec_cap) {
+        if (threadIdx.x == 0) atomicOr(&a.counters[2], kFlagRecOverflow);
+        n = a.rec_cap;
+    }
+    return n;
+}
+
+// One workgroup per stream.  Dynamic LDS: records | avg[F] | keys[n2] | vals[n2] | above[n2]
+__global__ __launch_bounds__(kDetBlock) void detect_sparse(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -412,7 +465,6 @@ __global__ __launch_bounds__(kBlock) void detect_sparse(const DetectArgs a) {
 
     unsigned char *ptr = smem;
     RecLds l = carve_rec_lds(ptr, a.rec_cap);
-    int *lds_base = l.count + 1;
     float *avg = reinterpret_cast<float *>(ptr);
     ptr += sizeof(float) * ((F + 3) & ~3);
     uint32_t *keys = reinterpret_cast<uint32_t *>(ptr);
@@ -422,34 +474,28 @@ __global__ __launch_bounds__(kBlock) void detect_sparse(const DetectArgs a) {
         *l.count = 0;
         atomicAdd(&a.counters[1], (unsigned long long)n_raw);
     }
-    if (n_raw > (uint32_t)a.hot_cap) {
+    if (n_raw > (uint32_t)a.hot_cap || n_raw == 0) {
         if (tid == 0) {
-            atomicOr(&a.counters[2], kFlagHotOverflow);
+            if (n_raw) atomicOr(&a.counters[2], kFlagHotOverflow);
             a.rec_offset[s] = 0;
             a.rec_count[s] = 0;
         }
         return;
     }
     const int n = (int)n_raw;
-    if (n == 0) {
-        if (tid == 0) {
-            a.rec_offset[s] = 0;
-            a.rec_count[s] = 0;
-        }
-        return;
-    }
     int n2 = 1;
     while (n2 < n) n2 <<= 1;
     float *vals = reinterpret_cast<float *>(keys + n2);
+    unsigned char *above = reinterpret_cast<unsigned char *>(vals + n2);
 
     // row means: np.mean(row) (analyze.py:375) from the scan's partial sums
-    for (int f = tid; f < F; f += kBlock) {
+    for (int f = tid; f < F; f += kDetBlock) {
         double sum = 0.0;
         const float *ps = a.psum + (int64_t)s * a.chunks * F + f;
         for (int c = 0; c < a.chunks; ++c) sum += (double)ps[(int64_t)c * F];
         avg[f] = (float)sum / (float)T;
     }
-    for (int i = tid; i < n2; i += kBlock) {
+    for (int i = tid; i < n2; i += kDetBlock) {
         if (i < n) {
             const uint2 e = a.hot[(int64_t)s * a.hot_cap + i];
             keys[i] = e.x;
@@ -464,18 +510,18 @@ __global__ __launch_bounds__(kBlock) void detect_sparse(const DetectArgs a) {
     // bitonic sort by key (keys are unique: one entry per cell)
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += kBlock) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool up = ((i & k) == 0);
-                    const uint32_t ki = keys[i], kj = keys[ixj];
-                    if ((ki > kj) == up) {
-                        keys[i] = kj;
-                        keys[ixj] = ki;
-                        const float t = vals[i];
-                        vals[i] = vals[ixj];
-                        vals[ixj] = t;
-                    }
+            for (int t = tid; t < (n2 >> 1); t += kDetBlock) {
+                // t-th compare-exchange pair of this step: i has bit j clear
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const bool up = ((i & k) == 0);
+                const uint32_t ki = keys[i], kj = keys[ixj];
+                if ((ki > kj) == up) {
+                    keys[i] = kj;
+                    keys[ixj] = ki;
+                    const float tv = vals[i];
+                    vals[i] = vals[ixj];
+                    vals[ixj] = tv;
                 }
             }
             __syncthreads();
@@ -483,35 +529,61 @@ __global__ __launch_bounds__(kBlock) void detect_sparse(const DetectArgs a) {
     }
 
     const DetectParams &dp = a.dp;
-    for (int i = tid; i < n; i += kBlock) {
+    // the predicate once per candidate cell (analyze.py:370, 378)
+    for (int i = tid; i < n; i += kDetBlock) {
+        const int fi = (int)(keys[i] / (uint32_t)T);
+        above[i] = cell_above(vals[i], avg[fi], dp.thr, dp.snr) ? 1 : 0;
+    }
+    __syncthreads();
+
+    // phase 1: maximal runs of above-cells -> gated candidates
+    const int max_len = dp.tail_cols + 2;  // anything longer fails the max-duration gate
+    for (int i = tid; i < n; i += kDetBlock) {
+        if (!above[i]) continue;
         const uint32_t key = keys[i];
         const int fi = (int)(key / (uint32_t)T);
         const int b = (int)(key - (uint32_t)fi * (uint32_t)T);
-        const float av = avg[fi];
-        if (!cell_above(vals[i], av, dp.thr, dp.snr)) continue;
-        if (i > 0 && b > 0 && keys[i - 1] == key - 1 && cell_above(vals[i - 1], av, dp.thr, dp.snr)) continue;
-        // i starts a maximal run [b, e)
+        if (i > 0 && b > 0 && keys[i - 1] == key - 1 && above[i - 1]) continue;  // not a run start
         int j = i;
-        while (j + 1 < n && keys[j + 1] == keys[j] + 1 && (b + (j + 1 - i)) < T &&
-               cell_above(vals[j + 1], av, dp.thr, dp.snr))
-            ++j;
+        while (j + 1 < n && (j - i) < max_len && keys[j + 1] == keys[j] + 1 && (b + (j + 1 - i)) < T && above[j + 1]) ++j;
+        if ((j - i) >= max_len) continue;  // longer than any admissible signal
         const int e = b + (j - i) + 1;
         if (b > 0 && (i == 0 || keys[i - 1] != key - 1)) {
             // the cell before a run must have been emitted by the scan (T11)
             atomicOr(&a.counters[2], kFlagInconsistent);
             continue;
         }
+        const float av = avg[fi];
         PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
-        auto cur = [&](int t) -> float { return vals[i + (t - b)]; };
-        auto emit = [&](int start, int end, const RunStats &st) { push_record(a, l, s, fi, start, end, st, av); };
-        finish_run(dp, b, e, av, cur, prev, emit);
+        int start;
+        if (gate_run(dp, b, e, av, prev, &start)) push_candidate(a, l, s, fi, start, e, av, i - b);
     }
-    publish_records(a, l, s, lds_base);
+    const int nrec = settled_count(a, l);
+
+    // phase 2: statistics, one wave per candidate
+    for (int c = tid >> 6; c < nrec; c += kDetBlock / 64) {
+        rt_record &r = l.rec[c];
+        const int start = r.start, off = r.reserved;
+        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + r.fi, F};
+        auto cell = [&](int k) -> float {
+            const int t = start + k;
+            return t < 0 ? prev(-t) : vals[off + t];
+        };
+        const RunStats st = run_stats_wave(r.end - start, cell);
+        if ((tid & 63) == 0) {
+            r.max_p = st.max_p;
+            r.mean_p = st.mean_p;
+            r.std_db = st.std_db;
+        }
+    }
+    __syncthreads();
+    publish_records(a, l, s, nrec);
 }
 
-// One workgroup per stream, one thread per bin (strided), sequential in time:
-// the reference's row scan (analyze.py:357-450) in its run-based form.
-__global__ __launch_bounds__(kBlock) void detect_dense(const DetectArgs a) {
+// One workgroup per stream.  Phase 1: one thread per bin (strided) scans its
+// row sequentially in time -- the reference's row scan (analyze.py:357-450) in
+// run-based form.  Phase 2/3 as in detect_sparse.
+__global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -519,27 +591,48 @@ __global__ __launch_bounds__(kBlock) void detect_dense(const DetectArgs a) {
     const int T = a.dp.n_seg;
     unsigned char *ptr = smem;
     RecLds l = carve_rec_lds(ptr, a.rec_cap);
-    int *lds_base = l.count + 1;
     if (tid == 0) *l.count = 0;
     __syncthreads();
 
     const DetectParams &dp = a.dp;
     const float *sp = a.spec + (int64_t)s * T * F;
-    for (int fi = tid; fi < F; fi += kBlock) {
+    for (int fi = tid; fi < F; fi += kDetBlock) {
         const float *row = sp + fi;
         PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
         auto cur = [&](int t) -> float { return row[(int64_t)t * F]; };
-        float av = 0.f;
-        auto emit = [&](int start, int end, const RunStats &st) { push_record(a, l, s, fi, start, end, st, av); };
         double row_sum = -1.0;
         if (a.psum) {  // same partial sums (and bits) as the sparse path
             row_sum = 0.0;
             const float *ps = a.psum + (int64_t)s * a.chunks * F + fi;
             for (int c = 0; c < a.chunks; ++c) row_sum += (double)ps[(int64_t)c * F];
         }
-        scan_dense_row(dp, cur, prev, row_sum, &av, emit);
+        float av = 0.f;
+        auto on_run = [&](int b, int e, float avg) {
+            int start;
+            if (gate_run(dp, b, e, avg, prev, &start)) push_candidate(a, l, s, fi, start, e, avg, 0);
+        };
+        scan_dense_row(dp, cur, row_sum, &av, on_run);
     }
-    publish_records(a, l, s, lds_base);
+    const int nrec = settled_count(a, l);
+
+    for (int c = tid >> 6; c < nrec; c += kDetBlock / 64) {
+        rt_record &r = l.rec[c];
+        const int start = r.start;
+        const float *row = sp + r.fi;
+        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + r.fi, F};
+        auto cell = [&](int k) -> float {
+            const int t = start + k;
+            return t < 0 ? prev(-t) : row[(int64_t)t * F];
+        };
+        const RunStats st = run_stats_wave(r.end - start, cell);
+        if ((tid & 63) == 0) {
+            r.max_p = st.max_p;
+            r.mean_p = st.mean_p;
+            r.std_db = st.std_db;
+        }
+    }
+    __syncthreads();
+    publish_records(a, l, s, nrec);
 }
 
 }  // namespace rt
