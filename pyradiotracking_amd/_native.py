@@ -120,7 +120,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RT_ANALYZE_LIB") or LIB_PATH  # env override: A/B builds of the kernels
     if not os.path.exists(p):
         raise ImportError(
             f"{p} is missing: build it with `python -m pyradiotracking_amd.build` "

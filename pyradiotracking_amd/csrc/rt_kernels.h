@@ -108,8 +108,12 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
     }
 }
 
+#ifndef RT_SCAN_MIN_WAVES
+#define RT_SCAN_MIN_WAVES 1
+#endif
+
 template <int R3, int MODE>
-__global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
+__global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
     constexpr int N = 256 * R3;
     constexpr int LG = 16 * R3;
     constexpr int GPW = kBlock / LG;  // lane groups per workgroup
@@ -131,19 +135,31 @@ __global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
 
     cf *gx = xch + g * LG * kRowF2;  // this group's exchange rows
 
-    // per-lane constants: window and pass twiddles
-    float w[16];
-    cf t1[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        w[m] = p.window[lt + LG * m];
-        t1[m] = p.tw1[lt * 16 + m];
+    // window and pass twiddles staged in LDS, laid out in the order the lanes
+    // read them (16-byte pieces, consecutive lanes -> consecutive pieces), and
+    // read just in time: keeping them in VGPRs would cost 62 registers per lane
+    // and a wave per SIMD of occupancy.
+    __shared__ __attribute__((aligned(16))) float4 w_lds[4 * LG];    // [m/4][lane]: w[lane + LG*(4*(m/4) + 0..3)]
+    __shared__ __attribute__((aligned(16))) float4 t1_lds[8 * LG];   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
+    __shared__ __attribute__((aligned(16))) float4 t2_lds[R3 > 1 ? 8 * R3 : 1];  // [q/2][b]
+    for (int idx = tid; idx < 4 * LG; idx += kBlock) {
+        const int mm = idx / LG, l = idx % LG;
+        w_lds[idx] = make_float4(p.window[l + LG * (4 * mm)], p.window[l + LG * (4 * mm + 1)],
+                                 p.window[l + LG * (4 * mm + 2)], p.window[l + LG * (4 * mm + 3)]);
     }
-    cf t2[16];
+    for (int idx = tid; idx < 8 * LG; idx += kBlock) {
+        const int kk = idx / LG, l = idx % LG;
+        const cf a = p.tw1[l * 16 + 2 * kk], b = p.tw1[l * 16 + 2 * kk + 1];
+        t1_lds[idx] = make_float4(a.x, a.y, b.x, b.y);
+    }
     if constexpr (R3 > 1) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t2[q] = p.tw2[(lt % R3) * 16 + q];
+        for (int idx = tid; idx < 8 * R3; idx += kBlock) {
+            const int kk = idx / R3, b = idx % R3;
+            const cf x = p.tw2[b * 16 + 2 * kk], y = p.tw2[b * 16 + 2 * kk + 1];
+            t2_lds[idx] = make_float4(x.x, x.y, y.x, y.y);
+        }
     }
+    __syncthreads();
 
     float acc[16];
 #pragma unroll
@@ -153,16 +169,35 @@ __global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
     const cf *stream_iq = p.iq + (int64_t)s * p.stream_stride;
     const int i_first = (MODE == 0) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
 
+    // software pipeline: the 16 loads of the next segment are issued before the
+    // current one is transformed, so their HBM latency hides under ~700 VALU ops.
+    // Loads are unconditional (segment index clamped into the stream): lanes of
+    // idle groups / past-the-end steps read valid memory and discard it.
+    const int seg_hi = T - 1;
+    cf nxt[16];
+    {
+        int seg0 = c0 + L - i_first;
+        seg0 = seg0 < seg_hi ? seg0 : seg_hi;
+        const cf *src = stream_iq + (int64_t)seg0 * N + lt;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) nxt[m] = src[LG * m];
+    }
+
     for (int i = i_first; i <= L; ++i) {
         const int seg = c0 + L - i;
         const bool halo = (i == 0);
         const bool active = chunk_ok && seg < T;
 
         cf v[16];
-        {
-            const cf *src = stream_iq + (int64_t)seg * N + lt;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = active ? src[LG * m] : cf{0.f, 0.f};
+        for (int m = 0; m < 16; ++m) v[m] = nxt[m];
+        {
+            // next step's segment (the last step re-reads its own: harmless, keeps the loop uniform)
+            int seg1 = (i < L) ? seg - 1 : seg;
+            seg1 = seg1 < seg_hi ? seg1 : seg_hi;
+            const cf *src = stream_iq + (int64_t)seg1 * N + lt;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) nxt[m] = src[LG * m];
         }
 
         // detrend='constant': subtract the segment mean (scipy _signaltools.py:3926)
@@ -172,12 +207,22 @@ __global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
         sum = group_sum<LG>(sum, red);
         const cf mean = cscale(sum, 1.0f / (float)N);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = cscale(csub(v[m], mean), w[m]);
+        for (int mm = 0; mm < 4; ++mm) {
+            const float4 w4 = w_lds[mm * LG + lt];
+            v[4 * mm + 0] = cscale(csub(v[4 * mm + 0], mean), w4.x);
+            v[4 * mm + 1] = cscale(csub(v[4 * mm + 1], mean), w4.y);
+            v[4 * mm + 2] = cscale(csub(v[4 * mm + 2], mean), w4.z);
+            v[4 * mm + 3] = cscale(csub(v[4 * mm + 3], mean), w4.w);
+        }
 
         // pass 1
         dft16(v);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], t1[k]);
+        for (int kk = 0; kk < 8; ++kk) {
+            const float4 t = t1_lds[kk * LG + lt];
+            if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
+            v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
+        }
 
         // exchange 1: element (a = lt, k1) -> row k1*R3 + b, column c
         {
@@ -201,7 +246,11 @@ __global__ __launch_bounds__(kBlock) void stft_scan(const StftParams p) {
 
         if constexpr (R3 > 1) {
 #pragma unroll
-            for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], t2[q]);
+            for (int kk = 0; kk < 8; ++kk) {
+                const float4 t = t2_lds[kk * R3 + (lt % R3)];
+                if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
+                v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
+            }
             group_sync<LG>();  // everyone has read exchange 1
             {
                 const int k1 = lt / R3, b = lt % R3;
