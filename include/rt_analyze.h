@@ -153,6 +153,15 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
 int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride,
                    float *spec_dev);
 
+/*
+ * Profiling aid: launches the scan kernel's load stream only (same grid, same
+ * addresses, same prefetch; no arithmetic, no stores).  Its byte count is
+ * known exactly -- S * (T + one halo segment per chunk) * nperseg * 8 -- so a
+ * rocprofv3 --pmc FETCH_SIZE pass over it calibrates the counter for this
+ * access shape (8-byte loads; MI355X_MICROARCH.md "HBM").  Synchronous.
+ */
+int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride);
+
 /* Per-call figures of the last rt_process (valid after rt_fetch). */
 typedef struct rt_call_info {
     int32_t n_seg;            /* T of the call                                           */

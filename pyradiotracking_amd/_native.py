@@ -94,6 +94,7 @@ ABI_SYMBOLS = (
     "rt_fetch",
     "rt_extract",
     "rt_spectrogram",
+    "rt_calibrate_read",
     "rt_get_call_info",
     "rt_last_error",
     "rt_dev_alloc",
@@ -142,6 +143,7 @@ def load_library(path: Optional[str] = None):
     lib.rt_fetch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.rt_extract.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, C.c_int32]
     lib.rt_spectrogram.argtypes = [vp, vp, C.c_int64, C.c_int64, vp]
+    lib.rt_calibrate_read.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_get_call_info.argtypes = [vp, C.POINTER(RtCallInfo)]
     lib.rt_last_error.argtypes = [vp]
     lib.rt_last_error.restype = C.c_char_p
@@ -320,6 +322,9 @@ class NativeAnalyzer:
 
     def spectrogram_device(self, iq_ptr: int, n_samples: int, stream_stride: int, out_ptr: int):
         self._check(self._lib.rt_spectrogram(self._handle, iq_ptr, n_samples, stream_stride, out_ptr))
+
+    def calibrate_read(self, iq_ptr: int, n_samples: int, stream_stride: int):
+        self._check(self._lib.rt_calibrate_read(self._handle, iq_ptr, n_samples, stream_stride))
 
     def call_info(self) -> RtCallInfo:
         info = RtCallInfo()

@@ -617,6 +617,22 @@ int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t 
     return RT_OK;
 }
 
+int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride) {
+    if (!h || !iq_dev) return RT_E_INVALID;
+    if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples) {
+        h->err = "n_samples/stream_stride out of range for this handle";
+        return RT_E_INVALID;
+    }
+    RT_HIP(h, hipSetDevice(h->cfg.device));
+    const int T = (int)(n_samples / h->N);
+    if (T < 2) return RT_OK;
+    StftParams sp = make_stft_params(h, iq_dev, stream_stride, T, 0);
+    launch_stft<3>(h, sp, h->cfg.n_streams * sp.blocks_per_stream);
+    RT_HIP(h, hipGetLastError());
+    RT_HIP(h, hipStreamSynchronize(h->stream));
+    return RT_OK;
+}
+
 int rt_get_call_info(rt_handle *h, rt_call_info *info) {
     if (!h || !info) return RT_E_INVALID;
     *info = h->info;

@@ -4,7 +4,8 @@
 //                         with per-bin partial row sums, the dense look-back
 //                         tail and either sparse candidate emission (MODE 0),
 //                         a dense spectrogram (MODE 1) or the spectrogram only
-//                         (MODE 2, debug).  Replaces scipy.signal.spectrogram
+//                         (MODE 2, debug; MODE 3 = loads only, for PMC traffic
+//                         calibration).  Replaces scipy.signal.spectrogram
 //                         as called at radiotracking/analyze.py:234-241.
 //   detect_sparse         per stream: finish row means, sort candidates,
 //                         plateau extraction + statistics + shadow filter.
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
 
     const cf *stream_iq = p.iq + (int64_t)s * p.stream_stride;
-    const int i_first = (MODE == 0) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
+    const int i_first = (MODE == 0 || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
 
     // software pipeline: the 16 loads of the next segment are issued before the
     // current one is transformed, so their HBM latency hides under ~700 VALU ops.
@@ -198,6 +199,13 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
             const cf *src = stream_iq + (int64_t)seg1 * N + lt;
 #pragma unroll
             for (int m = 0; m < 16; ++m) nxt[m] = src[LG * m];
+        }
+
+        if constexpr (MODE == 3) {
+            // traffic calibration: the scan's exact load stream, nothing else
+#pragma unroll
+            for (int m = 0; m < 16; ++m) acc[0] += v[m].x + v[m].y;
+            continue;
         }
 
         // detrend='constant': subtract the segment mean (scipy _signaltools.py:3926)
@@ -321,6 +329,10 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
         }
     }
 
+    if constexpr (MODE == 3) {
+        if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
+        return;
+    }
     if constexpr (MODE != 2) {
         // deterministic workgroup reduction of the lane groups' row sums: one
         // partial row per workgroup (fixed summation order, no float atomics)

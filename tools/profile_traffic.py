@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 --pmc passes (HBM traffic of the scan kernel).
+
+Runs, on config 2 (256 streams x 2.048 MS, nperseg 256):
+  * CAL launches of the load-only calibration kernel (stft_scan<1,3>), whose
+    byte count is known exactly, and
+  * STEPS full analysis steps (stft_scan<1,0> + detect_sparse).
+Prints the exact byte counts as JSON so tools/pmc_summary.py can turn the
+FETCH_SIZE / WRITE_SIZE rows into corrected bytes per launch.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/profile_traffic.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/profile_traffic.py
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+
+    from pyradiotracking_amd import synth
+    from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
+
+    S = int(os.environ.get("RT_PROF_STREAMS", "256"))
+    fs, nperseg = 2048000, 256
+    blen = int(os.environ.get("RT_PROF_SAMPLES", str(fs)))
+    cal = int(os.environ.get("RT_PROF_CAL", "3"))
+    steps = int(os.environ.get("RT_PROF_STEPS", "3"))
+    win = window_coefficients("hamming", nperseg)
+    iq = synth.make_batch_device(S, blen, fs, win, seed=1000)
+    torch.cuda.synchronize()
+    an = BatchSignalAnalyzer([str(i) for i in range(S)], sdr_callback_length=blen, sample_rate=fs, mode="sparse")
+    for _ in range(cal):
+        an.native.calibrate_read(iq.data_ptr(), blen, blen)
+    n_hot = n_rec = 0
+    for _ in range(steps):
+        an.enqueue(iq)
+        rec = an.fetch_records()
+        n_hot, n_rec = an.native.call_info().n_hot, len(rec)
+    T = blen // nperseg
+    L = 32  # default segs_per_chunk for this size
+    chunks = -(-T // L)
+    halo = chunks - 1  # every chunk but the last reads one halo segment
+    print(json.dumps({
+        "streams": S, "segments": T, "nperseg": nperseg, "segs_per_chunk": L,
+        "algorithmic_bytes": S * T * nperseg * 8,
+        "scan_read_bytes_exact": S * (T + halo) * nperseg * 8,
+        "candidate_cells": int(n_hot), "records": int(n_rec),
+    }))
+
+
+if __name__ == "__main__":
+    main()
