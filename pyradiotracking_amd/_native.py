@@ -127,10 +127,11 @@ def load_library(path: Optional[str] = None):
             f"{p} is missing: build it with `python -m pyradiotracking_amd.build` "
             "(hipcc --offload-arch=gfx950); this package has no CPU fallback"
         )
-    try:
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover - torch is optional for the product
-        pass
+    if not os.environ.get("RT_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the product
+            pass
     lib = C.CDLL(p, mode=getattr(os, "RTLD_NOW", 2) | getattr(os, "RTLD_GLOBAL", 0x100))
     vp = C.c_void_p
     lib.rt_abi_version.restype = C.c_int

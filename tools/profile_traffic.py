@@ -19,9 +19,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    import torch
+    # torch-free on purpose: rocprofv3 --pmc (ROCm 7.2) crashes at start-up when torch's
+    # bundled ROCm 7.0 runtime is loaded; the library itself only needs /opt/rocm's HIP.
+    os.environ["RT_NO_TORCH"] = "1"
+    import numpy as np
 
-    from pyradiotracking_amd import synth
+    from pyradiotracking_amd import _native, synth
     from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
 
     S = int(os.environ.get("RT_PROF_STREAMS", "256"))
@@ -30,14 +33,22 @@ def main():
     cal = int(os.environ.get("RT_PROF_CAL", "3"))
     steps = int(os.environ.get("RT_PROF_STEPS", "3"))
     win = window_coefficients("hamming", nperseg)
-    iq = synth.make_batch_device(S, blen, fs, win, seed=1000)
-    torch.cuda.synchronize()
+    # 8 distinct streams (noise + 4-8 pulses each), tiled to S: traffic does not depend on content
+    base = []
+    for s in range(8):
+        rng = np.random.default_rng([1000, s])
+        k = int(rng.integers(4, 9))
+        pulses = synth.random_pulses(rng, blen, fs, win, k, keep_clear_tail=2 * nperseg)
+        base.append(synth.make_stream(synth.StreamSpec(blen, fs, pulses), 1000 + s))
+    dev = _native.DeviceBuffer(0, S * blen * 8)
+    for s in range(S):
+        _native.load_library().rt_dev_upload(0, dev.ptr + s * blen * 8, base[s % 8].ctypes.data, blen * 8)
     an = BatchSignalAnalyzer([str(i) for i in range(S)], sdr_callback_length=blen, sample_rate=fs, mode="sparse")
     for _ in range(cal):
-        an.native.calibrate_read(iq.data_ptr(), blen, blen)
+        an.native.calibrate_read(dev.ptr, blen, blen)
     n_hot = n_rec = 0
     for _ in range(steps):
-        an.enqueue(iq)
+        an.enqueue(dev.ptr, n_samples=blen)
         rec = an.fetch_records()
         n_hot, n_rec = an.native.call_info().n_hot, len(rec)
     T = blen // nperseg
