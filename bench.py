@@ -27,6 +27,10 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE = 8  # one complex64 read
+# HBM bytes per scan-kernel launch on the default workload, from the PMC passes in
+# profiles/r01_c_pmc_traffic.txt (FETCH_SIZE x 1024 x 2 [gfx950 half-count, calibrated on the
+# kernel's own load stream] + WRITE_SIZE x 1024).  Only quoted for that exact workload.
+PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4427100000, "source": "profiles/r01_c_pmc_traffic.txt"}
 
 
 def parse():
@@ -126,6 +130,8 @@ def main():
     k_ms = ms_stft / max(1, args.steps)
     achieved = samples_per_step_gpu * BYTES_PER_SAMPLE / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
+    default_workload = (S, fs, blen, nperseg, args.window, args.segs_per_chunk, args.mode) == (256, 2048000, 2048000, 256, "hamming", 0, "auto")
+    traffic = PMC_TRAFFIC_DEFAULT["bytes_per_launch"] if default_workload else None
     out = {
         "metric": "IQ MSamples/s analysed (STFT + detect + records), detected-signal parity vs CPU",
         "value": round(value, 1),
@@ -157,7 +163,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "bytes/launch (PMC, profiles/r01_c_pmc_traffic.txt)" if traffic else None,
             "kernel_ms": round(k_ms, 4),
             "detect_kernel_ms": round(ms_detect / max(1, args.steps), 4),
             "algorithmic_bytes_per_launch": samples_per_step_gpu * BYTES_PER_SAMPLE,
