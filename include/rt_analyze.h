@@ -75,8 +75,8 @@ typedef struct rt_config {
     float calibration_db;       /* only used to order maxima in the shadow filter        */
     double min_duration_s;      /* signal_min_duration (analyze.py:113)                  */
     double max_duration_s;      /* signal_max_duration (analyze.py:114)                  */
-    int32_t hot_capacity;       /* sparse path: candidate cells kept per stream and call
-                                   (0 = default 8192)                                    */
+    int32_t hot_capacity;       /* sparse path: candidate cells kept per (stream, bin mod 16 bucket) and call
+                                   (0 = default: one full bin row, 1024..8192)                                    */
     int32_t record_capacity;    /* records kept per stream and call (0 = default 1024)   */
     int32_t segs_per_chunk;     /* segments per lane-group chunk (0 = default)           */
     int32_t flags;              /* RT_FLAG_*                                             */
@@ -119,7 +119,11 @@ int rt_reset(rt_handle *h);
  * Analyse one buffer per stream: the body of process_samples (analyze.py:234-251,
  * 268).  `iq_dev` is a DEVICE pointer to S*stream_stride complex64; n_samples =
  * len(buffer) (<= max_samples); stream_stride in samples (>= n_samples).
- * Asynchronous: enqueues on the handle's stream.  Results via rt_fetch.
+ * Asynchronous: enqueues on the handle's streams.  Results via rt_fetch.
+ * Up to two calls may be in flight (enqueue call k+1 before fetching call k: its
+ * scan overlaps call k's detection and record copy); a third rt_process without
+ * an rt_fetch drops the oldest unfetched result.  `iq_dev` must stay valid and
+ * unchanged until the call has been fetched.
  */
 int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride);
 
@@ -127,10 +131,12 @@ int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stre
 int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride);
 
 /*
- * Wait for the last rt_process / rt_extract and copy its records, ordered by
+ * Wait for the OLDEST unfetched rt_process / rt_extract and copy its records, ordered by
  * (stream, fi, start) -- the reference's emission order per stream
  * (analyze.py:357, 364).  Records carry the shadow verdict; none is removed.
  * *n_out receives the number of records available; at most `cap` are written.
+ * With out == NULL (or cap == 0) and records available the call is only a size
+ * query: the result stays pending until it is fetched with a buffer.
  */
 int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out);
 

@@ -1,6 +1,21 @@
 // rt_analyze.hip -- host side of the C-ABI declared in include/rt_analyze.h:
 // handle, device scratch, kernel launches.  gfx950 only; fails loudly when no
 // GPU is usable (there is no CPU fallback in the product path).
+//
+// Execution model of one handle
+//   * two "slots" of per-call scratch (candidate lists, partial row sums,
+//     record pool, counters, pinned mirrors), used alternately: the scan of
+//     call k+1 may run while call k is still being detected / fetched;
+//   * scan, detect kernels and readback of a call run in order on one stream
+//     (the caller's stream if one was given).  Overlapping detect k with scan
+//     k+1 on a second stream was measured and rejected: the scan's 3 waves/SIMD
+//     x 151 VGPRs leave no register space for co-resident detect waves, so they
+//     starve until the scan drains (profiles/r01_d_*).  What the two slots buy
+//     is host-side pipelining: call k+1 is enqueued before call k is fetched,
+//     so the GPU never waits for the host;
+//   * three look-back tail buffers in rotation: call k reads (k-1)%3 and writes
+//     k%3, so the scan of call k+1 never overwrites what detect k still reads;
+//   * rt_fetch returns calls in FIFO order (at most two are in flight).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -20,17 +35,40 @@ namespace {
 
 thread_local std::string g_create_error;
 
+constexpr int kSlots = 2;
+constexpr int kTails = 3;
+constexpr size_t kSpecRecords = 16384;  // records copied to the host speculatively with the counters
+
 struct CallCtx {
-    bool valid = false;
+    bool pending = false;   // enqueued, not fetched yet
+    uint64_t seq = 0;       // call number (0 = slot never used)
     const void *iq = nullptr;
     int64_t n_samples = 0;
     int64_t stream_stride = 0;
     int n_seg = 0;
-    int tail_read = 0;     // index of the tail buffer holding the previous buffer's columns
-    int n_seg_last = -1;   // columns of the previous buffer (-1: none)
+    int tail_read = 0, tail_write = 0;
+    int n_seg_last = -1;    // columns of the previous buffer (-1: none)
     int mode_used = 0;
     bool fell_back = false;
     bool is_extract = false;
+};
+
+struct Slot {
+    uint2 *d_hot = nullptr;
+    uint32_t *d_hot_count = nullptr;
+    float *d_psum = nullptr;
+    rt_record *d_raw = nullptr;
+    int32_t *d_raw_count = nullptr;
+    rt_record *d_records = nullptr;
+    int32_t *d_rec_offset = nullptr, *d_rec_count = nullptr;
+    unsigned long long *d_counters = nullptr;  // 4 words
+    // pinned host mirrors
+    unsigned long long *h_counters = nullptr;
+    int32_t *h_rec_offset = nullptr, *h_rec_count = nullptr;
+    rt_record *h_records = nullptr;
+    size_t h_records_cap = 0;
+    hipEvent_t ev_begin = nullptr, ev_scan = nullptr, ev_done = nullptr;
+    CallCtx call;
 };
 
 }  // namespace
@@ -43,39 +81,27 @@ struct rt_handle {
     int L = 32;            // segments per chunk
     int max_seg = 0;       // T for max_samples
     int max_chunks = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
+    hipStream_t s_scan = nullptr, s_copy = nullptr;
+    bool own_scan_stream = false;
     std::string err;
 
     float *d_window = nullptr;
     cf *d_tw1 = nullptr, *d_tw2 = nullptr;
-    float *d_psum = nullptr;
-    float *d_tail[2] = {nullptr, nullptr};
-    uint2 *d_hot = nullptr;
-    uint32_t *d_hot_count = nullptr;
-    rt_record *d_records = nullptr;
-    int64_t pool_cap = 0;
-    int32_t *d_rec_offset = nullptr, *d_rec_count = nullptr;
-    unsigned long long *d_counters = nullptr;  // 4 words
-    float *d_spec = nullptr;                   // lazily allocated dense spectrogram
+    float *d_tail[kTails] = {nullptr, nullptr, nullptr};
+    float *d_spec = nullptr;                   // lazily allocated dense spectrogram (shared)
     void *d_iq_stage = nullptr;                // for rt_process_host
     size_t iq_stage_bytes = 0;
-
-    // pinned host mirrors
-    unsigned long long *h_counters = nullptr;
-    int32_t *h_rec_offset = nullptr, *h_rec_count = nullptr;
-    rt_record *h_records = nullptr;
-    size_t h_records_cap = 0;
+    int64_t pool_cap = 0;
+    Slot slot[kSlots];
 
     int hot_cap = 8192, rec_cap = 1024;
-    size_t lds_sparse = 0, lds_dense = 0;
+    size_t lds_large = 0, lds_final = 0, lds_dense = 0;
 
-    int tail_cur = 0;      // tail buffer holding the most recent completed buffer
+    uint64_t n_calls = 0;  // calls enqueued so far
+    int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
 
-    CallCtx call;
     rt_call_info info{};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing = false;
 };
 
@@ -106,11 +132,11 @@ int next_pow2(int v) {
 template <int MODE>
 void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
     switch (h->R3) {
-        case 1: hipLaunchKernelGGL((stft_scan<1, MODE>), dim3(blocks), dim3(kBlock), 0, h->stream, p); break;
-        case 2: hipLaunchKernelGGL((stft_scan<2, MODE>), dim3(blocks), dim3(kBlock), 0, h->stream, p); break;
-        case 4: hipLaunchKernelGGL((stft_scan<4, MODE>), dim3(blocks), dim3(kBlock), 0, h->stream, p); break;
-        case 8: hipLaunchKernelGGL((stft_scan<8, MODE>), dim3(blocks), dim3(kBlock), 0, h->stream, p); break;
-        default: hipLaunchKernelGGL((stft_scan<16, MODE>), dim3(blocks), dim3(kBlock), 0, h->stream, p); break;
+        case 1: hipLaunchKernelGGL((stft_scan<1, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 2: hipLaunchKernelGGL((stft_scan<2, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 4: hipLaunchKernelGGL((stft_scan<4, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 8: hipLaunchKernelGGL((stft_scan<8, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        default: hipLaunchKernelGGL((stft_scan<16, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
     }
 }
 
@@ -127,7 +153,13 @@ int choose_chunk(const rt_handle *h, int n_seg) {
     return L;
 }
 
-StftParams make_stft_params(rt_handle *h, const void *iq, int64_t stream_stride, int n_seg, int tail_write) {
+int key_tbits(int n_seg) {
+    int t = 1;
+    while ((1ll << t) < (long long)n_seg) ++t;
+    return t;
+}
+
+StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stream_stride, int n_seg, int tail_write) {
     StftParams p{};
     p.iq = static_cast<const cf *>(iq);
     p.stream_stride = stream_stride;
@@ -142,16 +174,17 @@ StftParams make_stft_params(rt_handle *h, const void *iq, int64_t stream_stride,
     p.tw2 = h->d_tw2;
     p.scale = h->cfg.scale;
     p.thr = h->cfg.threshold;
-    p.psum = h->d_psum;
+    p.psum = sl.d_psum;
     p.tail = h->d_tail[tail_write];
     p.spec = h->d_spec;
-    p.hot = h->d_hot;
-    p.hot_count = h->d_hot_count;
+    p.hot = sl.d_hot;
+    p.hot_count = sl.d_hot_count;
     p.hot_cap = h->hot_cap;
+    p.tbits = key_tbits(n_seg);
     return p;
 }
 
-DetectArgs make_detect_args(rt_handle *h, int n_seg, int n_bins, int n_seg_last) {
+DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n_seg_last) {
     DetectArgs a{};
     a.dp.n_seg = n_seg;
     a.dp.n_seg_last = n_seg_last;
@@ -166,16 +199,19 @@ DetectArgs make_detect_args(rt_handle *h, int n_seg, int n_bins, int n_seg_last)
     a.dp.max_d = h->cfg.max_duration_s;
     a.n_streams = h->cfg.n_streams;
     a.n_bins = n_bins;
-    a.hot = h->d_hot;
-    a.hot_count = h->d_hot_count;
+    a.hot = sl.d_hot;
+    a.hot_count = sl.d_hot_count;
     a.hot_cap = h->hot_cap;
-    a.psum = h->d_psum;
-    a.records = h->d_records;
+    a.tbits = key_tbits(n_seg);
+    a.raw = sl.d_raw;
+    a.raw_count = sl.d_raw_count;
+    a.psum = sl.d_psum;
+    a.records = sl.d_records;
     a.pool_cap = h->pool_cap;
     a.rec_cap = h->rec_cap;
-    a.rec_offset = h->d_rec_offset;
-    a.rec_count = h->d_rec_count;
-    a.counters = h->d_counters;
+    a.rec_offset = sl.d_rec_offset;
+    a.rec_count = sl.d_rec_count;
+    a.counters = sl.d_counters;
     return a;
 }
 
@@ -191,52 +227,83 @@ int ensure_dense_spec(rt_handle *h) {
     return RT_OK;
 }
 
-int enqueue_readback(rt_handle *h) {
-    RT_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                             h->stream));
+size_t spec_records(const rt_handle *h) { return std::min<size_t>(kSpecRecords, (size_t)h->pool_cap); }
+
+// counters, per-stream tables and the head of the record pool -> pinned host memory
+int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
+    RT_HIP(h, hipMemcpyAsync(sl.h_counters, sl.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
-    RT_HIP(h, hipMemcpyAsync(h->h_rec_offset, h->d_rec_offset, sb, hipMemcpyDeviceToHost, h->stream));
-    RT_HIP(h, hipMemcpyAsync(h->h_rec_count, h->d_rec_count, sb, hipMemcpyDeviceToHost, h->stream));
+    RT_HIP(h, hipMemcpyAsync(sl.h_rec_offset, sl.d_rec_offset, sb, hipMemcpyDeviceToHost, st));
+    RT_HIP(h, hipMemcpyAsync(sl.h_rec_count, sl.d_rec_count, sb, hipMemcpyDeviceToHost, st));
+    RT_HIP(h, hipMemcpyAsync(sl.h_records, sl.d_records, spec_records(h) * sizeof(rt_record), hipMemcpyDeviceToHost, st));
     return RT_OK;
 }
 
-// enqueue scan + detect for the call described by h->call
-int enqueue_analysis(rt_handle *h, bool dense) {
-    const CallCtx &c = h->call;
-    const int tail_write = 1 - c.tail_read;
-    StftParams sp = make_stft_params(h, c.iq, c.stream_stride, c.n_seg, tail_write);
+// enqueue scan + detect + readback for the call described by sl.call
+int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool serial) {
+    const CallCtx &c = sl.call;
+    StftParams sp = make_stft_params(h, sl, c.iq, c.stream_stride, c.n_seg, c.tail_write);
     if (sp.chunks > h->max_chunks) {
         h->err = "internal: chunk count exceeds scratch";
         return RT_E_INVALID;
     }
     const int blocks = h->cfg.n_streams * sp.blocks_per_stream;
-    RT_HIP(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
-    if (!dense) RT_HIP(h, hipMemsetAsync(h->d_hot_count, 0, (size_t)h->cfg.n_streams * sizeof(uint32_t), h->stream));
-    if (dense) {
+    const int S = h->cfg.n_streams;
+    RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
+    if (!dense) {
+        RT_HIP(h, hipMemsetAsync(sl.d_hot_count, 0, (size_t)S * kBuckets * sizeof(uint32_t), h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.d_raw_count, 0, (size_t)S * sizeof(int32_t), h->s_scan));
+    } else {
         int rc = ensure_dense_spec(h);
         if (rc != RT_OK) return rc;
         sp.spec = h->d_spec;
     }
-    if (h->timing) RT_HIP(h, hipEventRecord(h->ev[0], h->stream));
+    RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
     if (dense)
         launch_stft<1>(h, sp, blocks);
     else
         launch_stft<0>(h, sp, blocks);
     RT_HIP(h, hipGetLastError());
-    if (h->timing) RT_HIP(h, hipEventRecord(h->ev[1], h->stream));
+    RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
 
-    DetectArgs a = make_detect_args(h, c.n_seg, h->N, c.n_seg_last);
+    (void)serial;
+    hipStream_t sd = h->s_scan;  // in order behind the scan (see the header comment)
+    DetectArgs a = make_detect_args(h, sl, c.n_seg, h->N, c.n_seg_last);
     a.prev = h->d_tail[c.tail_read];
     a.prev_cols = h->K;
     a.chunks = sp.blocks_per_stream;
     a.spec = h->d_spec;
-    if (dense)
-        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->stream, a);
-    else
-        hipLaunchKernelGGL(detect_sparse, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_sparse, h->stream, a);
+    if (dense) {
+        hipLaunchKernelGGL(detect_dense, dim3(S), dim3(kDetBlock), h->lds_dense, sd, a);
+    } else {
+        const int waves = S * kBuckets;
+        hipLaunchKernelGGL(detect_bucket<false>, dim3(waves), dim3(64), 0, sd, a);
+        if (h->hot_cap > kSmallBucket) hipLaunchKernelGGL(detect_bucket<true>, dim3(waves), dim3(64), h->lds_large, sd, a);
+        hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), h->lds_final, sd, a);
+    }
     RT_HIP(h, hipGetLastError());
-    if (h->timing) RT_HIP(h, hipEventRecord(h->ev[2], h->stream));
-    return enqueue_readback(h);
+    int rc = enqueue_readback(h, sl, sd);
+    if (rc != RT_OK) return rc;
+    RT_HIP(h, hipEventRecord(sl.ev_done, sd));
+    return RT_OK;
+}
+
+// claim the slot of the next call; the GPU work of the call that used it last must be over
+// before its scratch is rewritten (its results, if never fetched, are dropped)
+int claim_slot(rt_handle *h, Slot **out) {
+    Slot &sl = h->slot[h->n_calls % kSlots];
+    if (sl.call.seq) RT_HIP(h, hipStreamWaitEvent(h->s_scan, sl.ev_done, 0));
+    sl.call = CallCtx{};
+    sl.call.seq = h->n_calls + 1;
+    *out = &sl;
+    return RT_OK;
+}
+
+Slot *oldest_pending(rt_handle *h) {
+    Slot *best = nullptr;
+    for (auto &sl : h->slot)
+        if (sl.call.pending && (!best || sl.call.seq < best->call.seq)) best = &sl;
+    return best;
 }
 
 }  // namespace
@@ -263,28 +330,33 @@ const char *rt_last_error(rt_handle *h) { return h ? h->err.c_str() : g_create_e
 void rt_destroy(rt_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipDeviceSynchronize();
     (void)hipFree(h->d_window);
     (void)hipFree(h->d_tw1);
     (void)hipFree(h->d_tw2);
-    (void)hipFree(h->d_psum);
-    (void)hipFree(h->d_tail[0]);
-    (void)hipFree(h->d_tail[1]);
-    (void)hipFree(h->d_hot);
-    (void)hipFree(h->d_hot_count);
-    (void)hipFree(h->d_records);
-    (void)hipFree(h->d_rec_offset);
-    (void)hipFree(h->d_rec_count);
-    (void)hipFree(h->d_counters);
+    for (auto &t : h->d_tail) (void)hipFree(t);
     (void)hipFree(h->d_spec);
     (void)hipFree(h->d_iq_stage);
-    (void)hipHostFree(h->h_counters);
-    (void)hipHostFree(h->h_rec_offset);
-    (void)hipHostFree(h->h_rec_count);
-    (void)hipHostFree(h->h_records);
-    for (auto &e : h->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto &sl : h->slot) {
+        (void)hipFree(sl.d_hot);
+        (void)hipFree(sl.d_hot_count);
+        (void)hipFree(sl.d_psum);
+        (void)hipFree(sl.d_raw);
+        (void)hipFree(sl.d_raw_count);
+        (void)hipFree(sl.d_records);
+        (void)hipFree(sl.d_rec_offset);
+        (void)hipFree(sl.d_rec_count);
+        (void)hipFree(sl.d_counters);
+        (void)hipHostFree(sl.h_counters);
+        (void)hipHostFree(sl.h_rec_offset);
+        (void)hipHostFree(sl.h_rec_count);
+        (void)hipHostFree(sl.h_records);
+        if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
+        if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (h->own_scan_stream && h->s_scan) (void)hipStreamDestroy(h->s_scan);
+    if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     delete h;
 }
 
@@ -318,7 +390,6 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->LG = 16 * R3;
     h->GPW = kBlock / h->LG;
     h->timing = (cfg->flags & RT_FLAG_TIMING) != 0;
-    h->hot_cap = cfg->hot_capacity > 0 ? cfg->hot_capacity : 8192;
     h->rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : 1024;
     h->stride = probe_stride(h->N, cfg->sample_rate, cfg->min_duration_s);
     {
@@ -331,13 +402,17 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->L = choose_chunk(h, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
     const int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
-    if ((int64_t)h->max_seg * h->N > 0xFFFFFFFFll) {
+    if (((long long)h->N << key_tbits(std::max(h->max_seg, 2))) > 0x100000000ll) {
         delete h;
         return fail_create(RT_E_UNSUPPORTED, "max_samples too large for 32-bit cell keys");
     }
+    // candidate cells per (stream, bucket): a full row of one bin fits by default
+    h->hot_cap = cfg->hot_capacity > 0 ? cfg->hot_capacity
+                                       : std::min(8192, std::max(kSmallBucket, next_pow2(std::max(h->max_seg, 1))));
     h->lds_dense = rec_lds_bytes(h->rec_cap);
-    h->lds_sparse = rec_lds_bytes(h->rec_cap) + sizeof(float) * ((h->N + 3) & ~3) + (size_t)next_pow2(h->hot_cap) * 9;
-    if (h->lds_sparse > 160 * 1024 || h->lds_dense > 160 * 1024) {
+    h->lds_final = rec_lds_bytes(h->rec_cap);
+    h->lds_large = (size_t)next_pow2(std::max(h->hot_cap, 64)) * 9;
+    if (h->lds_large + 8 * 1024 > 160 * 1024 || h->lds_dense > 160 * 1024) {
         delete h;
         return fail_create(RT_E_INVALID, "hot_capacity/record_capacity do not fit the 160 KiB LDS of a CU");
     }
@@ -354,11 +429,12 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     } while (0)
 
     if (cfg->hip_stream) {
-        h->stream = static_cast<hipStream_t>(cfg->hip_stream);
+        h->s_scan = static_cast<hipStream_t>(cfg->hip_stream);
     } else {
-        RT_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        h->own_stream = true;
+        RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking));
+        h->own_scan_stream = true;
     }
+    RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
 
     const int S = cfg->n_streams, N = h->N, LG = h->LG;
     // window and twiddle tables (twiddles in double, rounded once to float32)
@@ -383,25 +459,33 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
 
     const size_t psum_bytes = (size_t)S * max_blocks_per_stream * N * sizeof(float);
     const size_t tail_bytes = (size_t)S * h->K * N * sizeof(float);
-    RT_CREATE_HIP(hipMalloc(&h->d_psum, std::max<size_t>(psum_bytes, 4)));
-    RT_CREATE_HIP(hipMalloc(&h->d_tail[0], tail_bytes));
-    RT_CREATE_HIP(hipMalloc(&h->d_tail[1], tail_bytes));
-    RT_CREATE_HIP(hipMalloc(&h->d_hot, (size_t)S * h->hot_cap * sizeof(uint2)));
-    RT_CREATE_HIP(hipMalloc(&h->d_hot_count, (size_t)S * sizeof(uint32_t)));
+    for (auto &t : h->d_tail) RT_CREATE_HIP(hipMalloc(&t, tail_bytes));
     h->pool_cap = (int64_t)S * h->rec_cap;
     if (h->pool_cap > 0x7FFFFFFFll) h->pool_cap = 0x7FFFFFFFll;
-    RT_CREATE_HIP(hipMalloc(&h->d_records, (size_t)h->pool_cap * sizeof(rt_record)));
-    RT_CREATE_HIP(hipMalloc(&h->d_rec_offset, (size_t)S * sizeof(int32_t)));
-    RT_CREATE_HIP(hipMalloc(&h->d_rec_count, (size_t)S * sizeof(int32_t)));
-    RT_CREATE_HIP(hipMalloc(&h->d_counters, 4 * sizeof(unsigned long long)));
-    RT_CREATE_HIP(hipHostMalloc(&h->h_counters, 4 * sizeof(unsigned long long)));
-    RT_CREATE_HIP(hipHostMalloc(&h->h_rec_offset, (size_t)S * sizeof(int32_t)));
-    RT_CREATE_HIP(hipHostMalloc(&h->h_rec_count, (size_t)S * sizeof(int32_t)));
-    if (h->timing)
-        for (auto &ev : h->ev) RT_CREATE_HIP(hipEventCreate(&ev));
+    for (auto &sl : h->slot) {
+        RT_CREATE_HIP(hipMalloc(&sl.d_psum, std::max<size_t>(psum_bytes, 4)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_hot, (size_t)S * kBuckets * h->hot_cap * sizeof(uint2)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_hot_count, (size_t)S * kBuckets * sizeof(uint32_t)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_raw, (size_t)S * h->rec_cap * sizeof(rt_record)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_raw_count, (size_t)S * sizeof(int32_t)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_records, (size_t)h->pool_cap * sizeof(rt_record)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_rec_offset, (size_t)S * sizeof(int32_t)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_rec_count, (size_t)S * sizeof(int32_t)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_counters, 4 * sizeof(unsigned long long)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_counters, 4 * sizeof(unsigned long long)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_offset, (size_t)S * sizeof(int32_t)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_count, (size_t)S * sizeof(int32_t)));
+        sl.h_records_cap = std::max<size_t>(spec_records(h), 1);
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_records, sl.h_records_cap * sizeof(rt_record)));
+        RT_CREATE_HIP(hipEventCreate(&sl.ev_begin));
+        RT_CREATE_HIP(hipEventCreate(&sl.ev_scan));
+        RT_CREATE_HIP(hipEventCreate(&sl.ev_done));
+    }
 
-    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_sparse),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sparse));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_records),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_final));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dense));
 #undef RT_CREATE_HIP
@@ -417,7 +501,6 @@ int rt_reset(rt_handle *h) {
 
 int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride) {
     if (!h) return RT_E_INVALID;
-    h->call.valid = false;
     if (!iq_dev && n_samples > 0) {
         h->err = "null IQ pointer";
         return RT_E_INVALID;
@@ -432,30 +515,37 @@ int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stre
         h->err = "exactly one segment: the reference raises IndexError (times[1])";
         return RT_E_ONE_SEGMENT;
     }
-    CallCtx &c = h->call;
-    c = CallCtx{};
+    Slot *slp = nullptr;
+    int rc = claim_slot(h, &slp);
+    if (rc != RT_OK) return rc;
+    Slot &sl = *slp;
+    CallCtx &c = sl.call;
     c.iq = iq_dev;
     c.n_samples = n_samples;
     c.stream_stride = stream_stride;
     c.n_seg = T;
     c.tail_read = h->tail_cur;
+    c.tail_write = (h->tail_cur + 1) % kTails;
     c.n_seg_last = h->n_seg_last;
     c.mode_used = (h->cfg.mode == RT_MODE_DENSE) ? RT_MODE_DENSE : RT_MODE_SPARSE;
-    h->info = rt_call_info{};
-    h->info.n_seg = T;
     if (T == 0) {
         // empty spectrogram: no signals; `_spectrogram_last` becomes an empty map
-        RT_HIP(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
-        RT_HIP(h, hipMemsetAsync(h->d_rec_count, 0, (size_t)h->cfg.n_streams * sizeof(int32_t), h->stream));
-        RT_HIP(h, hipMemsetAsync(h->d_rec_offset, 0, (size_t)h->cfg.n_streams * sizeof(int32_t), h->stream));
-        int rc = enqueue_readback(h);
+        const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
+        RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.d_rec_count, 0, sb, h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.d_rec_offset, 0, sb, h->s_scan));
+        RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
+        RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
+        rc = enqueue_readback(h, sl, h->s_scan);
         if (rc != RT_OK) return rc;
+        RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
     } else {
-        int rc = enqueue_analysis(h, c.mode_used == RT_MODE_DENSE);
+        rc = enqueue_analysis(h, sl, c.mode_used == RT_MODE_DENSE, false);
         if (rc != RT_OK) return rc;
     }
-    c.valid = true;
-    h->tail_cur = 1 - c.tail_read;
+    c.pending = true;
+    h->n_calls++;
+    h->tail_cur = c.tail_write;
     h->n_seg_last = T;
     return RT_OK;
 }
@@ -468,8 +558,10 @@ int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
     const size_t bytes = (size_t)h->cfg.n_streams * (size_t)stream_stride * sizeof(cf);
+    // one staging buffer: the previous call's scan must be over before it is overwritten
+    RT_HIP(h, hipStreamSynchronize(h->s_scan));
     if (bytes > h->iq_stage_bytes) {
-        RT_HIP(h, hipStreamSynchronize(h->stream));
+        RT_HIP(h, hipDeviceSynchronize());
         if (h->d_iq_stage) (void)hipFree(h->d_iq_stage);
         h->d_iq_stage = nullptr;
         h->iq_stage_bytes = 0;
@@ -480,14 +572,13 @@ int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_
         }
         h->iq_stage_bytes = bytes;
     }
-    if (bytes) RT_HIP(h, hipMemcpyAsync(h->d_iq_stage, iq_host, bytes, hipMemcpyHostToDevice, h->stream));
+    if (bytes) RT_HIP(h, hipMemcpyAsync(h->d_iq_stage, iq_host, bytes, hipMemcpyHostToDevice, h->s_scan));
     return rt_process(h, h->d_iq_stage, n_samples, stream_stride);
 }
 
 int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bins, const float *last_dev,
                int32_t n_seg_last) {
     if (!h) return RT_E_INVALID;
-    h->call.valid = false;
     if (n_seg < 0 || n_bins < 1 || (n_seg > 0 && !spec_dev) || (last_dev && n_seg_last < 0)) {
         h->err = "bad spectrogram arguments";
         return RT_E_INVALID;
@@ -501,98 +592,115 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
         return RT_E_UNSUPPORTED;
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
-    CallCtx &c = h->call;
-    c = CallCtx{};
+    Slot *slp = nullptr;
+    int rc = claim_slot(h, &slp);
+    if (rc != RT_OK) return rc;
+    Slot &sl = *slp;
+    CallCtx &c = sl.call;
     c.n_seg = n_seg;
     c.is_extract = true;
     c.mode_used = RT_MODE_DENSE;
-    h->info = rt_call_info{};
-    h->info.n_seg = n_seg;
-    RT_HIP(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+    const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
+    RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
+    RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
+    RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
     if (n_seg == 0) {
-        RT_HIP(h, hipMemsetAsync(h->d_rec_count, 0, (size_t)h->cfg.n_streams * sizeof(int32_t), h->stream));
-        RT_HIP(h, hipMemsetAsync(h->d_rec_offset, 0, (size_t)h->cfg.n_streams * sizeof(int32_t), h->stream));
+        RT_HIP(h, hipMemsetAsync(sl.d_rec_count, 0, sb, h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.d_rec_offset, 0, sb, h->s_scan));
     } else {
-        DetectArgs a = make_detect_args(h, n_seg, n_bins, last_dev ? n_seg_last : -1);
+        DetectArgs a = make_detect_args(h, sl, n_seg, n_bins, last_dev ? n_seg_last : -1);
         a.dp.tail_cols = last_dev ? n_seg_last : 0;
         a.prev = last_dev;
         a.prev_cols = last_dev ? n_seg_last : 0;
         a.spec = spec_dev;
         a.psum = nullptr;  // caller-supplied map: the kernel sums the rows itself
-        if (h->timing) RT_HIP(h, hipEventRecord(h->ev[0], h->stream));
-        if (h->timing) RT_HIP(h, hipEventRecord(h->ev[1], h->stream));
-        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->stream, a);
+        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
         RT_HIP(h, hipGetLastError());
-        if (h->timing) RT_HIP(h, hipEventRecord(h->ev[2], h->stream));
     }
-    int rc = enqueue_readback(h);
+    rc = enqueue_readback(h, sl, h->s_scan);
     if (rc != RT_OK) return rc;
-    c.valid = true;
+    RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
+    c.pending = true;
+    h->n_calls++;
     return RT_OK;
 }
 
 int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
     if (!h || !n_out) return RT_E_INVALID;
     *n_out = 0;
-    if (!h->call.valid) {
+    Slot *slp = oldest_pending(h);
+    if (!slp) {
         h->err = "rt_fetch without a preceding successful rt_process/rt_extract";
         return RT_E_INVALID;
     }
+    Slot &sl = *slp;
+    CallCtx &c = sl.call;
     RT_HIP(h, hipSetDevice(h->cfg.device));
-    RT_HIP(h, hipStreamSynchronize(h->stream));
-    CallCtx &c = h->call;
-    unsigned long long flags = h->h_counters[2];
-    h->info.n_hot = (int64_t)h->h_counters[1];
+    RT_HIP(h, hipEventSynchronize(sl.ev_done));
+    unsigned long long flags = sl.h_counters[2];
+    h->info = rt_call_info{};
+    h->info.n_seg = c.n_seg;
+    h->info.n_hot = (int64_t)sl.h_counters[1];
     if ((flags & kFlagHotOverflow) && !c.is_extract) {
         if (h->cfg.mode == RT_MODE_SPARSE) {
+            c.pending = false;
             h->err = "candidate-cell capacity exceeded (hot_capacity) in sparse mode";
             return RT_E_CAPACITY;
         }
-        // dense re-run of the same buffer with the same look-back state
+        // dense re-run of the same buffer with the same look-back state, after everything in flight
+        RT_HIP(h, hipDeviceSynchronize());
         c.fell_back = true;
         c.mode_used = RT_MODE_DENSE;
-        int rc = enqueue_analysis(h, true);
+        int rc = enqueue_analysis(h, sl, true, true);
         if (rc != RT_OK) return rc;
-        RT_HIP(h, hipStreamSynchronize(h->stream));
-        flags = h->h_counters[2];
+        RT_HIP(h, hipEventSynchronize(sl.ev_done));
+        flags = sl.h_counters[2];
     }
     if (flags & kFlagInconsistent) {
+        c.pending = false;
         h->err = "internal: candidate list lacks the cell preceding a run";
         return RT_E_HIP;
     }
     if (h->timing && c.n_seg > 0) {
-        (void)hipEventElapsedTime(&h->info.ms_stft, h->ev[0], h->ev[1]);
-        (void)hipEventElapsedTime(&h->info.ms_detect, h->ev[1], h->ev[2]);
-        (void)hipEventElapsedTime(&h->info.ms_total, h->ev[0], h->ev[2]);
+        (void)hipEventElapsedTime(&h->info.ms_stft, sl.ev_begin, sl.ev_scan);
+        (void)hipEventElapsedTime(&h->info.ms_detect, sl.ev_scan, sl.ev_done);
+        (void)hipEventElapsedTime(&h->info.ms_total, sl.ev_begin, sl.ev_done);
     }
     h->info.mode_used = c.mode_used;
     h->info.fell_back = c.fell_back ? 1 : 0;
 
     const int S = h->cfg.n_streams;
     size_t total = 0;
-    for (int s = 0; s < S; ++s) total += (size_t)h->h_rec_count[s];
+    for (int s = 0; s < S; ++s) total += (size_t)sl.h_rec_count[s];
     h->info.n_records = (int64_t)total;
     *n_out = total;
-    const size_t pool_used = (size_t)h->h_counters[0] <= (size_t)h->pool_cap ? (size_t)h->h_counters[0] : (size_t)h->pool_cap;
+    const size_t pool_used = std::min<size_t>((size_t)sl.h_counters[0], (size_t)h->pool_cap);
     if (total && out && cap) {
-        if (pool_used > h->h_records_cap) {
-            if (h->h_records) (void)hipHostFree(h->h_records);
-            h->h_records = nullptr;
-            h->h_records_cap = 0;
-            const size_t want = std::max<size_t>(pool_used * 2, 4096);
-            RT_HIP(h, hipHostMalloc(&h->h_records, want * sizeof(rt_record)));
-            h->h_records_cap = want;
+        if (pool_used > spec_records(h)) {
+            // more records than the speculative copy carried: fetch the whole used pool
+            if (pool_used > sl.h_records_cap) {
+                (void)hipHostFree(sl.h_records);
+                sl.h_records = nullptr;
+                sl.h_records_cap = 0;
+                const size_t want = std::max<size_t>(pool_used * 2, 4096);
+                RT_HIP(h, hipHostMalloc(&sl.h_records, want * sizeof(rt_record)));
+                sl.h_records_cap = want;
+            }
+            RT_HIP(h, hipMemcpyAsync(sl.h_records, sl.d_records, pool_used * sizeof(rt_record), hipMemcpyDeviceToHost,
+                                     h->s_copy));
+            RT_HIP(h, hipStreamSynchronize(h->s_copy));
         }
-        RT_HIP(h, hipMemcpyAsync(h->h_records, h->d_records, pool_used * sizeof(rt_record), hipMemcpyDeviceToHost,
-                                 h->stream));
-        RT_HIP(h, hipStreamSynchronize(h->stream));
         size_t w = 0;
         for (int s = 0; s < S && w < cap; ++s) {
-            const int n = h->h_rec_count[s];
-            const int off = h->h_rec_offset[s];
-            for (int i = 0; i < n && w < cap; ++i) out[w++] = h->h_records[(size_t)off + i];
+            const int n = sl.h_rec_count[s];
+            const int off = sl.h_rec_offset[s];
+            for (int i = 0; i < n && w < cap; ++i) out[w++] = sl.h_records[(size_t)off + i];
         }
+        c.pending = false;  // delivered
+    } else if (total == 0) {
+        c.pending = false;  // nothing to deliver
     }
+    // (out == NULL / cap == 0 with records available is a size query: the call stays pending)
     if (flags & kFlagRecOverflow) {
         h->err = "record capacity exceeded (record_capacity); results truncated";
         return RT_E_CAPACITY;
@@ -609,11 +717,12 @@ int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t 
     RT_HIP(h, hipSetDevice(h->cfg.device));
     const int T = (int)(n_samples / h->N);
     if (T == 0) return RT_OK;
-    StftParams sp = make_stft_params(h, iq_dev, stream_stride, T, 0);
+    RT_HIP(h, hipDeviceSynchronize());
+    StftParams sp = make_stft_params(h, h->slot[0], iq_dev, stream_stride, T, 0);
     sp.spec = spec_dev;
     launch_stft<2>(h, sp, h->cfg.n_streams * sp.blocks_per_stream);
     RT_HIP(h, hipGetLastError());
-    RT_HIP(h, hipStreamSynchronize(h->stream));
+    RT_HIP(h, hipStreamSynchronize(h->s_scan));
     return RT_OK;
 }
 
@@ -626,10 +735,11 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
     RT_HIP(h, hipSetDevice(h->cfg.device));
     const int T = (int)(n_samples / h->N);
     if (T < 2) return RT_OK;
-    StftParams sp = make_stft_params(h, iq_dev, stream_stride, T, 0);
+    RT_HIP(h, hipDeviceSynchronize());
+    StftParams sp = make_stft_params(h, h->slot[0], iq_dev, stream_stride, T, 0);
     launch_stft<3>(h, sp, h->cfg.n_streams * sp.blocks_per_stream);
     RT_HIP(h, hipGetLastError());
-    RT_HIP(h, hipStreamSynchronize(h->stream));
+    RT_HIP(h, hipStreamSynchronize(h->s_scan));
     return RT_OK;
 }
 

@@ -55,10 +55,57 @@ struct StftParams {
     float *psum;             // [S][blocks_per_stream][N] partial row sums (one row per workgroup)
     float *tail;             // [S][K][N] trailing K columns (written)
     float *spec;             // MODE 1/2: [S][T][N]
-    uint2 *hot;              // MODE 0: [S][hot_cap] (key = bin*T + t, bits of P)
-    uint32_t *hot_count;     // MODE 0: [S]
-    int32_t hot_cap;
+    uint2 *hot;              // MODE 0: [S][16][hot_cap] (key = bin << tbits | t, bits of P), bucket = bin & 15
+    uint32_t *hot_count;     // MODE 0: [S][16]
+    int32_t hot_cap;         // cells per (stream, bucket)
+    int32_t tbits;           // bits reserved for t in a key (2^tbits >= T)
 };
+
+constexpr int kBuckets = 16;
+
+constexpr int kStageCap = 256;  // candidate cells staged per wave before a flush (2 KiB)
+
+// Append a wave's staged candidate cells to the 16 per-bucket lists of its
+// stream (bucket = bin & 15).  Two passes over the <= kStageCap staged cells:
+// count per bucket (ballots), lanes 0..15 reserve their bucket's slots with one
+// returned atomic each, then every cell is stored at base + rank.
+__device__ __forceinline__ void flush_stage(const StftParams &p, int s, const uint2 *stg, int n) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // rare path: loops are deliberately not unrolled (register pressure of the hot loop matters more)
+    uint32_t my_cnt = 0;  // lane b (< 16): cells of bucket b
+#pragma nounroll
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const int bk = (i < n) ? (int)((stg[i].x >> p.tbits) & (kBuckets - 1)) : kBuckets;
+#pragma nounroll
+        for (int b = 0; b < kBuckets; ++b) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(bk == b);
+            if (lane == b) my_cnt += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+    uint32_t slot_base = 0;  // lane b: first free slot of bucket b for this flush
+    if (lane < kBuckets && my_cnt) slot_base = atomicAdd(&p.hot_count[s * kBuckets + lane], my_cnt);
+#pragma nounroll
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const uint2 e = (i < n) ? stg[i] : make_uint2(0u, 0u);
+        const int bk = (i < n) ? (int)((e.x >> p.tbits) & (kBuckets - 1)) : kBuckets;
+#pragma nounroll
+        for (int b = 0; b < kBuckets; ++b) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(bk == b);
+            if (m == 0) continue;
+            const uint32_t first = __shfl(slot_base, b, 64);
+            if (bk == b) {
+                const uint32_t slot = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                if (slot < (uint32_t)p.hot_cap) p.hot[((int64_t)s * kBuckets + b) * p.hot_cap + slot] = e;
+            }
+            if (lane == b) slot_base += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <int LG>
 __device__ __forceinline__ void group_sync() {
@@ -112,9 +159,20 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
 #ifndef RT_SCAN_MIN_WAVES
 #define RT_SCAN_MIN_WAVES 1
 #endif
+// diagnostic builds only (tools/ablate.sh): stop the scan step after stage n, folding the live
+// values into the row sums so nothing upstream is dead code.  0 = full kernel (the product).
+#ifndef RT_ABLATE
+#define RT_ABLATE 0
+#endif
+
+#define RT_ABLATE_STOP(n)                                               \
+    if constexpr (RT_ABLATE == (n)) {                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) acc[q_] += v[q_].x + v[q_].y; \
+        continue;                                                       \
+    }
 
 template <int R3, int MODE>
-__global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
+__global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
     constexpr int N = 256 * R3;
     constexpr int LG = 16 * R3;
     constexpr int GPW = kBlock / LG;  // lane groups per workgroup
@@ -166,6 +224,9 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
+    __shared__ uint2 stage[MODE == 0 ? (kBlock / 64) * kStageCap : 1];
+    uint2 *stg = stage + (MODE == 0 ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
+    int stg_n = 0;                                                    // wave-uniform fill level
 
     const cf *stream_iq = p.iq + (int64_t)s * p.stream_stride;
     const int i_first = (MODE == 0 || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
@@ -223,6 +284,7 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
             v[4 * mm + 3] = cscale(csub(v[4 * mm + 3], mean), w4.w);
         }
 
+        RT_ABLATE_STOP(1)  // loads + detrend + window
         // pass 1
         dft16(v);
 #pragma unroll
@@ -232,6 +294,7 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
             v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
         }
 
+        RT_ABLATE_STOP(2)  // + pass 1 and twiddles
         // exchange 1: element (a = lt, k1) -> row k1*R3 + b, column c
         {
             const int b = lt % R3, c = lt / R3;
@@ -249,8 +312,10 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
             }
         }
 
+        RT_ABLATE_STOP(3)  // + LDS exchange
         // pass 2
         dft16(v);
+        RT_ABLATE_STOP(4)  // + pass 2
 
         if constexpr (R3 > 1) {
 #pragma unroll
@@ -313,14 +378,40 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
             const uint32_t emit = (active && !halo) ? (hot | next_hot) : 0u;
-            if (emit) {
+            if (__builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare
+                // Candidates are staged per wave in LDS and flushed with ONE returned atomic per
+                // flush: an atomic per cell would stall on vmcnt(0) and drain the prefetch.
+                int need = 0;  // cells this wave emits in this step (scalar arithmetic on ballots)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (emit & (1u << r)) {
-                        const uint32_t slot = atomicAdd(&p.hot_count[s], 1u);
-                        if (slot < (uint32_t)p.hot_cap) {
-                            const uint32_t key = (uint32_t)bin_of<R3>(lt, r) * (uint32_t)T + (uint32_t)seg;
-                            p.hot[(int64_t)s * p.hot_cap + slot] = make_uint2(key, __float_as_uint(P[r]));
+                for (int r = 0; r < 16; ++r) need += __builtin_popcountll(__builtin_amdgcn_ballot_w64((emit >> r) & 1u));
+                if (stg_n + need > kStageCap) {
+                    flush_stage(p, s, stg, stg_n);
+                    stg_n = 0;
+                }
+                if (need <= kStageCap) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool mine = (emit >> r) & 1u;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+                        if (mine) {
+                            const int off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                            const uint32_t key = ((uint32_t)bin_of<R3>(lt, r) << p.tbits) | (uint32_t)seg;
+                            stg[stg_n + off] = make_uint2(key, __float_as_uint(P[r]));
+                        }
+                        stg_n += __builtin_popcountll(m);
+                    }
+                } else {
+                    // more than a staging area in one step (dense input): straight to memory
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (emit & (1u << r)) {
+                            const int bin = bin_of<R3>(lt, r);
+                            const int bkt = bin & (kBuckets - 1);
+                            const uint32_t slot = atomicAdd(&p.hot_count[s * kBuckets + bkt], 1u);
+                            if (slot < (uint32_t)p.hot_cap) {
+                                const uint32_t key = ((uint32_t)bin << p.tbits) | (uint32_t)seg;
+                                p.hot[((int64_t)s * kBuckets + bkt) * p.hot_cap + slot] = make_uint2(key, __float_as_uint(P[r]));
+                            }
                         }
                     }
                 }
@@ -329,6 +420,9 @@ __global__ __launch_bounds__(kBlock, RT_SCAN_MIN_WAVES) void stft_scan(const Stf
         }
     }
 
+    if constexpr (MODE == 0) {
+        if (stg_n) flush_stage(p, s, stg, stg_n);
+    }
     if constexpr (MODE == 3) {
         if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
         return;
@@ -366,9 +460,12 @@ struct DetectArgs {
     const float *prev;
     int32_t prev_cols;
     // sparse inputs
-    const uint2 *hot;
-    const uint32_t *hot_count;
-    int32_t hot_cap;
+    const uint2 *hot;          // [S][16][hot_cap]
+    const uint32_t *hot_count; // [S][16]
+    int32_t hot_cap;           // cells per (stream, bucket)
+    int32_t tbits;             // key = bin << tbits | t
+    rt_record *raw;            // [S][rec_cap] unordered records of the bucket waves
+    int32_t *raw_count;        // [S]
     const float *psum;         // [S][chunks][F] partial row sums
     int32_t chunks;            // partial rows per stream
     // dense input
@@ -385,6 +482,22 @@ struct DetectArgs {
 constexpr unsigned long long kFlagHotOverflow = 1ull;
 constexpr unsigned long long kFlagRecOverflow = 2ull;
 constexpr unsigned long long kFlagInconsistent = 4ull;
+
+// sum of one bin's partial row sums in float64, in partial-row order; loads are issued
+// eight at a time so their latency overlaps (the additions keep the sequential order)
+__device__ __forceinline__ double row_sum_from_partials(const float *ps, int chunks, int F) {
+    double sum = 0.0;
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ps[(int64_t)(c + j) * F];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (double)v[j];
+    }
+    for (; c < chunks; ++c) sum += (double)ps[(int64_t)c * F];
+    return sum;
+}
 
 struct PrevCells {
     const float *base;  // points at column prev_cols of this (stream, bin): base[-d*F]
@@ -516,129 +629,298 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
     return n;
 }
 
-// One workgroup per stream.  Dynamic LDS: records | avg[F] | keys[n2] | vals[n2] | above[n2]
-__global__ __launch_bounds__(kDetBlock) void detect_sparse(const DetectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int s = blockIdx.x;
-    const int tid = threadIdx.x;
+// ---------------------------------------------------------------------------
+// sparse detection: one WAVE per (stream, bucket), bucket = bin & 15
+// ---------------------------------------------------------------------------
+constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
+constexpr int kCandCap = 32;        // plateaus per (stream, bucket) and call
+
+// wave-synchronous LDS phases: DS operations of one wave execute in order, the
+// compiler just must not move them across
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Bitonic sort of 64*M (key, value) pairs held in registers, element i = m*64 + lane.
+// Compare-exchange distances >= 64 pair two registers of the same lane (no data
+// movement), distances < 64 pair the same register of two lanes (ds_bpermute via
+// __shfl_xor): no LDS memory, no synchronisation.
+template <int M>
+__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[M], float (&v)[M], int lane) {
+    constexpr int N2 = 64 * M;
+#pragma unroll
+    for (int kk = 2; kk <= N2; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j >= 64; j >>= 1) {  // register <-> register steps
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const int pm = m ^ (j / 64);
+                if (pm > m) {
+                    const bool up = (((m * 64) & kk) == 0);
+                    const bool sw = up ? (k[m] > k[pm]) : (k[m] < k[pm]);
+                    const uint32_t a = k[m], b = k[pm];
+                    const float x = v[m], y = v[pm];
+                    k[m] = sw ? b : a;
+                    k[pm] = sw ? a : b;
+                    v[m] = sw ? y : x;
+                    v[pm] = sw ? x : y;
+                }
+            }
+        }
+#pragma nounroll
+        for (int j = (kk >> 1) < 32 ? (kk >> 1) : 32; j > 0; j >>= 1) {  // lane <-> lane steps
+            const bool lower = (lane & j) == 0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const bool up = (((m * 64 + lane) & kk) == 0);
+                const uint32_t ok = (uint32_t)__shfl_xor((int)k[m], j, 64);
+                const float ov = __shfl_xor(v[m], j, 64);
+                const bool take = (lower == up) ? (ok < k[m]) : (ok > k[m]);
+                k[m] = take ? ok : k[m];
+                v[m] = take ? ov : v[m];
+            }
+        }
+    }
+}
+
+// load a bucket's cells into registers, sort, leave them in LDS in (bin, t) order
+template <int M>
+__device__ __forceinline__ void sort_bucket_regs(const uint2 *src, int n, int lane, uint32_t *keys, float *vals) {
+    uint32_t k[M];
+    float v[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int i = m * 64 + lane;
+        const uint2 e = (i < n) ? src[i] : make_uint2(0xFFFFFFFFu, 0u);
+        k[m] = e.x;
+        v[m] = __uint_as_float(e.y);
+    }
+    wave_bitonic_sort<M>(k, v, lane);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        keys[m * 64 + lane] = k[m];
+        vals[m * 64 + lane] = v[m];
+    }
+}
+
+// All cells of a bin live in one bucket, so a wave can finish its bins alone:
+// row means -> sort by (bin, t) -> predicate -> maximal runs (paired by a
+// prefix-max scan, no sequential walks) -> gates -> statistics -> raw records.
+// LARGE = false handles buckets of <= kSmallBucket cells (static 10 KiB of
+// LDS, many waves per CU, co-resident with the scan); LARGE = true handles the
+// rare bigger ones (up to hot_cap cells, dynamic LDS).  Both are launched; a
+// wave whose bucket belongs to the other instantiation exits at once.
+template <bool LARGE>
+__global__ __launch_bounds__(64) void detect_bucket(const DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    __shared__ __attribute__((aligned(16))) unsigned char small_smem[LARGE ? 16 : kSmallBucket * 9];
+    __shared__ float avg[256];            // row means of this bucket's bins (F/16 <= 256)
+    __shared__ rt_record cand[kCandCap];
+
+    const int sb = blockIdx.x;
+    const int s = sb / kBuckets, bkt = sb % kBuckets;
+    const int lane = threadIdx.x;
     const int F = a.n_bins;
     const int T = a.dp.n_seg;
-
-    unsigned char *ptr = smem;
-    RecLds l = carve_rec_lds(ptr, a.rec_cap);
-    float *avg = reinterpret_cast<float *>(ptr);
-    ptr += sizeof(float) * ((F + 3) & ~3);
-    uint32_t *keys = reinterpret_cast<uint32_t *>(ptr);
-
-    const uint32_t n_raw = a.hot_count[s];
-    if (tid == 0) {
-        *l.count = 0;
-        atomicAdd(&a.counters[1], (unsigned long long)n_raw);
+    const uint32_t n_raw = a.hot_count[sb];
+    if (n_raw == 0) return;
+    if (!LARGE && lane == 0) atomicAdd(&a.counters[1], (unsigned long long)n_raw);
+    if (n_raw > (uint32_t)a.hot_cap) {
+        if (!LARGE && lane == 0) atomicOr(&a.counters[2], kFlagHotOverflow);
+        return;
     }
-    if (n_raw > (uint32_t)a.hot_cap || n_raw == 0) {
-        if (tid == 0) {
-            if (n_raw) atomicOr(&a.counters[2], kFlagHotOverflow);
+    if (LARGE != (n_raw > (uint32_t)kSmallBucket)) return;
+    const int n = (int)n_raw;
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+
+    unsigned char *base = LARGE ? dyn_smem : small_smem;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(base);
+    float *vals = reinterpret_cast<float *>(keys + n2);
+    unsigned char *above = reinterpret_cast<unsigned char *>(vals + n2);
+    const uint32_t tmask = (1u << a.tbits) - 1u;
+    const DetectParams &dp = a.dp;
+
+    // row means of the bucket's bins: np.mean(row) (analyze.py:375) from the scan's partial sums
+    for (int r = lane; r < F / kBuckets; r += 64) {
+        const int bin = bkt + kBuckets * r;
+        avg[r] = (float)row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + bin, a.chunks, F) / (float)T;
+    }
+    const uint2 *src = a.hot + (int64_t)sb * a.hot_cap;
+    if constexpr (!LARGE) {
+        // <= 1024 cells: sort in registers
+        switch (n2) {
+            case 64: sort_bucket_regs<1>(src, n, lane, keys, vals); break;
+            case 128: sort_bucket_regs<2>(src, n, lane, keys, vals); break;
+            case 256: sort_bucket_regs<4>(src, n, lane, keys, vals); break;
+            case 512: sort_bucket_regs<8>(src, n, lane, keys, vals); break;
+            default: sort_bucket_regs<16>(src, n, lane, keys, vals); break;
+        }
+        wave_sync();
+    } else {
+        for (int i = lane; i < n2; i += 64) {
+            if (i < n) {
+                const uint2 e = src[i];
+                keys[i] = e.x;
+                vals[i] = __uint_as_float(e.y);
+            } else {
+                keys[i] = 0xFFFFFFFFu;
+                vals[i] = 0.f;
+            }
+        }
+        wave_sync();
+        // bitonic sort in LDS by key = (bin, t); keys are unique (one entry per cell)
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (n2 >> 1); t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int ixj = i | j;
+                    const bool up = ((i & k) == 0);
+                    const uint32_t ki = keys[i], kj = keys[ixj];
+                    if ((ki > kj) == up) {
+                        keys[i] = kj;
+                        keys[ixj] = ki;
+                        const float tv = vals[i];
+                        vals[i] = vals[ixj];
+                        vals[ixj] = tv;
+                    }
+                }
+                wave_sync();
+            }
+        }
+    }
+
+    // the predicate once per candidate cell (analyze.py:370, 378)
+    for (int i = lane; i < n; i += 64) {
+        const int bin = (int)(keys[i] >> a.tbits);
+        above[i] = cell_above(vals[i], avg[bin / kBuckets], dp.thr, dp.snr) ? 1 : 0;
+    }
+    wave_sync();
+
+    // maximal runs of above-cells: a run's last cell learns the index of its first cell from
+    // an inclusive prefix-max over "index if run start else -1" (64 cells per step + carry)
+    int ncand = 0;       // wave-uniform
+    int carry = -1;      // wave-uniform: last run start seen in earlier steps
+    for (int base_i = 0; base_i < n; base_i += 64) {
+        const int i = base_i + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys[i] : 0u;
+        const int t = (int)(key & tmask);
+        const bool ab = valid && above[i];
+        const bool prev_adj = ab && i > 0 && t > 0 && keys[i - 1] == key - 1 && above[i - 1];
+        const bool next_adj = ab && (i + 1 < n) && (t + 1 < T) && keys[i + 1] == key + 1 && above[i + 1];
+        const bool is_start = ab && !prev_adj;
+        const bool is_end = ab && !next_adj;
+        int first = is_start ? i : -1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(first, off, 64);
+            if (lane >= off) first = first > u ? first : u;
+        }
+        first = first > carry ? first : carry;
+        carry = __builtin_amdgcn_readlane(first, 63);
+
+        bool keep = false;
+        int fi = 0, b = 0, e = 0, start = 0;
+        float av = 0.f;
+        if (is_end) {
+            const uint32_t key0 = keys[first];
+            fi = (int)(key >> a.tbits);
+            b = (int)(key0 & tmask);
+            e = t + 1;
+            if (b > 0 && (first == 0 || keys[first - 1] != key0 - 1)) {
+                // the cell before a run must have been emitted by the scan (T11)
+                atomicOr(&a.counters[2], kFlagInconsistent);
+            } else {
+                av = avg[fi / kBuckets];
+                PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
+                keep = gate_run(dp, b, e, av, prev, &start);
+            }
+        }
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+        if (km) {
+            if (keep) {
+                const int idx = ncand + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
+                if (idx < kCandCap) {
+                    rt_record r;
+                    r.stream = s;
+                    r.fi = fi;
+                    r.start = start;
+                    r.end = e;
+                    r.max_p = 0.f;
+                    r.mean_p = 0.f;
+                    r.std_db = 0.f;
+                    r.row_mean = av;
+                    r.shadowed = 0;
+                    r.reserved = first - b;  // cell t of this bin sits at vals[reserved + t]
+                    cand[idx] = r;
+                }
+            }
+            ncand += __builtin_popcountll(km);
+        }
+    }
+    if (ncand == 0) return;
+    if (ncand > kCandCap) {
+        if (lane == 0) atomicOr(&a.counters[2], kFlagRecOverflow);
+        ncand = kCandCap;
+    }
+    wave_sync();
+
+    // statistics, the whole wave per plateau (canonical order of rt::run_stats)
+    for (int c = 0; c < ncand; ++c) {
+        const int start = cand[c].start, off = cand[c].reserved, fi = cand[c].fi, end = cand[c].end;
+        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
+        auto cell = [&](int k) -> float {
+            const int t = start + k;
+            return t < 0 ? prev(-t) : vals[off + t];
+        };
+        const RunStats st = run_stats_wave(end - start, cell);
+        if (lane == 0) {
+            cand[c].max_p = st.max_p;
+            cand[c].mean_p = st.mean_p;
+            cand[c].std_db = st.std_db;
+            cand[c].reserved = 0;
+        }
+    }
+    wave_sync();
+
+    // hand the records to the stream's unordered list (finalize_records orders and filters)
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&a.raw_count[s], ncand);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    for (int c = lane; c < ncand; c += 64) {
+        if (slot + c < a.rec_cap)
+            a.raw[(int64_t)s * a.rec_cap + slot + c] = cand[c];
+        else
+            atomicOr(&a.counters[2], kFlagRecOverflow);
+    }
+}
+
+// One workgroup per stream: order the stream's records by (fi, start), shadow verdicts, publish.
+__global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    int n = a.raw_count[s];
+    if (n <= 0) {
+        if (threadIdx.x == 0) {
             a.rec_offset[s] = 0;
             a.rec_count[s] = 0;
         }
         return;
     }
-    const int n = (int)n_raw;
-    int n2 = 1;
-    while (n2 < n) n2 <<= 1;
-    float *vals = reinterpret_cast<float *>(keys + n2);
-    unsigned char *above = reinterpret_cast<unsigned char *>(vals + n2);
-
-    // row means: np.mean(row) (analyze.py:375) from the scan's partial sums
-    for (int f = tid; f < F; f += kDetBlock) {
-        double sum = 0.0;
-        const float *ps = a.psum + (int64_t)s * a.chunks * F + f;
-        for (int c = 0; c < a.chunks; ++c) sum += (double)ps[(int64_t)c * F];
-        avg[f] = (float)sum / (float)T;
-    }
-    for (int i = tid; i < n2; i += kDetBlock) {
-        if (i < n) {
-            const uint2 e = a.hot[(int64_t)s * a.hot_cap + i];
-            keys[i] = e.x;
-            vals[i] = __uint_as_float(e.y);
-        } else {
-            keys[i] = 0xFFFFFFFFu;
-            vals[i] = 0.f;
-        }
+    if (n > a.rec_cap) n = a.rec_cap;  // overflow already flagged by the producer
+    unsigned char *ptr = smem;
+    RecLds l = carve_rec_lds(ptr, a.rec_cap);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const rt_record r = a.raw[(int64_t)s * a.rec_cap + i];
+        l.rec[i] = r;
+        l.ts_us[i] = timedelta_us(start_time(a.dp, r.start));
+        l.dur_us[i] = timedelta_us(run_duration(a.dp, r.start, r.end));
     }
     __syncthreads();
-
-    // bitonic sort by key (keys are unique: one entry per cell)
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += kDetBlock) {
-                // t-th compare-exchange pair of this step: i has bit j clear
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int ixj = i | j;
-                const bool up = ((i & k) == 0);
-                const uint32_t ki = keys[i], kj = keys[ixj];
-                if ((ki > kj) == up) {
-                    keys[i] = kj;
-                    keys[ixj] = ki;
-                    const float tv = vals[i];
-                    vals[i] = vals[ixj];
-                    vals[ixj] = tv;
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    const DetectParams &dp = a.dp;
-    // the predicate once per candidate cell (analyze.py:370, 378)
-    for (int i = tid; i < n; i += kDetBlock) {
-        const int fi = (int)(keys[i] / (uint32_t)T);
-        above[i] = cell_above(vals[i], avg[fi], dp.thr, dp.snr) ? 1 : 0;
-    }
-    __syncthreads();
-
-    // phase 1: maximal runs of above-cells -> gated candidates
-    const int max_len = dp.tail_cols + 2;  // anything longer fails the max-duration gate
-    for (int i = tid; i < n; i += kDetBlock) {
-        if (!above[i]) continue;
-        const uint32_t key = keys[i];
-        const int fi = (int)(key / (uint32_t)T);
-        const int b = (int)(key - (uint32_t)fi * (uint32_t)T);
-        if (i > 0 && b > 0 && keys[i - 1] == key - 1 && above[i - 1]) continue;  // not a run start
-        int j = i;
-        while (j + 1 < n && (j - i) < max_len && keys[j + 1] == keys[j] + 1 && (b + (j + 1 - i)) < T && above[j + 1]) ++j;
-        if ((j - i) >= max_len) continue;  // longer than any admissible signal
-        const int e = b + (j - i) + 1;
-        if (b > 0 && (i == 0 || keys[i - 1] != key - 1)) {
-            // the cell before a run must have been emitted by the scan (T11)
-            atomicOr(&a.counters[2], kFlagInconsistent);
-            continue;
-        }
-        const float av = avg[fi];
-        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
-        int start;
-        if (gate_run(dp, b, e, av, prev, &start)) push_candidate(a, l, s, fi, start, e, av, i - b);
-    }
-    const int nrec = settled_count(a, l);
-
-    // phase 2: statistics, one wave per candidate
-    for (int c = tid >> 6; c < nrec; c += kDetBlock / 64) {
-        rt_record &r = l.rec[c];
-        const int start = r.start, off = r.reserved;
-        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + r.fi, F};
-        auto cell = [&](int k) -> float {
-            const int t = start + k;
-            return t < 0 ? prev(-t) : vals[off + t];
-        };
-        const RunStats st = run_stats_wave(r.end - start, cell);
-        if ((tid & 63) == 0) {
-            r.max_p = st.max_p;
-            r.mean_p = st.mean_p;
-            r.std_db = st.std_db;
-        }
-    }
-    __syncthreads();
-    publish_records(a, l, s, nrec);
+    publish_records(a, l, s, n);
 }
 
 // One workgroup per stream.  Phase 1: one thread per bin (strided) scans its
@@ -661,12 +943,8 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
         const float *row = sp + fi;
         PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
         auto cur = [&](int t) -> float { return row[(int64_t)t * F]; };
-        double row_sum = -1.0;
-        if (a.psum) {  // same partial sums (and bits) as the sparse path
-            row_sum = 0.0;
-            const float *ps = a.psum + (int64_t)s * a.chunks * F + fi;
-            for (int c = 0; c < a.chunks; ++c) row_sum += (double)ps[(int64_t)c * F];
-        }
+        double row_sum = -1.0;  // same partial sums (and bits) as the sparse path
+        if (a.psum) row_sum = row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + fi, a.chunks, F);
         float av = 0.f;
         auto on_run = [&](int b, int e, float avg) {
             int start;
