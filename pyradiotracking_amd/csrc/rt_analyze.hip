@@ -37,7 +37,7 @@ thread_local std::string g_create_error;
 
 constexpr int kSlots = 2;
 constexpr int kTails = 3;
-constexpr size_t kSpecRecords = 16384;  // records copied to the host speculatively with the counters
+constexpr int64_t kMaxPoolRecords = 4 << 20;  // pinned record pool per slot: at most 4 Mi records (160 MiB)
 
 struct CallCtx {
     bool pending = false;   // enqueued, not fetched yet
@@ -59,14 +59,12 @@ struct Slot {
     float *d_psum = nullptr;
     rt_record *d_raw = nullptr;
     int32_t *d_raw_count = nullptr;
-    rt_record *d_records = nullptr;
-    int32_t *d_rec_offset = nullptr, *d_rec_count = nullptr;
-    unsigned long long *d_counters = nullptr;  // 4 words
-    // pinned host mirrors
+    unsigned long long *d_counters = nullptr;  // 4 words (atomics: device memory)
+    // Results are written by the finalize/detect kernels straight into pinned, device-visible
+    // host memory (no copy kernels); only the counter words are copied (32 bytes).
     unsigned long long *h_counters = nullptr;
-    int32_t *h_rec_offset = nullptr, *h_rec_count = nullptr;
-    rt_record *h_records = nullptr;
-    size_t h_records_cap = 0;
+    int32_t *h_rec_offset = nullptr, *h_rec_count = nullptr;  // [S]
+    rt_record *h_records = nullptr;                            // [pool_cap]
     hipEvent_t ev_begin = nullptr, ev_scan = nullptr, ev_done = nullptr;
     CallCtx call;
 };
@@ -95,7 +93,7 @@ struct rt_handle {
     Slot slot[kSlots];
 
     int hot_cap = 8192, rec_cap = 1024;
-    size_t lds_large = 0, lds_final = 0, lds_dense = 0;
+    size_t lds_large = 0, lds_small = 0, lds_final = 0, lds_dense = 0;
 
     uint64_t n_calls = 0;  // calls enqueued so far
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
@@ -201,16 +199,18 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.n_bins = n_bins;
     a.hot = sl.d_hot;
     a.hot_count = sl.d_hot_count;
+    a.hot_count_rw = sl.d_hot_count;
+    a.lds_cells = next_pow2(std::max(h->hot_cap, 64));
     a.hot_cap = h->hot_cap;
     a.tbits = key_tbits(n_seg);
     a.raw = sl.d_raw;
     a.raw_count = sl.d_raw_count;
     a.psum = sl.d_psum;
-    a.records = sl.d_records;
+    a.records = sl.h_records;
     a.pool_cap = h->pool_cap;
     a.rec_cap = h->rec_cap;
-    a.rec_offset = sl.d_rec_offset;
-    a.rec_count = sl.d_rec_count;
+    a.rec_offset = sl.h_rec_offset;
+    a.rec_count = sl.h_rec_count;
     a.counters = sl.d_counters;
     return a;
 }
@@ -227,15 +227,9 @@ int ensure_dense_spec(rt_handle *h) {
     return RT_OK;
 }
 
-size_t spec_records(const rt_handle *h) { return std::min<size_t>(kSpecRecords, (size_t)h->pool_cap); }
-
-// counters, per-stream tables and the head of the record pool -> pinned host memory
+// the counter words -> pinned host memory (records and per-stream tables are already there)
 int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
     RT_HIP(h, hipMemcpyAsync(sl.h_counters, sl.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
-    RT_HIP(h, hipMemcpyAsync(sl.h_rec_offset, sl.d_rec_offset, sb, hipMemcpyDeviceToHost, st));
-    RT_HIP(h, hipMemcpyAsync(sl.h_rec_count, sl.d_rec_count, sb, hipMemcpyDeviceToHost, st));
-    RT_HIP(h, hipMemcpyAsync(sl.h_records, sl.d_records, spec_records(h) * sizeof(rt_record), hipMemcpyDeviceToHost, st));
     return RT_OK;
 }
 
@@ -249,11 +243,10 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool serial) {
     }
     const int blocks = h->cfg.n_streams * sp.blocks_per_stream;
     const int S = h->cfg.n_streams;
-    RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
-    if (!dense) {
-        RT_HIP(h, hipMemsetAsync(sl.d_hot_count, 0, (size_t)S * kBuckets * sizeof(uint32_t), h->s_scan));
-        RT_HIP(h, hipMemsetAsync(sl.d_raw_count, 0, (size_t)S * sizeof(int32_t), h->s_scan));
-    } else {
+    // hot_count / raw_count are left zero by their last readers (detect_bucket<true>,
+    // finalize_records); only the four counter words need a reset
+    hipLaunchKernelGGL(reset_counters, dim3(1), dim3(1), 0, h->s_scan, sl.d_counters);
+    if (dense) {
         int rc = ensure_dense_spec(h);
         if (rc != RT_OK) return rc;
         sp.spec = h->d_spec;
@@ -277,8 +270,9 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool serial) {
         hipLaunchKernelGGL(detect_dense, dim3(S), dim3(kDetBlock), h->lds_dense, sd, a);
     } else {
         const int waves = S * kBuckets;
-        hipLaunchKernelGGL(detect_bucket<false>, dim3(waves), dim3(64), 0, sd, a);
-        if (h->hot_cap > kSmallBucket) hipLaunchKernelGGL(detect_bucket<true>, dim3(waves), dim3(64), h->lds_large, sd, a);
+        hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
+        // always launched: it is also the pass that re-zeroes the per-bucket counters
+        hipLaunchKernelGGL(detect_bucket<true>, dim3(waves), dim3(64), h->lds_large, sd, a);
         hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), h->lds_final, sd, a);
     }
     RT_HIP(h, hipGetLastError());
@@ -343,9 +337,6 @@ void rt_destroy(rt_handle *h) {
         (void)hipFree(sl.d_psum);
         (void)hipFree(sl.d_raw);
         (void)hipFree(sl.d_raw_count);
-        (void)hipFree(sl.d_records);
-        (void)hipFree(sl.d_rec_offset);
-        (void)hipFree(sl.d_rec_count);
         (void)hipFree(sl.d_counters);
         (void)hipHostFree(sl.h_counters);
         (void)hipHostFree(sl.h_rec_offset);
@@ -411,7 +402,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                                        : std::min(8192, std::max(kSmallBucket, next_pow2(std::max(h->max_seg, 1))));
     h->lds_dense = rec_lds_bytes(h->rec_cap);
     h->lds_final = rec_lds_bytes(h->rec_cap);
-    h->lds_large = (size_t)next_pow2(std::max(h->hot_cap, 64)) * 9;
+    {
+        const size_t tail = (((size_t)(h->N / kBuckets) * 4 + 15) & ~(size_t)15) + sizeof(rt_record) * kCandCap;
+        h->lds_large = (size_t)next_pow2(std::max(h->hot_cap, 64)) * 8 + tail;
+        h->lds_small = 4 * ((size_t)kSmallBucket * 8 + tail);
+    }
     if (h->lds_large + 8 * 1024 > 160 * 1024 || h->lds_dense > 160 * 1024) {
         delete h;
         return fail_create(RT_E_INVALID, "hot_capacity/record_capacity do not fit the 160 KiB LDS of a CU");
@@ -460,23 +455,21 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     const size_t psum_bytes = (size_t)S * max_blocks_per_stream * N * sizeof(float);
     const size_t tail_bytes = (size_t)S * h->K * N * sizeof(float);
     for (auto &t : h->d_tail) RT_CREATE_HIP(hipMalloc(&t, tail_bytes));
-    h->pool_cap = (int64_t)S * h->rec_cap;
-    if (h->pool_cap > 0x7FFFFFFFll) h->pool_cap = 0x7FFFFFFFll;
+    h->pool_cap = std::min<int64_t>((int64_t)S * h->rec_cap, kMaxPoolRecords);
     for (auto &sl : h->slot) {
         RT_CREATE_HIP(hipMalloc(&sl.d_psum, std::max<size_t>(psum_bytes, 4)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot, (size_t)S * kBuckets * h->hot_cap * sizeof(uint2)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_count, (size_t)S * kBuckets * sizeof(uint32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_raw, (size_t)S * h->rec_cap * sizeof(rt_record)));
         RT_CREATE_HIP(hipMalloc(&sl.d_raw_count, (size_t)S * sizeof(int32_t)));
-        RT_CREATE_HIP(hipMalloc(&sl.d_records, (size_t)h->pool_cap * sizeof(rt_record)));
-        RT_CREATE_HIP(hipMalloc(&sl.d_rec_offset, (size_t)S * sizeof(int32_t)));
-        RT_CREATE_HIP(hipMalloc(&sl.d_rec_count, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_counters, 4 * sizeof(unsigned long long)));
+        RT_CREATE_HIP(hipMemset(sl.d_hot_count, 0, (size_t)S * kBuckets * sizeof(uint32_t)));
+        RT_CREATE_HIP(hipMemset(sl.d_raw_count, 0, (size_t)S * sizeof(int32_t)));
+        RT_CREATE_HIP(hipMemset(sl.d_counters, 0, 4 * sizeof(unsigned long long)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_counters, 4 * sizeof(unsigned long long)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_offset, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_count, (size_t)S * sizeof(int32_t)));
-        sl.h_records_cap = std::max<size_t>(spec_records(h), 1);
-        RT_CREATE_HIP(hipHostMalloc(&sl.h_records, sl.h_records_cap * sizeof(rt_record)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_records, (size_t)h->pool_cap * sizeof(rt_record)));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_begin));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_scan));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_done));
@@ -484,6 +477,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
 
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_records),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_final));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense),
@@ -532,8 +527,8 @@ int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stre
         // empty spectrogram: no signals; `_spectrogram_last` becomes an empty map
         const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
         RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
-        RT_HIP(h, hipMemsetAsync(sl.d_rec_count, 0, sb, h->s_scan));
-        RT_HIP(h, hipMemsetAsync(sl.d_rec_offset, 0, sb, h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.h_rec_count, 0, sb, h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.h_rec_offset, 0, sb, h->s_scan));
         RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
         RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
         rc = enqueue_readback(h, sl, h->s_scan);
@@ -605,8 +600,8 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
     RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
     RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
     if (n_seg == 0) {
-        RT_HIP(h, hipMemsetAsync(sl.d_rec_count, 0, sb, h->s_scan));
-        RT_HIP(h, hipMemsetAsync(sl.d_rec_offset, 0, sb, h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.h_rec_count, 0, sb, h->s_scan));
+        RT_HIP(h, hipMemsetAsync(sl.h_rec_offset, 0, sb, h->s_scan));
     } else {
         DetectArgs a = make_detect_args(h, sl, n_seg, n_bins, last_dev ? n_seg_last : -1);
         a.dp.tail_cols = last_dev ? n_seg_last : 0;
@@ -674,22 +669,7 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
     for (int s = 0; s < S; ++s) total += (size_t)sl.h_rec_count[s];
     h->info.n_records = (int64_t)total;
     *n_out = total;
-    const size_t pool_used = std::min<size_t>((size_t)sl.h_counters[0], (size_t)h->pool_cap);
     if (total && out && cap) {
-        if (pool_used > spec_records(h)) {
-            // more records than the speculative copy carried: fetch the whole used pool
-            if (pool_used > sl.h_records_cap) {
-                (void)hipHostFree(sl.h_records);
-                sl.h_records = nullptr;
-                sl.h_records_cap = 0;
-                const size_t want = std::max<size_t>(pool_used * 2, 4096);
-                RT_HIP(h, hipHostMalloc(&sl.h_records, want * sizeof(rt_record)));
-                sl.h_records_cap = want;
-            }
-            RT_HIP(h, hipMemcpyAsync(sl.h_records, sl.d_records, pool_used * sizeof(rt_record), hipMemcpyDeviceToHost,
-                                     h->s_copy));
-            RT_HIP(h, hipStreamSynchronize(h->s_copy));
-        }
         size_t w = 0;
         for (int s = 0; s < S && w < cap; ++s) {
             const int n = sl.h_rec_count[s];

@@ -165,6 +165,7 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
 #define RT_ABLATE 0
 #endif
 
+
 #define RT_ABLATE_STOP(n)                                               \
     if constexpr (RT_ABLATE == (n)) {                                   \
         _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) acc[q_] += v[q_].x + v[q_].y; \
@@ -462,6 +463,8 @@ struct DetectArgs {
     // sparse inputs
     const uint2 *hot;          // [S][16][hot_cap]
     const uint32_t *hot_count; // [S][16]
+    uint32_t *hot_count_rw;    // same array, zeroed by its last reader
+    int32_t lds_cells;         // cells the large instantiation's LDS holds (power of two)
     int32_t hot_cap;           // cells per (stream, bucket)
     int32_t tbits;             // key = bin << tbits | t
     rt_record *raw;            // [S][rec_cap] unordered records of the bucket waves
@@ -713,18 +716,23 @@ __device__ __forceinline__ void sort_bucket_regs(const uint2 *src, int n, int la
 // rare bigger ones (up to hot_cap cells, dynamic LDS).  Both are launched; a
 // wave whose bucket belongs to the other instantiation exits at once.
 template <bool LARGE>
-__global__ __launch_bounds__(64) void detect_bucket(const DetectArgs a) {
+__global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    __shared__ __attribute__((aligned(16))) unsigned char small_smem[LARGE ? 16 : kSmallBucket * 9];
-    __shared__ float avg[256];            // row means of this bucket's bins (F/16 <= 256)
-    __shared__ rt_record cand[kCandCap];
-
-    const int sb = blockIdx.x;
+    // small: 4 waves = 4 buckets per workgroup; large: one wave per workgroup
+    // wave index made provably uniform; lane id from mbcnt (hipcc's value tracking on
+    // `threadIdx.x & 63` sends the unrolled register sort into a compile-time blow-up)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int sb = LARGE ? blockIdx.x : blockIdx.x * 4 + wave;
+    if (sb >= a.n_streams * kBuckets) return;
     const int s = sb / kBuckets, bkt = sb % kBuckets;
-    const int lane = threadIdx.x;
     const int F = a.n_bins;
     const int T = a.dp.n_seg;
     const uint32_t n_raw = a.hot_count[sb];
+    if (LARGE) {
+        // last reader of the counter: leave it zero for the slot's next call
+        if (lane == 0 && n_raw) a.hot_count_rw[sb] = 0u;
+    }
     if (n_raw == 0) return;
     if (!LARGE && lane == 0) atomicAdd(&a.counters[1], (unsigned long long)n_raw);
     if (n_raw > (uint32_t)a.hot_cap) {
@@ -736,10 +744,15 @@ __global__ __launch_bounds__(64) void detect_bucket(const DetectArgs a) {
     int n2 = 64;
     while (n2 < n) n2 <<= 1;
 
-    unsigned char *base = LARGE ? dyn_smem : small_smem;
+    // per-wave LDS: keys | vals | row means of the bucket's bins | plateau candidates
+    const int cap2 = LARGE ? a.lds_cells : kSmallBucket;
+    const int nbins_b = F / kBuckets;
+    const size_t wave_bytes = (size_t)cap2 * 8 + (((size_t)nbins_b * 4 + 15) & ~(size_t)15) + sizeof(rt_record) * kCandCap;
+    unsigned char *base = dyn_smem + (LARGE ? 0 : (size_t)wave * wave_bytes);
     uint32_t *keys = reinterpret_cast<uint32_t *>(base);
-    float *vals = reinterpret_cast<float *>(keys + n2);
-    unsigned char *above = reinterpret_cast<unsigned char *>(vals + n2);
+    float *vals = reinterpret_cast<float *>(keys + cap2);
+    float *avg = vals + cap2;
+    rt_record *cand = reinterpret_cast<rt_record *>(base + (size_t)cap2 * 8 + (((size_t)nbins_b * 4 + 15) & ~(size_t)15));
     const uint32_t tmask = (1u << a.tbits) - 1u;
     const DetectParams &dp = a.dp;
 
@@ -792,12 +805,11 @@ __global__ __launch_bounds__(64) void detect_bucket(const DetectArgs a) {
         }
     }
 
-    // the predicate once per candidate cell (analyze.py:370, 378)
-    for (int i = lane; i < n; i += 64) {
+    // the predicate (analyze.py:370, 378) is evaluated where it is needed: one float division
+    auto is_above = [&](int i) -> bool {
         const int bin = (int)(keys[i] >> a.tbits);
-        above[i] = cell_above(vals[i], avg[bin / kBuckets], dp.thr, dp.snr) ? 1 : 0;
-    }
-    wave_sync();
+        return cell_above(vals[i], avg[bin / kBuckets], dp.thr, dp.snr);
+    };
 
     // maximal runs of above-cells: a run's last cell learns the index of its first cell from
     // an inclusive prefix-max over "index if run start else -1" (64 cells per step + carry)
@@ -808,9 +820,9 @@ __global__ __launch_bounds__(64) void detect_bucket(const DetectArgs a) {
         const bool valid = i < n;
         const uint32_t key = valid ? keys[i] : 0u;
         const int t = (int)(key & tmask);
-        const bool ab = valid && above[i];
-        const bool prev_adj = ab && i > 0 && t > 0 && keys[i - 1] == key - 1 && above[i - 1];
-        const bool next_adj = ab && (i + 1 < n) && (t + 1 < T) && keys[i + 1] == key + 1 && above[i + 1];
+        const bool ab = valid && is_above(i);
+        const bool prev_adj = ab && i > 0 && t > 0 && keys[i - 1] == key - 1 && is_above(i - 1);
+        const bool next_adj = ab && (i + 1 < n) && (t + 1 < T) && keys[i + 1] == key + 1 && is_above(i + 1);
         const bool is_start = ab && !prev_adj;
         const bool is_end = ab && !next_adj;
         int first = is_start ? i : -1;
@@ -898,11 +910,22 @@ __global__ __launch_bounds__(64) void detect_bucket(const DetectArgs a) {
     }
 }
 
+// first kernel of a call on its slot: zero the slot's counter words (the previous call's were
+// copied to the host long ago).  One thread.
+__global__ void reset_counters(unsigned long long *counters) {
+    counters[0] = 0ull;
+    counters[1] = 0ull;
+    counters[2] = 0ull;
+    counters[3] = 0ull;
+}
+
 // One workgroup per stream: order the stream's records by (fi, start), shadow verdicts, publish.
 __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.x;
     int n = a.raw_count[s];
+    __syncthreads();
+    if (threadIdx.x == 0 && n) a.raw_count[s] = 0;  // ready for the slot's next call
     if (n <= 0) {
         if (threadIdx.x == 0) {
             a.rec_offset[s] = 0;
