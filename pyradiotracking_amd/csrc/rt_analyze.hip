@@ -56,6 +56,8 @@ struct CallCtx {
 struct Slot {
     uint2 *d_hot = nullptr;
     uint32_t *d_hot_count = nullptr;
+    uint32_t *d_hot_seen = nullptr;
+    int32_t *h_hot_total = nullptr;   // pinned, [S]
     float *d_psum = nullptr;
     rt_record *d_raw = nullptr;
     int32_t *d_raw_count = nullptr;
@@ -200,6 +202,8 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.hot = sl.d_hot;
     a.hot_count = sl.d_hot_count;
     a.hot_count_rw = sl.d_hot_count;
+    a.hot_seen = sl.d_hot_seen;
+    a.hot_total = sl.h_hot_total;
     a.lds_cells = next_pow2(std::max(h->hot_cap, 64));
     a.hot_cap = h->hot_cap;
     a.tbits = key_tbits(n_seg);
@@ -334,6 +338,8 @@ void rt_destroy(rt_handle *h) {
     for (auto &sl : h->slot) {
         (void)hipFree(sl.d_hot);
         (void)hipFree(sl.d_hot_count);
+        (void)hipFree(sl.d_hot_seen);
+        (void)hipHostFree(sl.h_hot_total);
         (void)hipFree(sl.d_psum);
         (void)hipFree(sl.d_raw);
         (void)hipFree(sl.d_raw_count);
@@ -460,6 +466,10 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipMalloc(&sl.d_psum, std::max<size_t>(psum_bytes, 4)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot, (size_t)S * kBuckets * h->hot_cap * sizeof(uint2)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_count, (size_t)S * kBuckets * sizeof(uint32_t)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_hot_seen, (size_t)S * kBuckets * sizeof(uint32_t)));
+        RT_CREATE_HIP(hipMemset(sl.d_hot_seen, 0, (size_t)S * kBuckets * sizeof(uint32_t)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_hot_total, (size_t)S * sizeof(int32_t)));
+        std::memset(sl.h_hot_total, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipMalloc(&sl.d_raw, (size_t)S * h->rec_cap * sizeof(rt_record)));
         RT_CREATE_HIP(hipMalloc(&sl.d_raw_count, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_counters, 4 * sizeof(unsigned long long)));
@@ -635,7 +645,9 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
     unsigned long long flags = sl.h_counters[2];
     h->info = rt_call_info{};
     h->info.n_seg = c.n_seg;
-    h->info.n_hot = (int64_t)sl.h_counters[1];
+    h->info.n_hot = 0;
+    if (c.mode_used == RT_MODE_SPARSE && !c.is_extract && c.n_seg > 0)
+        for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
     if ((flags & kFlagHotOverflow) && !c.is_extract) {
         if (h->cfg.mode == RT_MODE_SPARSE) {
             c.pending = false;

@@ -371,8 +371,16 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
         }
 
         if constexpr (MODE == 0) {
+            // candidates are rare: one max over the lane's 16 cells and a single compare in the
+            // common path, the per-cell tests only where that fires.  (A NaN cell means the whole
+            // segment is NaN -- the mean is -- so the max is NaN and `!(m < thr)` holds, as for the
+            // reference's `not (P < thr)`.)
+            float mx = __builtin_fmaxf(__builtin_fmaxf(P[0], P[1]), P[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, P[r]), P[r + 1]);
+            mx = __builtin_fmaxf(mx, P[15]);
             uint32_t hot = 0;
-            if (active) {
+            if (active && !(mx < p.thr)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (!(P[r] < p.thr)) hot |= (1u << r);
@@ -464,6 +472,8 @@ struct DetectArgs {
     const uint2 *hot;          // [S][16][hot_cap]
     const uint32_t *hot_count; // [S][16]
     uint32_t *hot_count_rw;    // same array, zeroed by its last reader
+    uint32_t *hot_seen;        // [S][16] copy of the counts for statistics
+    int32_t *hot_total;        // [S] (host-visible) candidate cells per stream
     int32_t lds_cells;         // cells the large instantiation's LDS holds (power of two)
     int32_t hot_cap;           // cells per (stream, bucket)
     int32_t tbits;             // key = bin << tbits | t
@@ -730,11 +740,15 @@ __global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectAr
     const int T = a.dp.n_seg;
     const uint32_t n_raw = a.hot_count[sb];
     if (LARGE) {
-        // last reader of the counter: leave it zero for the slot's next call
-        if (lane == 0 && n_raw) a.hot_count_rw[sb] = 0u;
+        // last reader of the counter: keep the value for the statistics (finalize_records sums
+        // them per stream -- one atomic per bucket on a single word would serialise ~11 ns each)
+        // and leave the counter zero for the slot's next call
+        if (lane == 0) {
+            a.hot_seen[sb] = n_raw;
+            if (n_raw) a.hot_count_rw[sb] = 0u;
+        }
     }
     if (n_raw == 0) return;
-    if (!LARGE && lane == 0) atomicAdd(&a.counters[1], (unsigned long long)n_raw);
     if (n_raw > (uint32_t)a.hot_cap) {
         if (!LARGE && lane == 0) atomicOr(&a.counters[2], kFlagHotOverflow);
         return;
@@ -925,7 +939,12 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     const int s = blockIdx.x;
     int n = a.raw_count[s];
     __syncthreads();
-    if (threadIdx.x == 0 && n) a.raw_count[s] = 0;  // ready for the slot's next call
+    if (threadIdx.x == 0) {
+        if (n) a.raw_count[s] = 0;  // ready for the slot's next call
+        uint32_t tot = 0;
+        for (int b = 0; b < kBuckets; ++b) tot += a.hot_seen[s * kBuckets + b];
+        a.hot_total[s] = (int32_t)tot;
+    }
     if (n <= 0) {
         if (threadIdx.x == 0) {
             a.rec_offset[s] = 0;
