@@ -63,7 +63,7 @@ struct StftParams {
 
 constexpr int kBuckets = 16;
 
-constexpr int kStageCap = 256;  // candidate cells staged per wave before a flush (2 KiB)
+constexpr int kStageCap = 128;  // candidate cells staged per wave before a flush (1 KiB)
 
 // Append a wave's staged candidate cells to the 16 per-bucket lists of its
 // stream (bucket = bin & 15).  Two passes over the <= kStageCap staged cells:
@@ -200,17 +200,20 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
     // read just in time: keeping them in VGPRs would cost 62 registers per lane
     // and a wave per SIMD of occupancy.
     __shared__ __attribute__((aligned(16))) float4 w_lds[4 * LG];    // [m/4][lane]: w[lane + LG*(4*(m/4) + 0..3)]
-    __shared__ __attribute__((aligned(16))) float4 t1_lds[8 * LG];   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
+    constexpr bool T1_IN_LDS = (R3 <= 4);  // N >= 2048: read the (L2-resident) table directly, LDS is needed for occupancy
+    __shared__ __attribute__((aligned(16))) float4 t1_lds[T1_IN_LDS ? 8 * LG : 1];   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
     __shared__ __attribute__((aligned(16))) float4 t2_lds[R3 > 1 ? 8 * R3 : 1];  // [q/2][b]
     for (int idx = tid; idx < 4 * LG; idx += kBlock) {
         const int mm = idx / LG, l = idx % LG;
         w_lds[idx] = make_float4(p.window[l + LG * (4 * mm)], p.window[l + LG * (4 * mm + 1)],
                                  p.window[l + LG * (4 * mm + 2)], p.window[l + LG * (4 * mm + 3)]);
     }
-    for (int idx = tid; idx < 8 * LG; idx += kBlock) {
-        const int kk = idx / LG, l = idx % LG;
-        const cf a = p.tw1[l * 16 + 2 * kk], b = p.tw1[l * 16 + 2 * kk + 1];
-        t1_lds[idx] = make_float4(a.x, a.y, b.x, b.y);
+    if constexpr (T1_IN_LDS) {
+        for (int idx = tid; idx < 8 * LG; idx += kBlock) {
+            const int kk = idx / LG, l = idx % LG;
+            const cf a = p.tw1[l * 16 + 2 * kk], b = p.tw1[l * 16 + 2 * kk + 1];
+            t1_lds[idx] = make_float4(a.x, a.y, b.x, b.y);
+        }
     }
     if constexpr (R3 > 1) {
         for (int idx = tid; idx < 8 * R3; idx += kBlock) {
@@ -290,7 +293,13 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
         dft16(v);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            const float4 t = t1_lds[kk * LG + lt];
+            float4 t;
+            if constexpr (T1_IN_LDS) {
+                t = t1_lds[kk * LG + lt];
+            } else {
+                const float4 *row = reinterpret_cast<const float4 *>(p.tw1 + lt * 16);  // 128 B per lane
+                t = row[kk];
+            }
             if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
             v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
         }
