@@ -251,6 +251,49 @@ def test_strided_device_batch_and_reset():
     assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in rec[rec["stream"] == 0]] == [(x.fi, x.start, x.end) for x in want]
 
 
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_varying_buffer_lengths_and_short_buffers(mode):
+    """Consecutive callbacks of different lengths (T changes between calls, including buffers
+    shorter than the look-back window and a T=2 buffer): the carried tail must behave like
+    `_spectrogram_last` of whatever shape the previous call left."""
+    _need_gpu()
+    fs, nperseg = 300000, 256
+    lens = [256 * 40 + 5, 256 * 3, 256 * 2, 256 * 120 + 200, 256 * 7 + 1, 256 * 90, 100, 256 * 60]
+    total = sum(lens)
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(99)
+    pulses = synth.random_pulses(rng, total, fs, w, 40, dur_ms=(3, 45), peak_dbw=(-85, -60))
+    # pulses straddling every boundary
+    edge = 0
+    for n in lens[:-1]:
+        edge += n
+        pulses.append(synth.Pulse(max(0, edge - 2500), 5200, 40e3, synth.amp_for_peak_dbw(-70, w, fs), 0.1))
+    iq = synth.make_stream(synth.StreamSpec(total, fs, pulses), 7)
+    kw = dict(sample_rate=fs, signal_min_duration_ms=2, signal_max_duration_ms=40)
+    b = _batch_for(kw, 1, max(lens), mode)
+    oa = oracle.OracleAnalyzer(device="0", **kw)
+    pos = 0
+    seen = 0
+    for k, n in enumerate(lens):
+        buf = iq[pos : pos + n]
+        pos += n
+        if n // nperseg == 1:
+            continue
+        b.enqueue(np.ascontiguousarray(buf).reshape(1, -1))
+        rec = b.fetch_records()
+        want, kept = oa.process(buf, gu.TS0)
+        assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in rec] == [(x.fi, x.start, x.end) for x in want], f"buffer {k} (len {n})"
+        kept_ids = {id(x) for x in kept}
+        assert [bool(r["shadowed"]) for r in rec] == [id(x) not in kept_ids for x in want]
+        sigs = b._decoder.signals(rec, ["0"], [gu.TS0])
+        for g, x in zip(sigs, want):
+            assert g.ts == x.ts and g.duration == x.duration
+            for name in ("max", "avg", "noise", "snr", "std"):
+                assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB
+        seen += len(rec)
+    assert seen > 10
+
+
 def test_pipelined_calls_match_serial():
     """Two calls in flight (enqueue k+1 before fetching k) give exactly the serial results,
     FIFO, including the look-back across the pipelined buffers."""
