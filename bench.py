@@ -29,9 +29,9 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE = 8  # one complex64 read
 # HBM bytes per scan-kernel launch on the default workload, from the PMC passes in
-# profiles/r01_c_pmc_traffic.txt (FETCH_SIZE x 1024 x 2 [gfx950 half-count, calibrated on the
+# profiles/r01_f_pmc_traffic_final.txt (FETCH_SIZE x 1024 x 2 [gfx950 half-count, calibrated on the
 # kernel's own load stream] + WRITE_SIZE x 1024).  Only quoted for that exact workload.
-PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4427100000, "source": "profiles/r01_c_pmc_traffic.txt"}
+PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4424100000, "source": "profiles/r01_f_pmc_traffic_final.txt"}
 
 
 def parse():
@@ -171,7 +171,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "traffic_unit": "bytes/launch (PMC, profiles/r01_c_pmc_traffic.txt)" if traffic else None,
+            "traffic_unit": "bytes/launch (PMC, " + PMC_TRAFFIC_DEFAULT["source"] + ")" if traffic else None,
             "kernel_ms": round(k_ms, 4),
             "detect_kernel_ms": round(ms_detect / max(1, args.steps), 4),
             "algorithmic_bytes_per_launch": samples_per_step_gpu * BYTES_PER_SAMPLE,
