@@ -127,6 +127,16 @@ int rt_reset(rt_handle *h);
  */
 int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride);
 
+/*
+ * Same for the RTL-SDR wire format: `iq_u8_dev` is a DEVICE pointer to S*stream_stride samples
+ * of interleaved uint8 (I, Q) -- 2 bytes per sample, what librtlsdr delivers before pyrtlsdr's
+ * packed_bytes_to_iq (the producer of the buffer handed to process_samples, analyze.py:157).
+ * The conversion (byte/127.5 - 1) is fused into the scan kernel's load (one float32 fma per
+ * component, <= 1 float32 ulp from pyrtlsdr's float64 expression); everything after it is the
+ * complex64 path.  n_samples / stream_stride count samples, not bytes.  [SURVEY 8(f) rank 1]
+ */
+int rt_process_u8(rt_handle *h, const void *iq_u8_dev, int64_t n_samples, int64_t stream_stride);
+
 /* Same with IQ in host memory (copied to an internal device buffer first). */
 int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride);
 

@@ -90,6 +90,7 @@ ABI_SYMBOLS = (
     "rt_destroy",
     "rt_reset",
     "rt_process",
+    "rt_process_u8",
     "rt_process_host",
     "rt_fetch",
     "rt_extract",
@@ -140,6 +141,7 @@ def load_library(path: Optional[str] = None):
     lib.rt_destroy.restype = None
     lib.rt_reset.argtypes = [vp]
     lib.rt_process.argtypes = [vp, vp, C.c_int64, C.c_int64]
+    lib.rt_process_u8.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_process_host.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_fetch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.rt_extract.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, C.c_int32]
@@ -296,6 +298,9 @@ class NativeAnalyzer:
     # -- analysis ---------------------------------------------------------
     def process_device(self, iq_ptr: int, n_samples: int, stream_stride: Optional[int] = None):
         self._check(self._lib.rt_process(self._handle, iq_ptr, n_samples, stream_stride or n_samples))
+
+    def process_device_u8(self, iq_ptr: int, n_samples: int, stream_stride: Optional[int] = None):
+        self._check(self._lib.rt_process_u8(self._handle, iq_ptr, n_samples, stream_stride or n_samples))
 
     def process_host(self, iq: np.ndarray):
         a = np.ascontiguousarray(iq, dtype=np.complex64)

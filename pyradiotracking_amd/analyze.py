@@ -205,6 +205,9 @@ class BatchSignalAnalyzer:
                 raise ValueError("n_samples is required with a raw device pointer")
             self._native.process_device(iq, n_samples, stream_stride)
             return
+        if isinstance(iq, np.ndarray) and iq.dtype == np.uint8:
+            self.enqueue_bytes(iq)
+            return
         if isinstance(iq, np.ndarray):
             self._native.process_host(iq)
             return
@@ -226,6 +229,45 @@ class BatchSignalAnalyzer:
 
             torch.cuda.current_stream(iq.device).synchronize()
         self._native.process_device(iq.data_ptr(), iq.shape[1], iq.stride(0) if iq.shape[0] > 1 else iq.shape[1])
+
+    def enqueue_bytes(self, raw, n_samples: Optional[int] = None, stream_stride: Optional[int] = None):
+        """Same as :meth:`enqueue` for the RTL-SDR wire format: interleaved uint8 I, Q (what
+        librtlsdr delivers; pyrtlsdr's ``packed_bytes_to_iq`` turns it into the complex buffer
+        the reference's callback sees).  ``raw``: host ndarray / CUDA torch tensor of uint8 shaped
+        ``[S, 2*B]`` (or ``[2*B]`` for one stream), or a raw device pointer with ``n_samples``.
+        The byte -> float conversion is fused into the scan kernel's load."""
+        if isinstance(raw, int):
+            if n_samples is None:
+                raise ValueError("n_samples is required with a raw device pointer")
+            self._native.process_device_u8(raw, n_samples, stream_stride)
+            return
+        if isinstance(raw, np.ndarray):
+            a = np.ascontiguousarray(raw, dtype=np.uint8)
+            if a.ndim == 1:
+                a = a[None, :]
+            if a.shape[0] != len(self.devices) or a.shape[1] % 2:
+                raise ValueError("expected uint8 [S, 2*B]")
+            # staged through an own device buffer, one per slot in flight (two calls may overlap)
+            bufs = getattr(self, "_u8_stage", None)
+            if bufs is None or bufs[0].nbytes < a.nbytes:
+                bufs = [_native.DeviceBuffer(self.gpu, a.nbytes), _native.DeviceBuffer(self.gpu, a.nbytes)]
+                self._u8_stage, self._u8_turn = bufs, 0
+            buf = bufs[self._u8_turn]
+            self._u8_turn ^= 1
+            buf.upload(a)
+            self._native.process_device_u8(buf.ptr, a.shape[1] // 2, a.shape[1] // 2)
+            return
+        if raw.dim() == 1:
+            raw = raw[None, :]
+        if str(raw.dtype) != "torch.uint8" or not raw.is_cuda or raw.stride(1) != 1 or raw.shape[1] % 2:
+            raise TypeError("device bytes must be a CUDA uint8 tensor [S, 2*B] with unit stride")
+        self._keep = raw
+        if self._hip_stream is None:
+            import torch
+
+            torch.cuda.current_stream(raw.device).synchronize()
+        stride = (raw.stride(0) if raw.shape[0] > 1 else raw.shape[1]) // 2
+        self._native.process_device_u8(raw.data_ptr(), raw.shape[1] // 2, stride)
 
     def fetch_records(self) -> np.ndarray:
         """Wait for the enqueued call; structured array of ``rt_record``."""
@@ -353,6 +395,30 @@ class SignalAnalyzer:
         ts_start = self._ts - buffer_len_dt  # :231
         filtered = self.analyze_buffer(buffer, ts_start)
         [self.consume_signal(s) for s in filtered]  # :251
+        return None
+
+    def process_bytes(self, raw: np.ndarray, context=None):
+        """The callback for ``RtlSdr.read_bytes_async``: ``raw`` is the interleaved uint8 I/Q
+        buffer (2 bytes per sample).  Same bookkeeping and queue contract as
+        :meth:`process_samples`; the conversion pyrtlsdr would do on the host happens in the
+        scan kernel's load."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        n = raw.size // 2
+        ts_recv = datetime.datetime.now()
+        buffer_len_dt = datetime.timedelta(seconds=n / self.sample_rate)
+        if self.last_data_ts is not None:
+            self.last_data_ts.value = datetime.datetime.timestamp(ts_recv)
+        if not self._ts:
+            self._ts = ts_recv
+        else:
+            self._ts += buffer_len_dt
+        ts_start = self._ts - buffer_len_dt
+        if n > self._batch.sdr_callback_length:
+            raise ValueError("buffer longer than sdr_callback_length")
+        self._batch.enqueue_bytes(raw.reshape(1, -1))
+        rec = self._batch.fetch_records()
+        rec = rec[rec["shadowed"] == 0]
+        [self.consume_signal(s) for s in self._decoder.signals(rec, [self.device], [ts_start])]
         return None
 
     def analyze_buffer(self, buffer: np.ndarray, ts_start: datetime.datetime, filtered: bool = True) -> List[Signal]:

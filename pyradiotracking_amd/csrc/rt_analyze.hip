@@ -51,6 +51,7 @@ struct CallCtx {
     int mode_used = 0;
     bool fell_back = false;
     bool is_extract = false;
+    bool u8 = false;        // IQ is interleaved uint8 (RTL-SDR wire format)
 };
 
 struct Slot {
@@ -129,14 +130,14 @@ int next_pow2(int v) {
     return p;
 }
 
-template <int MODE>
+template <int MODE, bool U8 = false>
 void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
     switch (h->R3) {
-        case 1: hipLaunchKernelGGL((stft_scan<1, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 2: hipLaunchKernelGGL((stft_scan<2, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 4: hipLaunchKernelGGL((stft_scan<4, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 8: hipLaunchKernelGGL((stft_scan<8, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        default: hipLaunchKernelGGL((stft_scan<16, MODE>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        default: hipLaunchKernelGGL((stft_scan<16, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
     }
 }
 
@@ -161,7 +162,7 @@ int key_tbits(int n_seg) {
 
 StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stream_stride, int n_seg, int tail_write) {
     StftParams p{};
-    p.iq = static_cast<const cf *>(iq);
+    p.iq = iq;
     p.stream_stride = stream_stride;
     p.n_streams = h->cfg.n_streams;
     p.n_seg = n_seg;
@@ -256,10 +257,11 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool serial) {
         sp.spec = h->d_spec;
     }
     RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
-    if (dense)
-        launch_stft<1>(h, sp, blocks);
-    else
-        launch_stft<0>(h, sp, blocks);
+    if (dense) {
+        if (c.u8) launch_stft<1, true>(h, sp, blocks); else launch_stft<1>(h, sp, blocks);
+    } else {
+        if (c.u8) launch_stft<0, true>(h, sp, blocks); else launch_stft<0>(h, sp, blocks);
+    }
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
 
@@ -504,7 +506,17 @@ int rt_reset(rt_handle *h) {
     return RT_OK;
 }
 
+static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride, bool u8);
+
 int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride) {
+    return process_impl(h, iq_dev, n_samples, stream_stride, false);
+}
+
+int rt_process_u8(rt_handle *h, const void *iq_u8_dev, int64_t n_samples, int64_t stream_stride) {
+    return process_impl(h, iq_u8_dev, n_samples, stream_stride, true);
+}
+
+static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride, bool u8) {
     if (!h) return RT_E_INVALID;
     if (!iq_dev && n_samples > 0) {
         h->err = "null IQ pointer";
@@ -526,6 +538,7 @@ int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stre
     Slot &sl = *slp;
     CallCtx &c = sl.call;
     c.iq = iq_dev;
+    c.u8 = u8;
     c.n_samples = n_samples;
     c.stream_stride = stream_stride;
     c.n_seg = T;

@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/rt_analyze.h"
 #include "rt_core.h"
 #include "rt_fft.h"
@@ -39,7 +41,7 @@ constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kRowF2 = 18;           // LDS exchange row stride in float2 (16 data + 2 pad = 144 B)
 
 struct StftParams {
-    const cf *iq;            // [S][stream_stride] complex64
+    const void *iq;          // [S][stream_stride] complex64, or interleaved uint8 I/Q (U8 instantiations)
     int64_t stream_stride;   // samples
     int32_t n_streams;
     int32_t n_seg;           // T
@@ -172,8 +174,22 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
         continue;                                                       \
     }
 
-template <int R3, int MODE>
+// raw sample as it sits in HBM: complex64, or the RTL-SDR wire format (interleaved uint8 I, Q)
+struct iq_u8 {
+    uint16_t iq;  // low byte I, high byte Q
+};
+
+// pyrtlsdr's packed_bytes_to_iq is (byte / 127.5) - 1 per component (in float64); here one
+// float32 fma per component, at most one float32 ulp away, then float32 like complex64 input
+__device__ __forceinline__ cf to_cf(cf x) { return x; }
+__device__ __forceinline__ cf to_cf(iq_u8 x) {
+    constexpr float c = 1.0f / 127.5f;
+    return cf{__builtin_fmaf((float)(x.iq & 0xFFu), c, -1.0f), __builtin_fmaf((float)(x.iq >> 8), c, -1.0f)};
+}
+
+template <int R3, int MODE, bool U8 = false>
 __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
+    using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
     constexpr int LG = 16 * R3;
     constexpr int GPW = kBlock / LG;  // lane groups per workgroup
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
     uint2 *stg = stage + (MODE == 0 ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
     int stg_n = 0;                                                    // wave-uniform fill level
 
-    const cf *stream_iq = p.iq + (int64_t)s * p.stream_stride;
+    const raw_t *stream_iq = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride;
     const int i_first = (MODE == 0 || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
 
     // software pipeline: the 16 loads of the next segment are issued before the
@@ -240,11 +256,11 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
     // Loads are unconditional (segment index clamped into the stream): lanes of
     // idle groups / past-the-end steps read valid memory and discard it.
     const int seg_hi = T - 1;
-    cf nxt[16];
+    raw_t nxt[16];
     {
         int seg0 = c0 + L - i_first;
         seg0 = seg0 < seg_hi ? seg0 : seg_hi;
-        const cf *src = stream_iq + (int64_t)seg0 * N + lt;
+        const raw_t *src = stream_iq + (int64_t)seg0 * N + lt;
 #pragma unroll
         for (int m = 0; m < 16; ++m) nxt[m] = src[LG * m];
     }
@@ -256,12 +272,12 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
 
         cf v[16];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = nxt[m];
+        for (int m = 0; m < 16; ++m) v[m] = to_cf(nxt[m]);
         {
             // next step's segment (the last step re-reads its own: harmless, keeps the loop uniform)
             int seg1 = (i < L) ? seg - 1 : seg;
             seg1 = seg1 < seg_hi ? seg1 : seg_hi;
-            const cf *src = stream_iq + (int64_t)seg1 * N + lt;
+            const raw_t *src = stream_iq + (int64_t)seg1 * N + lt;
 #pragma unroll
             for (int m = 0; m < 16; ++m) nxt[m] = src[LG * m];
         }

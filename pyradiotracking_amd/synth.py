@@ -74,6 +74,37 @@ def make_stream(spec: StreamSpec, seed: int) -> np.ndarray:
     return x.astype(np.complex64)
 
 
+U8_SCALE = np.float32(1.0 / 127.5)
+
+
+def quantize_u8(x: np.ndarray, gain: float = 1.0) -> np.ndarray:
+    """complex IQ -> the RTL-SDR wire format: interleaved uint8 (I, Q), value = round((v*gain+1)*127.5)
+    clipped to 0..255 -- the inverse of pyrtlsdr's ``packed_bytes_to_iq``."""
+    z = np.asarray(x, dtype=np.complex128) * gain
+    out = np.empty(z.shape + (2,), dtype=np.float64)
+    out[..., 0] = z.real
+    out[..., 1] = z.imag
+    q = np.clip(np.rint((out + 1.0) * 127.5), 0, 255).astype(np.uint8)
+    return q.reshape(z.shape[:-1] + (2 * z.shape[-1],))
+
+
+def u8_to_complex64_like_kernel(raw: np.ndarray) -> np.ndarray:
+    """What the scan kernel makes of wire bytes: fma(byte, float32(1/127.5), -1) per component,
+    one rounding (evaluated exactly here: the product fits float64)."""
+    v = np.asarray(raw, dtype=np.float64) * np.float64(U8_SCALE) - 1.0
+    v = v.astype(np.float32)
+    return (v[..., 0::2] + 1j * v[..., 1::2]).astype(np.complex64)
+
+
+def u8_to_complex128_like_pyrtlsdr(raw: np.ndarray) -> np.ndarray:
+    """pyrtlsdr ``packed_bytes_to_iq``: bytes -> float64, /= 127.5, -= (1+1j)."""
+    v = np.asarray(raw, dtype=np.float64)
+    iq = v[..., 0::2] + 1j * v[..., 1::2]
+    iq /= 127.5
+    iq -= 1 + 1j
+    return iq
+
+
 def random_pulses(
     rng: np.random.Generator,
     n_samples: int,

@@ -22,7 +22,7 @@ def lib():
 def _declared_symbols():
     text = open(os.path.join(REPO, "include", "rt_analyze.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

@@ -294,6 +294,58 @@ def test_varying_buffer_lengths_and_short_buffers(mode):
     assert seen > 10
 
 
+@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann")])
+def test_uint8_wire_format_ingestion(nperseg, window):
+    """interleaved uint8 I/Q converted inside the scan kernel's load.
+    (1) identical to the complex64 path fed with the same conversion; (2) against the oracle on
+    that complex64; (3) against the oracle on pyrtlsdr's float64 conversion (the reference's
+    real input): same records, powers within tolerance."""
+    _need_gpu()
+    fs = 2048000
+    n_streams, n_buf = 3, 2
+    blen = 256 * 1100 + 40
+    w = oracle.window_coefficients(window, nperseg)
+    rng = np.random.default_rng(321 + nperseg)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_threshold_dbw=-80.0)
+    raw_all = []
+    for s in range(n_streams):
+        pulses = synth.random_pulses(rng, n_buf * blen, fs, w, 8, dur_ms=(9, 30), peak_dbw=(-62, -48))
+        x = synth.make_stream(synth.StreamSpec(n_buf * blen, fs, pulses, noise_sigma=0.012), 900 + s)
+        raw_all.append(synth.quantize_u8(x))
+    raw_all = np.stack(raw_all)  # [S, 2*n_buf*blen]
+    b8 = _batch_for(kw, n_streams, blen, "sparse")
+    bc = _batch_for(kw, n_streams, blen, "sparse")
+    oas = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(n_streams)]
+    oas128 = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(n_streams)]
+    total = 0
+    for k in range(n_buf):
+        raw = np.ascontiguousarray(raw_all[:, 2 * k * blen : 2 * (k + 1) * blen])
+        c64 = synth.u8_to_complex64_like_kernel(raw)
+        b8.enqueue(raw)
+        rec8 = b8.fetch_records()
+        bc.enqueue(c64)
+        recc = bc.fetch_records()
+        assert rec8.tobytes() == recc.tobytes()  # (1)
+        c128 = synth.u8_to_complex128_like_pyrtlsdr(raw)
+        for s in range(n_streams):
+            mine = rec8[rec8["stream"] == s]
+            want, kept = oas[s].process(c64[s], gu.TS0)  # (2)
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want]
+            kept_ids = {id(x) for x in kept}
+            assert [bool(r["shadowed"]) for r in mine] == [id(x) not in kept_ids for x in want]
+            sigs = b8._decoder.signals(mine, [str(s)] * n_streams, [gu.TS0] * n_streams)
+            for g, x in zip(sigs, want):
+                for name in ("max", "avg", "noise", "snr", "std"):
+                    assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB
+            want128, _ = oas128[s].process(c128[s], gu.TS0)  # (3) float64 reference path
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want128]
+            for g, x in zip(sigs, want128):
+                for name in ("max", "avg", "noise", "snr", "std"):
+                    assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB
+            total += len(mine)
+    assert total > 20
+
+
 def test_pipelined_calls_match_serial():
     """Two calls in flight (enqueue k+1 before fetching k) give exactly the serial results,
     FIFO, including the look-back across the pipelined buffers."""
