@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--window", default="hamming")
     ap.add_argument("--mode", default="auto", choices=["auto", "dense", "sparse"])
     ap.add_argument("--segs-per-chunk", type=int, default=0)
+    ap.add_argument("--input", default="c64", choices=["c64", "u8"],
+                    help="IQ representation in HBM: complex64 (the BASELINE workload) or the RTL-SDR wire format "
+                         "(interleaved uint8, converted inside the scan kernel; SURVEY 8(f) rank 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--parity-streams", type=int, default=4)
@@ -80,8 +83,16 @@ def main():
     S = args.streams
     win = window_coefficients(args.window, nperseg)
     kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=args.window)
-
-    iq = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}")
+    u8 = args.input == "u8"
+    if u8:
+        # 8-bit front end: noise ~1.5 LSB rms, pulses 18..32 dB above the -80 dBW threshold
+        kw["signal_threshold_dbw"] = -80.0
+        iq_c = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}",
+                                       noise_sigma=0.012, peak_dbw=(-62.0, -48.0))
+        iq = synth.quantize_u8_device(iq_c)
+        del iq_c
+    else:
+        iq = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream()
     an = BatchSignalAnalyzer(
         [str(i) for i in range(S)],
@@ -104,11 +115,12 @@ def main():
         record copy and host-side fetch.  Every step's work completes inside this function."""
         acc = [0.0, 0.0, 0]
         rec = info = None
+        enq = an.enqueue_bytes if u8 else an.enqueue
         if n_steps:
-            an.enqueue(iq)
+            enq(iq)
         for i in range(n_steps):
             if i + 1 < n_steps:
-                an.enqueue(iq)
+                enq(iq)
             rec = an.fetch_records()
             info = an.native.call_info()
             acc[0] += info.ms_stft
@@ -135,9 +147,10 @@ def main():
     total_samples = samples_per_step_gpu * world * args.steps
     value = total_samples / elapsed / 1e6
     k_ms = ms_stft / max(1, args.steps)
-    achieved = samples_per_step_gpu * BYTES_PER_SAMPLE / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    bytes_per_sample = 2 if u8 else BYTES_PER_SAMPLE
+    achieved = samples_per_step_gpu * bytes_per_sample / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
-    default_workload = (S, fs, blen, nperseg, args.window, args.segs_per_chunk, args.mode) == (256, 2048000, 2048000, 256, "hamming", 0, "auto")
+    default_workload = (S, fs, blen, nperseg, args.window, args.segs_per_chunk, args.mode, args.input) == (256, 2048000, 2048000, 256, "hamming", 0, "auto", "c64")
     traffic = PMC_TRAFFIC_DEFAULT["bytes_per_launch"] if default_workload else None
     out = {
         "metric": "IQ MSamples/s analysed (STFT + detect + records), detected-signal parity vs CPU",
@@ -150,10 +163,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not u8 else "f32 (uint8 IQ converted in the load)",
         "data": "synthetic",
         "config": {
-            "workload": f"config2: {S} streams/GPU x {fs} SPS x {args.seconds:g} s complex64, nperseg {nperseg} {args.window}, 4-8 sparse 15 ms pulses/stream",
+            "workload": f"config2: {S} streams/GPU x {fs} SPS x {args.seconds:g} s {'uint8 I/Q' if u8 else 'complex64'}, nperseg {nperseg} {args.window}, 4-8 sparse 15 ms pulses/stream",
             "streams_per_gpu": S,
             "samples_per_stream": blen,
             "segments_per_stream": n_seg,
@@ -174,11 +187,11 @@ def main():
             "traffic_unit": "bytes/launch (PMC, " + PMC_TRAFFIC_DEFAULT["source"] + ")" if traffic else None,
             "kernel_ms": round(k_ms, 4),
             "detect_kernel_ms": round(ms_detect / max(1, args.steps), 4),
-            "algorithmic_bytes_per_launch": samples_per_step_gpu * BYTES_PER_SAMPLE,
+            "algorithmic_bytes_per_launch": samples_per_step_gpu * bytes_per_sample,
         },
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not u8:
         out["cpu_baseline"], out["parity"] = cpu_baseline(args, iq, rec, kw, blen, n_seg, nperseg)
 
     if world > 1:

@@ -141,6 +141,7 @@ def make_batch_device(
     seed: int = 0,
     device="cuda",
     chunk_streams: int = 64,
+    noise_sigma: float = NOISE_SIGMA,
 ):
     """``[S, B]`` complex64 batch generated in device memory with torch.
 
@@ -158,7 +159,7 @@ def make_batch_device(
     real_view = torch.view_as_real(out)  # [S, B, 2] float32
     for s0 in range(0, n_streams, chunk_streams):
         s1 = min(n_streams, s0 + chunk_streams)
-        real_view[s0:s1].normal_(0.0, NOISE_SIGMA, generator=gen)
+        real_view[s0:s1].normal_(0.0, noise_sigma, generator=gen)
     nperseg = len(window)
     two_pi = 2.0 * math.pi
     for s in range(n_streams):
@@ -172,3 +173,12 @@ def make_batch_device(
             tone = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64) * p.amp
             out[s, p.start : p.start + p.length] += tone
     return out
+
+
+def quantize_u8_device(iq, gain: float = 1.0):
+    """``[S, B]`` complex64 CUDA tensor -> ``[S, 2*B]`` uint8 in the RTL-SDR wire format (on device)."""
+    import torch
+
+    v = torch.view_as_real(iq)  # [S, B, 2]
+    q = torch.clamp(torch.round((v * gain + 1.0) * 127.5), 0, 255).to(torch.uint8)
+    return q.reshape(iq.shape[0], 2 * iq.shape[1]).contiguous()
