@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--input", default="c64", choices=["c64", "u8"],
                     help="IQ representation in HBM: complex64 (the BASELINE workload) or the RTL-SDR wire format "
                          "(interleaved uint8, converted inside the scan kernel; SURVEY 8(f) rank 1)")
+    ap.add_argument("--trains", action="store_true",
+                    help="BASELINE config 5 style input: 8-16 tags per stream, pulse trains 10-38 ms, period 0.1-1 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--parity-streams", type=int, default=4)
@@ -92,7 +94,7 @@ def main():
         iq = synth.quantize_u8_device(iq_c)
         del iq_c
     else:
-        iq = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}")
+        iq = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}", trains=args.trains)
     stream = torch.cuda.current_stream()
     an = BatchSignalAnalyzer(
         [str(i) for i in range(S)],
@@ -175,6 +177,7 @@ def main():
             "records_per_step": int(len(rec)),
             "candidate_cells_per_step": int(info.n_hot),
             "sharding": "streams sharded per GPU, no collective",
+            "pulse_recipe": "tag trains (config 5)" if args.trains else "4-8 pulses of 15 ms",
         },
         "roofline": {
             "bound": "hbm",

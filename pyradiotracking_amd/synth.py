@@ -142,6 +142,7 @@ def make_batch_device(
     device="cuda",
     chunk_streams: int = 64,
     noise_sigma: float = NOISE_SIGMA,
+    trains: bool = False,
 ):
     """``[S, B]`` complex64 batch generated in device memory with torch.
 
@@ -165,14 +166,38 @@ def make_batch_device(
     for s in range(n_streams):
         rng = np.random.default_rng([seed, s])
         k = int(rng.integers(pulses_per_stream[0], pulses_per_stream[1] + 1))
-        for p in random_pulses(
-            rng, n_samples, sample_rate, window, k, dur_ms, peak_dbw, keep_clear_tail=2 * nperseg
-        ):
+        if trains:
+            plist = tag_trains(rng, n_samples, sample_rate, window, peak_dbw=peak_dbw, keep_clear_tail=2 * nperseg)
+        else:
+            plist = random_pulses(rng, n_samples, sample_rate, window, k, dur_ms, peak_dbw, keep_clear_tail=2 * nperseg)
+        for p in plist:
             t = torch.arange(p.start, p.start + p.length, device=dev, dtype=torch.float64)
             ph = two_pi * (p.freq * t / sample_rate + p.phase)
             tone = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64) * p.amp
             out[s, p.start : p.start + p.length] += tone
     return out
+
+
+def tag_trains(rng: np.random.Generator, n_samples: int, sample_rate: float, window: np.ndarray,
+               n_tags: Sequence[int] = (8, 16), dur_ms: Sequence[float] = (10.0, 38.0),
+               period_s: Sequence[float] = (0.1, 1.0), peak_dbw: Sequence[float] = (-80.0, -60.0),
+               keep_clear_tail: int = 0) -> List[Pulse]:
+    """BASELINE config 5: several tags per stream, each with its own frequency, pulse length,
+    level and repetition period; pulses of different tags overlap in time (shadow filter)."""
+    pulses: List[Pulse] = []
+    total_s = n_samples / sample_rate
+    for _ in range(int(rng.integers(n_tags[0], n_tags[1] + 1))):
+        freq = float(rng.uniform(-0.45, 0.45) * sample_rate)
+        length = int(round(rng.uniform(*dur_ms) * 1e-3 * sample_rate))
+        period = float(rng.uniform(*period_s))
+        amp = amp_for_peak_dbw(float(rng.uniform(*peak_dbw)), window, sample_rate)
+        t = float(rng.uniform(0, period))
+        while t < total_s:
+            start = int(t * sample_rate)
+            if start + length <= n_samples - keep_clear_tail:
+                pulses.append(Pulse(start, length, freq, amp, float(rng.uniform(0, 1))))
+            t += period
+    return pulses
 
 
 def quantize_u8_device(iq, gain: float = 1.0):
