@@ -189,7 +189,7 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
 }
 
 template <int R3, int MODE, bool U8 = false>
-__global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
+__global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES < 3) ? 3 : RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
     constexpr int LG = 16 * R3;
@@ -216,14 +216,17 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
     // read them (16-byte pieces, consecutive lanes -> consecutive pieces), and
     // read just in time: keeping them in VGPRs would cost 62 registers per lane
     // and a wave per SIMD of occupancy.
-    __shared__ __attribute__((aligned(16))) float4 w_lds[4 * LG];    // [m/4][lane]: w[lane + LG*(4*(m/4) + 0..3)]
+    constexpr bool W_IN_LDS = (R3 <= 8);  // N = 4096: the window comes from L2 as well (3 workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float4 w_lds[W_IN_LDS ? 4 * LG : 1];    // [m/4][lane]: w[lane + LG*(4*(m/4) + 0..3)]
     constexpr bool T1_IN_LDS = (R3 <= 4);  // N >= 2048: read the (L2-resident) table directly, LDS is needed for occupancy
     __shared__ __attribute__((aligned(16))) float4 t1_lds[T1_IN_LDS ? 8 * LG : 1];   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
     __shared__ __attribute__((aligned(16))) float4 t2_lds[R3 > 1 ? 8 * R3 : 1];  // [q/2][b]
-    for (int idx = tid; idx < 4 * LG; idx += kBlock) {
-        const int mm = idx / LG, l = idx % LG;
-        w_lds[idx] = make_float4(p.window[l + LG * (4 * mm)], p.window[l + LG * (4 * mm + 1)],
-                                 p.window[l + LG * (4 * mm + 2)], p.window[l + LG * (4 * mm + 3)]);
+    if constexpr (W_IN_LDS) {
+        for (int idx = tid; idx < 4 * LG; idx += kBlock) {
+            const int mm = idx / LG, l = idx % LG;
+            w_lds[idx] = make_float4(p.window[l + LG * (4 * mm)], p.window[l + LG * (4 * mm + 1)],
+                                     p.window[l + LG * (4 * mm + 2)], p.window[l + LG * (4 * mm + 3)]);
+        }
     }
     if constexpr (T1_IN_LDS) {
         for (int idx = tid; idx < 8 * LG; idx += kBlock) {
@@ -298,7 +301,13 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 && RT_SCAN_MIN_WAVES < 3) ? 3 : RT
         const cf mean = cscale(sum, 1.0f / (float)N);
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
-            const float4 w4 = w_lds[mm * LG + lt];
+            float4 w4;
+            if constexpr (W_IN_LDS) {
+                w4 = w_lds[mm * LG + lt];
+            } else {
+                w4 = make_float4(p.window[lt + LG * (4 * mm)], p.window[lt + LG * (4 * mm + 1)],
+                                 p.window[lt + LG * (4 * mm + 2)], p.window[lt + LG * (4 * mm + 3)]);
+            }
             v[4 * mm + 0] = cscale(csub(v[4 * mm + 0], mean), w4.x);
             v[4 * mm + 1] = cscale(csub(v[4 * mm + 1], mean), w4.y);
             v[4 * mm + 2] = cscale(csub(v[4 * mm + 2], mean), w4.z);
