@@ -187,6 +187,12 @@ class BatchSignalAnalyzer:
     def native(self) -> "_native.NativeAnalyzer":
         return self._native
 
+    def _hold(self, tensor):
+        # two calls may be in flight: keep the device buffers of both alive (torch's caching
+        # allocator would otherwise hand the memory to someone else while the scan still reads it)
+        held = getattr(self, "_held", [])
+        self._held = (held + [tensor])[-2:]
+
     def reset(self):
         """``_spectrogram_last = None`` for every stream."""
         self._native.reset()
@@ -221,7 +227,7 @@ class BatchSignalAnalyzer:
             raise TypeError("device IQ must be complex64")
         if iq.shape[0] != len(self.devices) or iq.stride(1) != 1:
             raise ValueError("device IQ must be [S, B] with unit sample stride")
-        self._keep = iq
+        self._hold(iq)
         if self._hip_stream is None:
             # the handle launches on its own stream: whatever torch still has in flight on
             # the producing stream must have landed before the scan kernel reads the IQ
@@ -261,7 +267,7 @@ class BatchSignalAnalyzer:
             raw = raw[None, :]
         if str(raw.dtype) != "torch.uint8" or not raw.is_cuda or raw.stride(1) != 1 or raw.shape[1] % 2:
             raise TypeError("device bytes must be a CUDA uint8 tensor [S, 2*B] with unit stride")
-        self._keep = raw
+        self._hold(raw)
         if self._hip_stream is None:
             import torch
 

@@ -590,7 +590,8 @@ int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_
         }
         h->iq_stage_bytes = bytes;
     }
-    if (bytes) RT_HIP(h, hipMemcpyAsync(h->d_iq_stage, iq_host, bytes, hipMemcpyHostToDevice, h->s_scan));
+    // blocking copy: the caller may reuse or free its (pageable) buffer as soon as this returns
+    if (bytes) RT_HIP(h, hipMemcpy(h->d_iq_stage, iq_host, bytes, hipMemcpyHostToDevice));
     return rt_process(h, h->d_iq_stage, n_samples, stream_stride);
 }
 

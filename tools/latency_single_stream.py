@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-callback latency of the drop-in single-stream path (BASELINE config 1: 300 kSPS, 1 s
+buffers from host memory, nperseg 256) next to the oracle on one host core."""
+import datetime
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from oracle import analyze_oracle as oracle
+from pyradiotracking_amd import synth
+from pyradiotracking_amd.analyze import SignalAnalyzer
+
+fs = 300000
+w = oracle.window_coefficients("hamming", 256)
+rng = np.random.default_rng(0)
+iq = synth.make_stream(synth.StreamSpec(fs, fs, synth.random_pulses(rng, fs, fs, w, 3, dur_ms=(20, 20))), 0)
+ts = datetime.datetime(2024, 1, 1)
+an = SignalAnalyzer("0")
+for _ in range(5):
+    an.analyze_buffer(iq, ts)
+n = 50
+t0 = time.perf_counter()
+for _ in range(n):
+    sig = an.analyze_buffer(iq, ts)
+gpu_ms = (time.perf_counter() - t0) / n * 1e3
+oa = oracle.OracleAnalyzer(device="0")
+oa.process(iq, ts)
+t0 = time.perf_counter()
+for _ in range(5):
+    every, kept = oa.process(iq, ts)
+cpu_ms = (time.perf_counter() - t0) / 5 * 1e3
+print(f"single stream, 300 kSPS x 1 s from host memory: GPU path {gpu_ms:.3f} ms/callback ({len(sig)} signals), "
+      f"oracle (1 core) {cpu_ms:.2f} ms/callback ({len(kept)} signals)")
