@@ -681,7 +681,7 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
 // sparse detection: one WAVE per (stream, bucket), bucket = bin & (kBuckets-1)
 // ---------------------------------------------------------------------------
 constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
-constexpr int kCandCap = 32;        // plateaus per (stream, bucket) and call
+constexpr int kCandCap = 64;        // plateaus per (stream, bucket) and call; more -> dense re-run (AUTO)
 
 // wave-synchronous LDS phases: DS operations of one wave execute in order, the
 // compiler just must not move them across
@@ -924,7 +924,9 @@ __global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectAr
     }
     if (ncand == 0) return;
     if (ncand > kCandCap) {
-        if (lane == 0) atomicOr(&a.counters[2], kFlagRecOverflow);
+        // more plateaus in one bucket than the wave can stage: treated like a candidate-list
+        // overflow (AUTO mode re-runs the batch dense, which has no such limit)
+        if (lane == 0) atomicOr(&a.counters[2], kFlagHotOverflow);
         ncand = kCandCap;
     }
     wave_sync();
