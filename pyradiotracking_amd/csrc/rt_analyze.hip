@@ -82,7 +82,7 @@ struct rt_handle {
     int L = 32;            // segments per chunk
     int max_seg = 0;       // T for max_samples
     int max_chunks = 0;
-    hipStream_t s_scan = nullptr, s_copy = nullptr;
+    hipStream_t s_scan = nullptr;
     bool own_scan_stream = false;
     std::string err;
 
@@ -239,7 +239,7 @@ int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
 }
 
 // enqueue scan + detect + readback for the call described by sl.call
-int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool serial) {
+int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
     const CallCtx &c = sl.call;
     StftParams sp = make_stft_params(h, sl, c.iq, c.stream_stride, c.n_seg, c.tail_write);
     if (sp.chunks > h->max_chunks) {
@@ -265,7 +265,6 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool serial) {
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
 
-    (void)serial;
     hipStream_t sd = h->s_scan;  // in order behind the scan (see the header comment)
     DetectArgs a = make_detect_args(h, sl, c.n_seg, h->N, c.n_seg_last);
     a.prev = h->d_tail[c.tail_read];
@@ -355,7 +354,6 @@ void rt_destroy(rt_handle *h) {
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     }
     if (h->own_scan_stream && h->s_scan) (void)hipStreamDestroy(h->s_scan);
-    if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     delete h;
 }
 
@@ -437,7 +435,6 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking));
         h->own_scan_stream = true;
     }
-    RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
 
     const int S = cfg->n_streams, N = h->N, LG = h->LG;
     // window and twiddle tables (twiddles in double, rounded once to float32)
@@ -558,7 +555,7 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
     } else {
-        rc = enqueue_analysis(h, sl, c.mode_used == RT_MODE_DENSE, false);
+        rc = enqueue_analysis(h, sl, c.mode_used == RT_MODE_DENSE);
         if (rc != RT_OK) return rc;
     }
     c.pending = true;
@@ -672,7 +669,7 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
         RT_HIP(h, hipDeviceSynchronize());
         c.fell_back = true;
         c.mode_used = RT_MODE_DENSE;
-        int rc = enqueue_analysis(h, sl, true, true);
+        int rc = enqueue_analysis(h, sl, true);
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventSynchronize(sl.ev_done));
         flags = sl.h_counters[2];
