@@ -277,7 +277,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
         const int waves = S * kBuckets;
         hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
         // always launched: it is also the pass that re-zeroes the per-bucket counters
-        hipLaunchKernelGGL(detect_bucket<true>, dim3(waves), dim3(64), h->lds_large, sd, a);
+        hipLaunchKernelGGL(detect_bucket<true>, dim3(waves), dim3(256), h->lds_large, sd, a);
         hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), h->lds_final, sd, a);
     }
     RT_HIP(h, hipGetLastError());

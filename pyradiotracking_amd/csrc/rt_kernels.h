@@ -761,9 +761,10 @@ __device__ __forceinline__ void sort_bucket_regs(const uint2 *src, int n, int la
 // rare bigger ones (up to hot_cap cells, dynamic LDS).  Both are launched; a
 // wave whose bucket belongs to the other instantiation exits at once.
 template <bool LARGE>
-__global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectArgs a) {
+__global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    // small: 4 waves = 4 buckets per workgroup; large: one wave per workgroup
+    // small: 4 waves = 4 buckets per workgroup; large: the 4 waves sort ONE bucket together in
+    // LDS, then wave 0 finishes it alone
     // wave index made provably uniform; lane id from mbcnt (hipcc's value tracking on
     // `threadIdx.x & 63` sends the unrolled register sort into a compile-time blow-up)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -777,8 +778,10 @@ __global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectAr
     if (LARGE) {
         // last reader of the counter: keep the value for the statistics (finalize_records sums
         // them per stream -- one atomic per bucket on a single word would serialise ~11 ns each)
-        // and leave the counter zero for the slot's next call
-        if (lane == 0) {
+        // and leave the counter zero for the slot's next call -- after every wave of the
+        // workgroup has read it (they must all take the same exits below)
+        __syncthreads();
+        if (threadIdx.x == 0) {
             a.hot_seen[sb] = n_raw;
             if (n_raw) a.hot_count_rw[sb] = 0u;
         }
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectAr
     const DetectParams &dp = a.dp;
 
     // row means of the bucket's bins: np.mean(row) (analyze.py:375) from the scan's partial sums
-    for (int r = lane; r < F / kBuckets; r += 64) {
+    for (int r = lane; r < F / kBuckets && (!LARGE || wave == 0); r += 64) {
         const int bin = bkt + kBuckets * r;
         avg[r] = (float)row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + bin, a.chunks, F) / (float)T;
     }
@@ -822,7 +825,8 @@ __global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectAr
         }
         wave_sync();
     } else {
-        for (int i = lane; i < n2; i += 64) {
+        const int tid = threadIdx.x;
+        for (int i = tid; i < n2; i += 256) {
             if (i < n) {
                 const uint2 e = src[i];
                 keys[i] = e.x;
@@ -832,11 +836,11 @@ __global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectAr
                 vals[i] = 0.f;
             }
         }
-        wave_sync();
-        // bitonic sort in LDS by key = (bin, t); keys are unique (one entry per cell)
+        __syncthreads();
+        // bitonic sort in LDS by key = (bin, t), all 256 threads; keys are unique (one entry per cell)
         for (int k = 2; k <= n2; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = lane; t < (n2 >> 1); t += 64) {
+                for (int t = tid; t < (n2 >> 1); t += 256) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                     const int ixj = i | j;
                     const bool up = ((i & k) == 0);
@@ -849,9 +853,10 @@ __global__ __launch_bounds__(LARGE ? 64 : 256) void detect_bucket(const DetectAr
                         vals[ixj] = tv;
                     }
                 }
-                wave_sync();
+                __syncthreads();
             }
         }
+        if (wave != 0) return;  // no block-wide barrier below this point
     }
 
     // the predicate (analyze.py:370, 378) is evaluated where it is needed: one float division
