@@ -95,7 +95,7 @@ struct rt_handle {
     int64_t pool_cap = 0;
     Slot slot[kSlots];
 
-    int hot_cap = 8192, rec_cap = 1024;
+    int hot_cap = 8192, rec_cap = 1024, cand_cap = 32;
     size_t lds_large = 0, lds_small = 0, lds_final = 0, lds_dense = 0;
 
     uint64_t n_calls = 0;  // calls enqueued so far
@@ -206,6 +206,7 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.hot_seen = sl.d_hot_seen;
     a.hot_total = sl.h_hot_total;
     a.lds_cells = next_pow2(std::max(h->hot_cap, 64));
+    a.cand_cap = h->cand_cap;
     a.hot_cap = h->hot_cap;
     a.tbits = key_tbits(n_seg);
     a.raw = sl.d_raw;
@@ -409,7 +410,10 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->lds_dense = rec_lds_bytes(h->rec_cap);
     h->lds_final = rec_lds_bytes(h->rec_cap);
     {
-        const size_t tail = (((size_t)(h->N / kBuckets) * 4 + 15) & ~(size_t)15) + sizeof(rt_record) * kCandCap;
+        // plateaus a wave stages per bucket: a bucket holds N/16 bins; 32 keeps four waves' LDS
+        // under 40 KiB (all 16 bucket waves of a CU resident at once) for nperseg 256/512
+        h->cand_cap = (h->N / kBuckets <= 32) ? 32 : kCandCapMax;
+        const size_t tail = (((size_t)(h->N / kBuckets) * 4 + 15) & ~(size_t)15) + sizeof(rt_record) * h->cand_cap;
         h->lds_large = (size_t)next_pow2(std::max(h->hot_cap, 64)) * 8 + tail;
         h->lds_small = 4 * ((size_t)kSmallBucket * 8 + tail);
     }

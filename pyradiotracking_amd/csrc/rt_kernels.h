@@ -510,6 +510,7 @@ struct DetectArgs {
     uint32_t *hot_seen;        // [S][kBuckets] copy of the counts for statistics
     int32_t *hot_total;        // [S] (host-visible) candidate cells per stream
     int32_t lds_cells;         // cells the large instantiation's LDS holds (power of two)
+    int32_t cand_cap;          // plateaus a wave can stage per bucket (LDS)
     int32_t hot_cap;           // cells per (stream, bucket)
     int32_t tbits;             // key = bin << tbits | t
     rt_record *raw;            // [S][rec_cap] unordered records of the bucket waves
@@ -681,7 +682,7 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
 // sparse detection: one WAVE per (stream, bucket), bucket = bin & (kBuckets-1)
 // ---------------------------------------------------------------------------
 constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
-constexpr int kCandCap = 64;        // plateaus per (stream, bucket) and call; more -> dense re-run (AUTO)
+constexpr int kCandCapMax = 64;     // plateaus per (stream, bucket) and call (a.cand_cap <= this); more -> dense re-run (AUTO)
 
 // wave-synchronous LDS phases: DS operations of one wave execute in order, the
 // compiler just must not move them across
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     // per-wave LDS: keys | vals | row means of the bucket's bins | plateau candidates
     const int cap2 = LARGE ? a.lds_cells : kSmallBucket;
     const int nbins_b = F / kBuckets;
-    const size_t wave_bytes = (size_t)cap2 * 8 + (((size_t)nbins_b * 4 + 15) & ~(size_t)15) + sizeof(rt_record) * kCandCap;
+    const size_t wave_bytes = (size_t)cap2 * 8 + (((size_t)nbins_b * 4 + 15) & ~(size_t)15) + sizeof(rt_record) * a.cand_cap;
     unsigned char *base = dyn_smem + (LARGE ? 0 : (size_t)wave * wave_bytes);
     uint32_t *keys = reinterpret_cast<uint32_t *>(base);
     float *vals = reinterpret_cast<float *>(keys + cap2);
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
         if (km) {
             if (keep) {
                 const int idx = ncand + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
-                if (idx < kCandCap) {
+                if (idx < a.cand_cap) {
                     rt_record r;
                     r.stream = s;
                     r.fi = fi;
@@ -928,11 +929,11 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
         }
     }
     if (ncand == 0) return;
-    if (ncand > kCandCap) {
+    if (ncand > a.cand_cap) {
         // more plateaus in one bucket than the wave can stage: treated like a candidate-list
         // overflow (AUTO mode re-runs the batch dense, which has no such limit)
         if (lane == 0) atomicOr(&a.counters[2], kFlagHotOverflow);
-        ncand = kCandCap;
+        ncand = a.cand_cap;
     }
     wave_sync();
 
