@@ -50,7 +50,8 @@ typedef enum rt_status {
 
 /* how the batch is analysed */
 typedef enum rt_mode {
-    RT_MODE_AUTO = 0,   /* fused sparse path; falls back to dense on overflow   */
+    RT_MODE_AUTO = 0,   /* fused sparse path; re-runs a buffer dense when its candidate
+                           lists overflow and then stays dense for the next 16 buffers */
     RT_MODE_DENSE = 1,  /* materialise the power spectrogram (any input)        */
     RT_MODE_SPARSE = 2  /* fused sparse path only; overflow -> RT_E_CAPACITY    */
 } rt_mode;

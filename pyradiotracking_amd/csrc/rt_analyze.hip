@@ -98,6 +98,7 @@ struct rt_handle {
     int hot_cap = 8192, rec_cap = 1024, cand_cap = 32;
     size_t lds_large = 0, lds_small = 0, lds_final = 0, lds_dense = 0;
 
+    int dense_sticky = 0;  // AUTO mode: calls left to run dense directly after a sparse overflow
     uint64_t n_calls = 0;  // calls enqueued so far
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
@@ -547,6 +548,12 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
     c.tail_write = (h->tail_cur + 1) % kTails;
     c.n_seg_last = h->n_seg_last;
     c.mode_used = (h->cfg.mode == RT_MODE_DENSE) ? RT_MODE_DENSE : RT_MODE_SPARSE;
+    if (h->cfg.mode == RT_MODE_AUTO && h->dense_sticky > 0) {
+        // the input recently overflowed the candidate lists: do not pay for a sparse attempt
+        // plus a dense re-run on every buffer; probe the sparse path again after a while
+        c.mode_used = RT_MODE_DENSE;
+        --h->dense_sticky;
+    }
     if (T == 0) {
         // empty spectrogram: no signals; `_spectrogram_last` becomes an empty map
         const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
@@ -673,6 +680,7 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
         RT_HIP(h, hipDeviceSynchronize());
         c.fell_back = true;
         c.mode_used = RT_MODE_DENSE;
+        h->dense_sticky = 16;
         int rc = enqueue_analysis(h, sl, true);
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventSynchronize(sl.ev_done));

@@ -1008,6 +1008,50 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     publish_records(a, l, s, n);
 }
 
+// Device form of rt::scan_dense_row (same decisions): the row is read in blocks of 16 time
+// steps so the 16 independent loads overlap -- one dependent load per step made the kernel
+// latency-bound at ~1 us per cell.
+template <class OnRun>
+__device__ __forceinline__ bool scan_dense_row_blocked(const DetectParams &p, const float *row, int64_t stride,
+                                                       double row_sum, float *avg_out, OnRun on_run) {
+    const int T = p.n_seg;
+    constexpr int B = 16;
+    if (row_sum < 0.0) {  // row mean not known (caller-supplied spectrogram): sum it here, in t order
+        double sum = 0.0;
+        for (int t0 = 0; t0 < T; t0 += B) {
+            float v[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) v[k] = (t0 + k < T) ? row[(int64_t)(t0 + k) * stride] : 0.f;
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (t0 + k < T) sum += (double)v[k];
+        }
+        row_sum = sum;
+    }
+    const float avg = (float)row_sum / (float)T;  // np.mean(row) (analyze.py:375)
+    *avg_out = avg;
+    int b = -1;
+    for (int t0 = 0; t0 < T; t0 += B) {
+        float v[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) v[k] = (t0 + k < T) ? row[(int64_t)(t0 + k) * stride] : 0.f;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int t = t0 + k;
+            if (t >= T) break;
+            if (cell_above(v[k], avg, p.thr, p.snr)) {
+                if (b < 0) b = t;
+            } else if (b >= 0) {
+                const int rb = b;
+                b = -1;
+                on_run(rb, t, avg);
+            }
+        }
+    }
+    // a run still open here touches the end of the buffer: skipped (analyze.py:415)
+    return true;
+}
+
 // One workgroup per stream.  Phase 1: one thread per bin (strided) scans its
 // row sequentially in time -- the reference's row scan (analyze.py:357-450) in
 // run-based form.  Phase 2/3 as in detect_sparse.
@@ -1027,7 +1071,6 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     for (int fi = tid; fi < F; fi += kDetBlock) {
         const float *row = sp + fi;
         PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
-        auto cur = [&](int t) -> float { return row[(int64_t)t * F]; };
         double row_sum = -1.0;  // same partial sums (and bits) as the sparse path
         if (a.psum) row_sum = row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + fi, a.chunks, F);
         float av = 0.f;
@@ -1035,7 +1078,7 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
             int start;
             if (gate_run(dp, b, e, avg, prev, &start)) push_candidate(a, l, s, fi, start, e, avg, 0);
         };
-        scan_dense_row(dp, cur, row_sum, &av, on_run);
+        scan_dense_row_blocked(dp, row, F, row_sum, &av, on_run);
     }
     const int nrec = settled_count(a, l);
 

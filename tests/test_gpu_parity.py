@@ -396,13 +396,18 @@ def test_sparse_overflow_falls_back_to_dense():
         info = auto.native.call_info()
         ref.enqueue(buf.reshape(1, -1))
         want = ref.fetch_records()
-        assert info.fell_back == 1 and info.mode_used == _native.RT_MODE_DENSE
+        assert info.mode_used == _native.RT_MODE_DENSE and info.fell_back == (1 if k == 0 else 0)
         assert got.tobytes() == want.tobytes()
         assert len(got) == meta["n_signals"][k]
     only.enqueue(buffers[0].reshape(1, -1))
     with pytest.raises(_native.NativeError) as ei:
         only.fetch_records()
     assert ei.value.code == _native.RT_E_CAPACITY
+    # after an overflow AUTO stays dense for a while (no sparse attempt + re-run per buffer)
+    auto.enqueue(buffers[0].reshape(1, -1))
+    auto.fetch_records()
+    info = auto.native.call_info()
+    assert info.mode_used == _native.RT_MODE_DENSE and info.fell_back == 0
 
 
 def test_dense_input_everything_above_threshold():
