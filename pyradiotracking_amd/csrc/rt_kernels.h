@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
 // latency-bound at ~1 us per cell.
 template <class OnRun>
 __device__ __forceinline__ bool scan_dense_row_blocked(const DetectParams &p, const float *row, int64_t stride,
-                                                       double row_sum, float *avg_out, OnRun on_run) {
+                                                       double row_sum, int t_begin, int t_end, float *avg_out,
+                                                       OnRun on_run) {
     const int T = p.n_seg;
     constexpr int B = 16;
     if (row_sum < 0.0) {  // row mean not known (caller-supplied spectrogram): sum it here, in t order
@@ -1030,23 +1031,32 @@ __device__ __forceinline__ bool scan_dense_row_blocked(const DetectParams &p, co
     }
     const float avg = (float)row_sum / (float)T;  // np.mean(row) (analyze.py:375)
     *avg_out = avg;
+    // This thread owns the runs that START in [t_begin, t_end): a run already open at t_begin
+    // belongs to the thread of the earlier range (which follows it past its own end).
+    bool in_cont = (t_begin > 0) && cell_above(row[(int64_t)(t_begin - 1) * stride], avg, p.thr, p.snr);
     int b = -1;
-    for (int t0 = 0; t0 < T; t0 += B) {
+    for (int t0 = t_begin; t0 < T; t0 += B) {
         float v[B];
 #pragma unroll
         for (int k = 0; k < B; ++k) v[k] = (t0 + k < T) ? row[(int64_t)(t0 + k) * stride] : 0.f;
+        bool done = false;
 #pragma unroll
         for (int k = 0; k < B; ++k) {
             const int t = t0 + k;
-            if (t >= T) break;
-            if (cell_above(v[k], avg, p.thr, p.snr)) {
-                if (b < 0) b = t;
+            if (t >= T || done) break;
+            const bool ab = cell_above(v[k], avg, p.thr, p.snr);
+            if (in_cont) {
+                if (!ab) in_cont = false;
+            } else if (ab) {
+                if (b < 0 && t < t_end) b = t;
             } else if (b >= 0) {
                 const int rb = b;
                 b = -1;
                 on_run(rb, t, avg);
             }
+            if (t + 1 >= t_end && b < 0) done = true;  // own range finished, nothing open
         }
+        if (done) break;
     }
     // a run still open here touches the end of the buffer: skipped (analyze.py:415)
     return true;
@@ -1068,7 +1078,17 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
 
     const DetectParams &dp = a.dp;
     const float *sp = a.spec + (int64_t)s * T * F;
-    for (int fi = tid; fi < F; fi += kDetBlock) {
+    // work items = (bin, time range): with few bins the time axis is split so that all 1024
+    // threads scan (runs are owned by the range they start in)
+    int Q = 1;
+    if (a.psum)
+        while (F * Q * 2 <= kDetBlock && Q * 2 * 64 <= T) Q *= 2;
+    const int span = (T + Q - 1) / Q;
+    for (int item = tid; item < F * Q; item += kDetBlock) {
+        const int fi = item % F, q = item / F;
+        const int t_begin = q * span;
+        const int t_end = (t_begin + span < T) ? t_begin + span : T;
+        if (t_begin >= T) continue;
         const float *row = sp + fi;
         PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
         double row_sum = -1.0;  // same partial sums (and bits) as the sparse path
@@ -1078,7 +1098,7 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
             int start;
             if (gate_run(dp, b, e, avg, prev, &start)) push_candidate(a, l, s, fi, start, e, avg, 0);
         };
-        scan_dense_row_blocked(dp, row, F, row_sum, &av, on_run);
+        scan_dense_row_blocked(dp, row, F, row_sum, t_begin, t_end, &av, on_run);
     }
     const int nrec = settled_count(a, l);
 
