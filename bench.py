@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--input", default="c64", choices=["c64", "u8"],
                     help="IQ representation in HBM: complex64 (the BASELINE workload) or the RTL-SDR wire format "
                          "(interleaved uint8, converted inside the scan kernel; SURVEY 8(f) rank 1)")
+    ap.add_argument("--threshold-dbw", type=float, default=None,
+                    help="signal_threshold_dbw (default: the reference's -90, or -80 with --input u8)")
     ap.add_argument("--trains", action="store_true",
                     help="BASELINE config 5 style input: 8-16 tags per stream, pulse trains 10-38 ms, period 0.1-1 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +97,8 @@ def main():
         del iq_c
     else:
         iq = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}", trains=args.trains)
+    if args.threshold_dbw is not None:
+        kw["signal_threshold_dbw"] = args.threshold_dbw
     stream = torch.cuda.current_stream()
     an = BatchSignalAnalyzer(
         [str(i) for i in range(S)],
