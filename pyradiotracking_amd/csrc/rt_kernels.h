@@ -182,6 +182,9 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
 #ifndef RT_ABLATE
 #define RT_ABLATE 0
 #endif
+#ifndef RT_W_REGS
+#define RT_W_REGS 0  // A/B switch: window coefficients in VGPRs (N = 256) instead of LDS -- measured: no difference
+#endif
 
 
 #define RT_ABLATE_STOP(n)                                               \
@@ -259,6 +262,15 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
     }
     __syncthreads();
 
+    // N = 256: the 16 window coefficients of a lane fit the register budget of 3 waves/SIMD
+    // (saves four LDS reads and their exposed latency per step); larger N reads them per step
+    constexpr bool W_IN_REGS = (R3 == 1) && (RT_W_REGS != 0);
+    float wreg[16];
+    if constexpr (W_IN_REGS) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) wreg[m] = p.window[lt + LG * m];
+    }
+
     float acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -323,7 +335,9 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             float4 w4;
-            if constexpr (W_IN_LDS) {
+            if constexpr (W_IN_REGS) {
+                w4 = make_float4(wreg[4 * mm], wreg[4 * mm + 1], wreg[4 * mm + 2], wreg[4 * mm + 3]);
+            } else if constexpr (W_IN_LDS) {
                 w4 = w_lds[mm * LG + lt];
             } else {
                 w4 = make_float4(p.window[lt + LG * (4 * mm)], p.window[lt + LG * (4 * mm + 1)],
