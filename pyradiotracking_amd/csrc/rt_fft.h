@@ -8,6 +8,29 @@
 
 namespace rt {
 
+#ifndef RT_PK
+#define RT_PK 0  // complex values as <2 x float>: butterflies become v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+#endif
+
+#if RT_PK
+// A complex value is one aligned VGPR pair and complex add/sub/scale/twiddle are single packed
+// instructions (two float32 lanes each, IEEE-identical per component to the scalar forms).
+typedef float cf __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+// (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x): one packed multiply and one packed fma; the same
+// roundings as fmaf(a.x, b.x, -(a.y*b.y)), fmaf(a.x, b.y, a.y*b.x).
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    cf t = a.yy * b.yx;
+    t.x = -t.x;
+    return __builtin_elementwise_fma(a.xx, b, t);
+}
+// multiply by -i  (forward-transform quarter turn): (x + iy)(-i) = y - ix
+__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
+__device__ __forceinline__ cf cscale(cf a, float s) { return a * s; }
+__device__ __forceinline__ cf cneg(cf a) { return -a; }
+#else
 struct cf {
     float x, y;
 };
@@ -22,6 +45,8 @@ __device__ __forceinline__ cf cmul(cf a, cf b) {
 // multiply by -i  (forward-transform quarter turn): (x + iy)(-i) = y - ix
 __device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
 __device__ __forceinline__ cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
+__device__ __forceinline__ cf cneg(cf a) { return cf{-a.x, -a.y}; }
+#endif
 
 // 4-point DFT in place, natural order out.
 __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3) {
@@ -44,8 +69,9 @@ __device__ __forceinline__ void dft2(cf &a0, cf &a1) {
 #define RT_SIN_PI_8 0.38268343236508977173f
 
 // multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
-__device__ __forceinline__ cf mul_w8_1(cf a) { return cf{(a.x + a.y) * RT_SQRT1_2, (a.y - a.x) * RT_SQRT1_2}; }
-__device__ __forceinline__ cf mul_w8_3(cf a) { return cf{(a.y - a.x) * RT_SQRT1_2, -(a.x + a.y) * RT_SQRT1_2}; }
+// (a + (-i)a) = (x + y, y - x);  ((-i)a - a) = (y - x, -(x + y)) -- the same sums, then one scale
+__device__ __forceinline__ cf mul_w8_1(cf a) { return cscale(cadd(a, mul_mi(a)), RT_SQRT1_2); }
+__device__ __forceinline__ cf mul_w8_3(cf a) { return cscale(csub(mul_mi(a), a), RT_SQRT1_2); }
 
 // 8-point DFT, natural order in and out:  n = n0 + 2*n1, k = ka + 4*kb
 // (4-point DFTs over n1 for each n0, twiddle W8^(n0*ka), 2-point over n0).
@@ -83,8 +109,7 @@ __device__ __forceinline__ void dft16(cf (&v)[16]) {
     v[7] = cmul(v[7], w3);                    // n0=3 ka=1 : W^3
     v[11] = mul_w8_3(v[11]);                  // n0=3 ka=2 : W^6
     {                                         // n0=3 ka=3 : W^9 = -W^1
-        cf t = cmul(v[15], w1);
-        v[15] = cf{-t.x, -t.y};
+        v[15] = cneg(cmul(v[15], w1));
     }
     // 4-point DFTs over n0 for each ka: Y[ka + 4*kb] lands in v[4*ka + kb]
     dft4(v[0], v[1], v[2], v[3]);

@@ -123,6 +123,14 @@ __device__ __forceinline__ void group_sync() {
     }
 }
 
+// ordering point for LDS traffic that stays inside one wave (DS operations of a wave execute in program
+// order; only the compiler must not move them across)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // v + (v of another lane of the same row of 16), the lane picked by a DPP control: the shuffle
 // rides on the add's operand fetch, no LDS round trip (ds_bpermute costs ~100 cycles of latency
 // per step, four dependent steps per segment)
@@ -147,9 +155,11 @@ __device__ __forceinline__ cf group_sum(cf v, cf *red /* [kBlock/64] LDS */) {
         v.y += __shfl_xor(v.y, off, 64);
     }
     if constexpr (LG > 64) {
+        // One workgroup barrier.  `red` needs no barrier before the write: its readers of the previous step
+        // all read it before they reached that step's exchange barrier, which this wave has passed since.
+        // The barrier also separates the previous step's last use of the exchange rows from this step's.
         const int wave = threadIdx.x >> 6;
         constexpr int WPG = LG / 64;  // waves per group
-        __syncthreads();
         if ((threadIdx.x & 63) == 0) red[wave] = v;
         __syncthreads();
         const int w0 = (wave / WPG) * WPG;
@@ -202,6 +212,26 @@ struct iq_u8 {
     uint16_t iq;  // low byte I, high byte Q
 };
 
+#ifndef RT_NT_LOADS
+#define RT_NT_LOADS 1  // A/B switch: IQ loads carry the non-temporal hint (read once; keep L1/L2 for the tables)
+#endif
+__device__ __forceinline__ cf load_iq(const cf *p) {
+#if RT_NT_LOADS
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
+    return cf{v.x, v.y};
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ iq_u8 load_iq(const iq_u8 *p) {
+#if RT_NT_LOADS
+    return iq_u8{__builtin_nontemporal_load(&p->iq)};
+#else
+    return *p;
+#endif
+}
+
 // pyrtlsdr's packed_bytes_to_iq is (byte / 127.5) - 1 per component (in float64); here one
 // float32 fma per component, at most one float32 ulp away, then float32 like complex64 input
 __device__ __forceinline__ cf to_cf(cf x) { return x; }
@@ -211,7 +241,7 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
 }
 
 template <int R3, int MODE, bool U8 = false>
-__global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES < 3) ? 3 : RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
+__global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 >= 8) && RT_SCAN_MIN_WAVES < 3) ? 3 : RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
     constexpr int LG = 16 * R3;
@@ -224,8 +254,19 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
     const int tid = threadIdx.x;
     const int g = tid / LG;
     const int lt = tid % LG;
+#ifndef RT_BLOCK_ORDER
+#define RT_BLOCK_ORDER 1  // A/B switch: 1 = latest chunks first (all streams), 0 = stream-major ascending
+#endif
+#if RT_BLOCK_ORDER
+    // Workgroups are dispatched in index order.  The ones holding a stream's last segments also write the
+    // look-back tail columns and run longer; they go first so that their extra time is hidden behind the
+    // rest of the launch instead of stretching its end.
+    const int s = blockIdx.x % p.n_streams;
+    const int cb = p.blocks_per_stream - 1 - blockIdx.x / p.n_streams;
+#else
     const int s = blockIdx.x / p.blocks_per_stream;
     const int cb = blockIdx.x % p.blocks_per_stream;
+#endif
     const int chunk = cb * GPW + g;
     const bool chunk_ok = chunk < p.chunks;
     const int c0 = chunk * p.segs_per_chunk;
@@ -240,7 +281,13 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
     // and a wave per SIMD of occupancy.
     constexpr bool W_IN_LDS = (R3 <= 8);  // N = 4096: the window comes from L2 as well (3 workgroups per CU)
     __shared__ __attribute__((aligned(16))) float4 w_lds[W_IN_LDS ? 4 * LG : 1];    // [m/4][lane]: w[lane + LG*(4*(m/4) + 0..3)]
-    constexpr bool T1_IN_LDS = (R3 <= 4);  // N >= 2048: read the (L2-resident) table directly, LDS is needed for occupancy
+    constexpr bool T1_IN_LDS = (R3 <= 4);
+    // N >= 2048: the full table (128 B per lane) does not fit LDS next to the exchange rows at 3 workgroups
+    // per CU, and read from L2 it doubles the step's L1 fill traffic (measured +0.2 .. +0.34 ms per launch).
+    // Only W^(a), W^(2a), W^(4a), W^(8a) are staged (32 B per lane); the other eleven factors are products
+    // of two to four of them (W^(a k) with k in binary), 44 more VALU operations per step.
+    constexpr bool T1_FACTORED = !T1_IN_LDS;
+    __shared__ __attribute__((aligned(16))) float4 t1f_lds[T1_FACTORED ? 2 * LG : 1];  // [0][lane] = (W^a, W^2a), [1][lane] = (W^4a, W^8a)
     __shared__ __attribute__((aligned(16))) float4 t1_lds[T1_IN_LDS ? 8 * LG : 1];   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
     __shared__ __attribute__((aligned(16))) float4 t2_lds[R3 > 1 ? 8 * R3 : 1];  // [q/2][b]
     if constexpr (W_IN_LDS) {
@@ -255,6 +302,13 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
             const int kk = idx / LG, l = idx % LG;
             const cf a = p.tw1[l * 16 + 2 * kk], b = p.tw1[l * 16 + 2 * kk + 1];
             t1_lds[idx] = make_float4(a.x, a.y, b.x, b.y);
+        }
+    }
+    if constexpr (T1_FACTORED) {
+        for (int l = tid; l < LG; l += kBlock) {
+            const cf w1 = p.tw1[l * 16 + 1], w2 = p.tw1[l * 16 + 2], w4 = p.tw1[l * 16 + 4], w8 = p.tw1[l * 16 + 8];
+            t1f_lds[l] = make_float4(w1.x, w1.y, w2.x, w2.y);
+            t1f_lds[LG + l] = make_float4(w4.x, w4.y, w8.x, w8.y);
         }
     }
     if constexpr (R3 > 1) {
@@ -304,7 +358,7 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
         seg0 = seg0 < seg_hi ? seg0 : seg_hi;
         const raw_t *src = stream_iq + (int64_t)seg0 * N + lt;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) nxt[m] = src[LG * m];
+        for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
     }
 
     for (int i = i_first; i <= L; ++i) {
@@ -321,7 +375,7 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
             seg1 = seg1 < seg_hi ? seg1 : seg_hi;
             const raw_t *src = stream_iq + (int64_t)seg1 * N + lt;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) nxt[m] = src[LG * m];
+            for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
         }
 
         if constexpr (MODE == 3) {
@@ -363,17 +417,32 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
         RT_ABLATE_STOP(1)  // loads + detrend + window
         // pass 1
         dft16(v);
+        if constexpr (T1_FACTORED) {
+            const float4 ta = t1f_lds[lt], tb = t1f_lds[LG + lt];
+            const cf w1{ta.x, ta.y}, w2{ta.z, ta.w}, w4{tb.x, tb.y}, w8{tb.z, tb.w};
+            const cf w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+            v[1] = cmul(v[1], w1);
+            v[2] = cmul(v[2], w2);
+            v[3] = cmul(v[3], w3);
+            v[4] = cmul(v[4], w4);
+            v[5] = cmul(v[5], w5);
+            v[6] = cmul(v[6], w6);
+            v[7] = cmul(v[7], w7);
+            v[8] = cmul(v[8], w8);
+            v[9] = cmul(v[9], cmul(w8, w1));
+            v[10] = cmul(v[10], cmul(w8, w2));
+            v[11] = cmul(v[11], cmul(w8, w3));
+            v[12] = cmul(v[12], cmul(w8, w4));
+            v[13] = cmul(v[13], cmul(w8, w5));
+            v[14] = cmul(v[14], cmul(w8, w6));
+            v[15] = cmul(v[15], cmul(w8, w7));
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float4 t;
-            if constexpr (T1_IN_LDS) {
-                t = t1_lds[kk * LG + lt];
-            } else {
-                const float4 *row = reinterpret_cast<const float4 *>(p.tw1 + lt * 16);  // 128 B per lane
-                t = row[kk];
+            for (int kk = 0; kk < 8; ++kk) {
+                const float4 t = t1_lds[kk * LG + lt];
+                if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
+                v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
             }
-            if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
-            v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
         }
 
         RT_ABLATE_STOP(2)  // + pass 1 and twiddles
@@ -406,14 +475,16 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
                 if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
                 v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
             }
-            group_sync<LG>();  // everyone has read exchange 1
+            // Exchange 2 stays inside the R3 lanes that share k1 (R3 consecutive lanes, R3 consecutive
+            // rows: the rows those very lanes read in exchange 1), so wave-level ordering is enough.
+            wave_sync();
             {
                 const int k1 = lt / R3, b = lt % R3;
 #pragma unroll
                 for (int q1 = 0; q1 < 16; ++q1)
                     gx[(k1 * R3 + q1 / G) * kRowF2 + (q1 % G) * R3 + b] = v[q1];
             }
-            group_sync<LG>();
+            wave_sync();
             {
                 const float4 *row = reinterpret_cast<const float4 *>(gx + lt * kRowF2);
 #pragma unroll
@@ -423,10 +494,14 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
                     v[2 * j + 1] = cf{q.z, q.w};
                 }
             }
+            RT_ABLATE_STOP(5)  // + pass-2 twiddles and exchange 2
             // pass 3
             dft_groups<R3>(v);
         }
-        group_sync<LG>();  // rows are free for the next segment
+        // rows are free for the next segment: inside a wave by program order; across the waves of a larger
+        // group the next step's mean reduction has the barrier (group_sum)
+        wave_sync();
+        RT_ABLATE_STOP(6)  // + pass 3
 
         // |X|^2 * scale  (scipy _spectral_py.py:2126-2128)
         float P[16];
@@ -436,21 +511,58 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 == 16) && RT_SCAN_MIN_WAVES
         if (active && !halo) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += P[r];
-            if constexpr (MODE != 0) {
-                float *dst = p.spec + ((int64_t)s * T + seg) * N;
+        }
+        if constexpr (RT_ABLATE == 8) continue;  // + power and row sums only
+        {
+            // spectrogram row (dense modes) and look-back tail column (last K segments)
+            const int col = seg - (T - p.tail_cols);
+            const bool to_spec = (MODE == 1 || MODE == 2) && active && !halo;
+            const bool to_tail = (MODE != 2) && active && !halo && col >= 0;
+            float *spec_dst = p.spec + ((int64_t)s * T + seg) * N;
+            float *tail_dst = p.tail + ((int64_t)s * p.tail_cols + col) * N;
+            if constexpr (R3 == 1) {
+                // bin = lane + 16 r: every store instruction already writes 64-byte runs
+                if (to_spec) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[bin_of<R3>(lt, r)] = P[r];
-            }
-            if constexpr (MODE != 2) {
-                const int col = seg - (T - p.tail_cols);
-                if (col >= 0) {
-                    float *dst = p.tail + ((int64_t)s * p.tail_cols + col) * N;
+                    for (int r = 0; r < 16; ++r) spec_dst[bin_of<R3>(lt, r)] = P[r];
+                }
+                if (to_tail) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[bin_of<R3>(lt, r)] = P[r];
+                    for (int r = 0; r < 16; ++r) tail_dst[bin_of<R3>(lt, r)] = P[r];
+                }
+            } else {
+                // Larger N: a lane's 16 bins are N/16 (or more) apart and neighbouring lanes' bins 64..512 B
+                // apart, so direct stores would touch one cache line per lane.  The row goes through the
+                // group's (now free) exchange rows instead and leaves as whole lines.  The barrier inside
+                // must be reached by every wave of the workgroup: the decision is made for the workgroup
+                // (its last group holds the latest segment), the stores stay per group.
+                bool need;
+                if constexpr (MODE == 1 || MODE == 2) {
+                    need = true;
+                } else if constexpr (LG > 64) {
+                    const int seg_last = (cb * GPW + GPW - 1) * L + L - i;
+                    need = !halo && seg_last >= T - p.tail_cols;
+                } else {
+                    need = to_tail;
+                }
+                if (need) {
+                    float *row = reinterpret_cast<float *>(gx);  // N floats of the group's LG * 36
+                    group_sync<LG>();  // every wave of the group is done with its exchange rows
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) row[bin_of<R3>(lt, r)] = P[r];
+                    group_sync<LG>();
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float q = row[j * LG + lt];
+                        if (to_spec) spec_dst[j * LG + lt] = q;
+                        if (to_tail) tail_dst[j * LG + lt] = q;
+                    }
+                    wave_sync();  // (across waves: the next step's mean-reduction barrier)
                 }
             }
         }
 
+        if constexpr (RT_ABLATE == 7) continue;  // + power, row sums, tail columns (no candidate test)
         if constexpr (MODE == 0) {
             // candidates are rare: one max over the lane's 16 cells and a single compare in the
             // common path, the per-cell tests only where that fires.  (A NaN cell means the whole
@@ -733,14 +845,6 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
 // ---------------------------------------------------------------------------
 constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
 constexpr int kCandCapMax = 64;     // plateaus per (stream, bucket) and call (a.cand_cap <= this); more -> dense re-run (AUTO)
-
-// wave-synchronous LDS phases: DS operations of one wave execute in order, the
-// compiler just must not move them across
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Bitonic sort of 64*M (key, value) pairs held in registers, element i = m*64 + lane.
 // Compare-exchange distances >= 64 pair two registers of the same lane (no data
