@@ -9,16 +9,19 @@ This module is the message model the path emits (reference
 ``radiotracking/__init__.py:13-22`` for the dB helpers and ``:110-202`` for
 ``Signal``).  Downstream consumers of the reference (matcher, CSV/MQTT sinks)
 only look at the attributes / ``header`` / ``as_list`` / ``as_dict`` defined
-here, so these are kept field-for-field compatible.
+here, so these are kept field-for-field compatible.  ``MatchedSignal`` /
+``MatchingSignal`` (reference ``:205-406``) are the result types of the
+cross-SDR matcher (``pyradiotracking_amd.match``).
 """
 import datetime as _dt
-from typing import Any, Dict, List, Union
+import statistics as _statistics
+from typing import Any, Dict, List, Optional, Union
 
 import numpy as np
 
 __version__ = "0.1.0"
 
-__all__ = ["dB", "from_dB", "Signal", "__version__"]
+__all__ = ["dB", "from_dB", "Signal", "MatchedSignal", "MatchingSignal", "__version__"]
 
 
 def dB(val):
@@ -106,3 +109,126 @@ class Signal:
 
     def __hash__(self):
         return hash(tuple(self.as_list))
+
+
+class MatchedSignal:
+    """A signal seen on several devices of one station: earliest timestamp, median frequency,
+    longest duration and one average power per device (``None`` where a device saw nothing).
+
+    Constructor, ``header``, ``as_list``, ``as_dict``, ``repr`` and ``str`` follow the reference
+    record (radiotracking/__init__.py:205-276)."""
+
+    def __init__(
+        self,
+        devices: List[str],
+        ts: Union[_dt.datetime, str],
+        frequency: Union[float, str],
+        duration: Union[_dt.timedelta, float, str],
+        *avgs: Optional[float],
+    ):
+        self.devices = devices
+        self._ts = ts if isinstance(ts, _dt.datetime) else _dt.datetime.fromisoformat(ts)
+        self._frequency = float(frequency)
+        self._duration = duration if isinstance(duration, _dt.timedelta) else _dt.timedelta(seconds=float(duration))
+        self._avg_list: List[Optional[float]] = []
+        for a in avgs:
+            try:
+                self._avg_list.append(float(a))
+            except TypeError:  # None marks a device without a detection
+                self._avg_list.append(None)
+
+    @property
+    def ts(self) -> _dt.datetime:
+        return self._ts
+
+    @property
+    def frequency(self) -> float:
+        return self._frequency
+
+    @property
+    def duration(self) -> _dt.timedelta:
+        return self._duration
+
+    @property
+    def _avgs(self) -> List[Optional[float]]:
+        return self._avg_list
+
+    @property
+    def header(self) -> List[str]:
+        return ["Time", "Frequency", "Duration", *self.devices]
+
+    @property
+    def as_list(self) -> List[Any]:
+        return [self.ts, self.frequency, self.duration, *self._avgs]
+
+    @property
+    def as_dict(self) -> Dict[str, Any]:
+        return dict(zip(self.header, self.as_list))
+
+    def __repr__(self) -> str:
+        powers = ", ".join(repr(a) for a in self._avgs)
+        return f"MatchedSignal({self.devices}, {self.ts}, {self.frequency}, {self.duration}, {powers})"
+
+    def __str__(self) -> str:
+        powers = ", ".join(f"{a:.2f}" if a else "None" for a in self._avgs)
+        mhz = self.frequency / 1000 / 1000
+        ms = self.duration.total_seconds() * 1000
+        return f"{type(self).__name__}<SDRs {self.devices}, {mhz:.3f} MHz, {ms:.2f} ms, dBWs: [{powers}]>"
+
+
+class MatchingSignal(MatchedSignal):
+    """A group of per-device signals that is still collecting members
+    (radiotracking/__init__.py:279-406): at most one ``Signal`` per device, the louder one on a
+    repeat; ``ts`` / ``frequency`` / ``duration`` are min / median / max over the members.
+
+    Groups handed out by :class:`pyradiotracking_amd.match.SignalMatcher` are snapshots of the
+    native matcher's state: they carry the aggregated values and no member ``Signal`` objects."""
+
+    def __init__(self, devices: List[str]):
+        self.devices = devices
+        self._sigs: Dict[str, Signal] = {}
+        self._snapshot = None  # (ts, frequency, duration, avgs) of a group exported by the native matcher
+
+    @classmethod
+    def from_aggregate(cls, devices, ts, frequency, duration, avgs) -> "MatchingSignal":
+        grp = cls(devices)
+        grp._snapshot = (ts, float(frequency), duration, list(avgs))
+        return grp
+
+    @property
+    def ts(self) -> _dt.datetime:
+        return self._snapshot[0] if self._snapshot else min(s.ts for s in self._sigs.values())
+
+    @property
+    def frequency(self) -> float:
+        return self._snapshot[1] if self._snapshot else _statistics.median(s.frequency for s in self._sigs.values())
+
+    @property
+    def duration(self) -> _dt.timedelta:
+        return self._snapshot[2] if self._snapshot else max(s.duration for s in self._sigs.values())
+
+    @property
+    def _avgs(self) -> List[Optional[float]]:
+        if self._snapshot:
+            return self._snapshot[3]
+        return [self._sigs[d].avg if d in self._sigs else None for d in self.devices]
+
+    def has_member(self, sig: Signal, time_diff: _dt.timedelta = _dt.timedelta(0), bandwidth: float = 0,
+                   duration_diff: Optional[_dt.timedelta] = None) -> bool:
+        """Does ``sig`` overlap this group in frequency (+- bandwidth / 2), in time (+- time_diff)
+        and, if ``duration_diff`` is given, in duration (+- duration_diff / 2)?"""
+        centre, first, span = self.frequency, self.ts, self.duration
+        if sig.frequency - bandwidth / 2 > centre or sig.frequency + bandwidth / 2 < centre:
+            return False
+        if sig.ts - time_diff > first + span or (sig.ts + sig.duration) + time_diff < first:
+            return False
+        if duration_diff and (sig.duration - duration_diff / 2 > span or sig.duration + duration_diff / 2 < span):
+            return False
+        return True
+
+    def add_member(self, sig: Signal) -> None:
+        if self._snapshot:
+            raise TypeError("this group is a snapshot of the native matcher; it takes no members")
+        have = self._sigs.get(sig.device)
+        if have is None or have.avg < sig.avg:
+            self._sigs[sig.device] = sig

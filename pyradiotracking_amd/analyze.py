@@ -179,6 +179,7 @@ class BatchSignalAnalyzer:
             hip_stream=hip_stream,
         )
         self._decoder = _RecordDecoder(fft_nperseg, sample_rate, center_freq, calibration_db)
+        self.decoder = self._decoder  # record -> field conversion, shared with pyradiotracking_amd.match
         self.gpu = gpu
         self._hip_stream = hip_stream
 

@@ -1,6 +1,6 @@
 """Build the native pieces in-tree (no JIT cache: the .so files travel with the repo snapshot).
 
-* ``librt_analyze.so``   gfx950 HIP kernels + C-ABI (include/rt_analyze.h)   -- the product
+* ``librt_analyze.so``   gfx950 HIP kernels + C-ABI (include/rt_analyze.h, include/rt_match.h) -- the product
 * ``_rt_hostcheck.so``   host build of csrc/rt_core.h's scalar logic          -- unit tests only
 """
 import os
@@ -54,6 +54,7 @@ def build_library(force=False, verbose=False):
         "-o",
         LIB,
         os.path.join(CSRC, "rt_analyze.hip"),
+        os.path.join(CSRC, "rt_match.cpp"),  # host-only part of the C-ABI (include/rt_match.h)
     ]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

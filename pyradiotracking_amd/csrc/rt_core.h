@@ -18,7 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__)
+#if defined(__HIP__)  // HIP translation units only (hipcc also compiles the plain C++ ones)
 #define RT_HD __host__ __device__ __forceinline__
 #else
 #define RT_HD inline

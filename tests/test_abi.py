@@ -19,26 +19,36 @@ def lib():
     return _native.load_library()
 
 
-def _declared_symbols():
-    text = open(os.path.join(REPO, "include", "rt_analyze.h")).read()
+def _declared_symbols(header="rt_analyze.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
+    from pyradiotracking_amd import match
+
     assert _declared_symbols() == sorted(_native.ABI_SYMBOLS)
+    assert _declared_symbols("rt_match.h") == sorted(match.MATCH_SYMBOLS)
 
 
 def test_every_declared_symbol_is_exported(lib):
     raw = C.CDLL(_native.LIB_PATH)
-    for name in _declared_symbols():
-        assert hasattr(raw, name), name
+    headers = [h for h in os.listdir(os.path.join(REPO, "include")) if h.endswith(".h")]
+    assert sorted(headers) == ["rt_analyze.h", "rt_match.h"]
+    for header in headers:
+        for name in _declared_symbols(header):
+            assert hasattr(raw, name), name
     assert lib.rt_abi_version() == 1
 
 
 def test_record_layout_matches_header():
+    from pyradiotracking_amd import match
+
     assert _native.RECORD_DTYPE.itemsize == 40
     assert C.sizeof(_native.RtCallInfo) == 48
+    assert match.SIGNAL_DTYPE.itemsize == 40 and match.MATCHED_DTYPE.itemsize == 32
+    assert C.sizeof(match.RtMatchConfig) == 40
 
 
 def test_code_object_targets_gfx950():

@@ -494,3 +494,57 @@ def test_config2_full_size_properties():
         for g, x in zip(sigs, want):
             for name in ("max", "avg", "noise", "snr", "std"):
                 assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB
+
+
+# ---------------------------------------------------------------------------
+# analysis -> matcher on record arrays
+# ---------------------------------------------------------------------------
+def test_analysis_records_feed_the_matcher():
+    """Four SDRs of one station hear the same tags at different levels.  The record-array path
+    (rt_fetch -> records_from_analysis -> rt_match_add) must consume the same groups as the
+    oracle matcher fed with the Signal objects of the same call, buffer after buffer."""
+    _need_gpu()
+    from oracle.match_oracle import MatchInput, OracleMatcher
+    from pyradiotracking_amd import match as rtm
+
+    fs, nperseg, window = 300000, 256, "hamming"
+    n_dev, n_buf, blen = 4, 6, 300000
+    w = oracle.window_coefficients(window, nperseg)
+    rng = np.random.default_rng(42)
+    tags = synth.tag_trains(rng, n_buf * blen, fs, w, n_tags=(5, 5), dur_ms=(12, 30), period_s=(0.25, 0.7),
+                            keep_clear_tail=0)
+    iq = []
+    for d in range(n_dev):
+        gain = 10 ** (-rng.uniform(0, 12) / 20)
+        heard = [synth.Pulse(p.start, p.length, p.freq, p.amp * gain, p.phase) for p in tags if rng.uniform() < 0.85]
+        iq.append(synth.make_stream(synth.StreamSpec(n_buf * blen, fs, heard), 900 + d))
+    iq = np.stack(iq)
+    devices = [str(d) for d in range(n_dev)]
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window)
+    b = _batch_for(kw, n_dev, blen, "sparse")
+    params = dict(matching_timeout_s=1.0, matching_time_diff_s=0.002, matching_bandwidth_hz=2 * fs / nperseg,
+                  matching_duration_diff_ms=4.0)
+    nm = rtm.NativeMatcher(n_dev, params["matching_timeout_s"], params["matching_time_diff_s"],
+                           params["matching_bandwidth_hz"], params["matching_duration_diff_ms"])
+    om = OracleMatcher(devices, **params)
+    got_groups, want_groups = [], []
+    for k in range(n_buf):
+        ts_start = gu.TS0 + datetime.timedelta(seconds=k * blen / fs)
+        b.enqueue(np.ascontiguousarray(iq[:, k * blen:(k + 1) * blen]))
+        rec = b.fetch_records()
+        # the analyzer hands signals on stream by stream (each SDR process drains its own buffer)
+        sig_rec = rtm.records_from_analysis(rec, b.decoder, [rtm.datetime_to_us(ts_start)] * n_dev, list(range(n_dev)))
+        kept = rec[rec["shadowed"] == 0]
+        sigs = b.decoder.signals(kept, devices, [ts_start] * n_dev)
+        assert len(sigs) == len(sig_rec)
+        for s, r in zip(sigs, sig_rec):  # the vectorised conversion is the per-Signal one
+            assert (rtm.datetime_to_us(s.ts), s.duration // datetime.timedelta(microseconds=1), s.frequency, s.avg) == \
+                (int(r["ts_us"]), int(r["duration_us"]), float(r["frequency"]), float(r["avg"]))
+        out = nm.add(sig_rec)
+        got_groups += [(int(g["ts_us"]), float(g["frequency"]), int(g["duration_us"]), [float(x) if q else None for x, q in zip(a, p)])
+                       for g, a, p in zip(out.groups, out.avgs, out.present)]
+        for s in sigs:
+            for ts, freq, dur, avgs, _ in om.add(MatchInput(s.device, s.ts, s.frequency, s.duration, s.avg)):
+                want_groups.append((rtm.datetime_to_us(ts), freq, dur // datetime.timedelta(microseconds=1), avgs))
+    assert got_groups == want_groups
+    assert len(got_groups) > 10 and any(sum(a is not None for a in g[3]) >= 3 for g in got_groups)
