@@ -29,9 +29,9 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE = 8  # one complex64 read
 # HBM bytes per scan-kernel launch on the default workload, from the PMC passes in
-# profiles/r01_f_pmc_traffic_final.txt (FETCH_SIZE x 1024 x 2 [gfx950 half-count, calibrated on the
+# profiles/r01_i_pmc_traffic.txt (FETCH_SIZE x 1024 / 0.51 [gfx950 half-count, calibrated on the
 # kernel's own load stream] + WRITE_SIZE x 1024).  Only quoted for that exact workload.
-PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4423800000, "source": "profiles/r01_f_pmc_traffic_final.txt"}
+PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4454700000, "source": "profiles/r01_i_pmc_traffic.txt"}
 
 
 def parse():
