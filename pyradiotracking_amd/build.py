@@ -1,6 +1,6 @@
 """Build the native pieces in-tree (no JIT cache: the .so files travel with the repo snapshot).
 
-* ``librt_analyze.so``   gfx950 HIP kernels + C-ABI (include/rt_analyze.h, include/rt_match.h) -- the product
+* ``librt_analyze.so``   gfx950 HIP kernels + C-ABI (include/rt_analyze.h, rt_match.h, rt_format.h) -- the product
 * ``_rt_hostcheck.so``   host build of csrc/rt_core.h's scalar logic          -- unit tests only
 """
 import os
@@ -54,7 +54,8 @@ def build_library(force=False, verbose=False):
         "-o",
         LIB,
         os.path.join(CSRC, "rt_analyze.hip"),
-        os.path.join(CSRC, "rt_match.cpp"),  # host-only part of the C-ABI (include/rt_match.h)
+        os.path.join(CSRC, "rt_match.cpp"),  # host-only parts of the C-ABI (include/rt_match.h, rt_format.h)
+        os.path.join(CSRC, "rt_format.cpp"),
     ]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -1,0 +1,259 @@
+"""Record serialisers: the reference's CSV / JSON / CBOR messages for arrays of records
+(reference radiotracking/consume.py:23-55, 127-160, 165-199).
+
+The formatting runs in the native library (include/rt_format.h, csrc/rt_format.cpp) on whole
+arrays; this module is the host-side mirror of the reference interface:
+
+* :func:`jsonify` / :func:`csvify` -- the value converters (consume.py:23-32, 50-55),
+* :class:`CSVConsumer` -- same constructor and ``add(signal)`` as the reference class
+  (consume.py:165-199), plus ``add_rows`` for record arrays,
+* :func:`mqtt_messages` -- the (topic, payload) triples ``MQTTConsumer.add`` publishes for one
+  message (consume.py:127-160); there is no MQTT client here (network I/O is out of scope),
+* :func:`format_signals` / :func:`format_matched` -- the batch entries.
+
+No Python fallback: without ``librt_analyze.so`` these raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import datetime as _dt
+from typing import Any, Iterable, List, Optional, Sequence, Tuple, Type
+
+import numpy as np
+
+from . import MatchedSignal, Signal
+from . import _native
+from .match import MatchedBatch, datetime_to_us
+
+FORMAT_CSV, FORMAT_JSON, FORMAT_CBOR = 0, 1, 2
+_KINDS = {"csv": FORMAT_CSV, "json": FORMAT_JSON, "cbor": FORMAT_CBOR}
+
+FORMAT_SYMBOLS = ("rt_format_signals", "rt_format_matched", "rt_format_float_repr")
+
+# include/rt_format.h: rt_signal_row (72 B), rt_matched_row (24 B)
+SIGNAL_ROW_DTYPE = np.dtype(
+    [("device", "<i4"), ("reserved", "<i4"), ("ts_us", "<i8"), ("duration_us", "<i8"), ("frequency", "<f8"),
+     ("max_dbw", "<f8"), ("avg_dbw", "<f8"), ("std_db", "<f8"), ("noise_dbw", "<f8"), ("snr_db", "<f8")]
+)
+MATCHED_ROW_DTYPE = np.dtype([("ts_us", "<i8"), ("duration_us", "<i8"), ("frequency", "<f8")])
+
+_US = _dt.timedelta(microseconds=1)
+_bound = None
+
+
+def _lib():
+    global _bound
+    if _bound is not None:
+        return _bound
+    lib = _native.load_library()
+    vp, sz = C.c_void_p, C.c_size_t
+    lib.rt_format_signals.argtypes = [C.c_int32, vp, sz, vp, C.c_int32, vp, sz, vp, C.POINTER(sz)]
+    lib.rt_format_matched.argtypes = [C.c_int32, vp, vp, vp, sz, vp, C.c_int32, vp, sz, vp, C.POINTER(sz)]
+    lib.rt_format_float_repr.argtypes = [C.c_double, C.c_char_p]
+    for name in FORMAT_SYMBOLS:
+        getattr(lib, name)
+    _bound = lib
+    return lib
+
+
+def jsonify(o):
+    """``default=`` hook of the JSON messages: datetime -> ISO 8601, timedelta -> seconds."""
+    if isinstance(o, _dt.datetime):
+        return o.isoformat()
+    if isinstance(o, _dt.timedelta):
+        return o.total_seconds()
+    raise TypeError(f"Object of type {type(o)} is not JSON serializable")
+
+
+def csvify(o):
+    """CSV cell converter: timedelta -> seconds, everything else unchanged."""
+    return o.total_seconds() if isinstance(o, _dt.timedelta) else o
+
+
+class Messages:
+    """``n`` serialised messages back to back: ``data`` (bytes) and ``offsets`` (n + 1)."""
+
+    __slots__ = ("data", "offsets")
+
+    def __init__(self, data: bytes, offsets: np.ndarray):
+        self.data, self.offsets = data, offsets
+
+    def __len__(self) -> int:
+        return len(self.offsets) - 1
+
+    def __getitem__(self, i: int) -> bytes:
+        return self.data[int(self.offsets[i]): int(self.offsets[i + 1])]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def _names(device_names: Sequence[str]):
+    enc = [str(d).encode("utf-8") for d in device_names]
+    arr = (C.c_char_p * max(1, len(enc)))(*enc)
+    return arr, enc
+
+
+def _call(fn, n: int, guess: int, *args) -> Messages:
+    """One formatting pass into a buffer of ``guess`` bytes; only if that was too small a second one with
+    the exact size the first pass reported."""
+    offsets = np.zeros(n + 1, dtype=np.uintp)
+    need = C.c_size_t(0)
+    cap = max(1, guess)
+    buf = C.create_string_buffer(cap)
+    rc = fn(*args, buf, cap, offsets.ctypes.data, C.byref(need))
+    if rc == _native.RT_E_CAPACITY:
+        cap = need.value
+        buf = C.create_string_buffer(max(1, cap))
+        rc = fn(*args, buf, cap, offsets.ctypes.data, C.byref(need))
+    if rc != 0:
+        raise _native.NativeError(rc, "rt_format: invalid arguments")
+    return Messages(buf.raw[: need.value], offsets)
+
+
+def format_signals(kind: str, rows: np.ndarray, device_names: Sequence[str]) -> Messages:
+    """``rows`` (SIGNAL_ROW_DTYPE) -> CSV rows (``\\r\\n`` terminated) / JSON documents / CBOR messages."""
+    rows = np.ascontiguousarray(rows, dtype=SIGNAL_ROW_DTYPE)
+    names, _keep = _names(device_names)
+    guess = len(rows) * (320 + max((len(e) for e in _keep), default=0))
+    return _call(_lib().rt_format_signals, len(rows), guess, _KINDS[kind], rows.ctypes.data, len(rows), names, len(device_names))
+
+
+def format_matched(kind: str, rows: np.ndarray, avgs: np.ndarray, present: np.ndarray,
+                   device_names: Sequence[str]) -> Messages:
+    rows = np.ascontiguousarray(rows, dtype=MATCHED_ROW_DTYPE)
+    nd = len(device_names)
+    avgs = np.ascontiguousarray(avgs, dtype=np.float64).reshape(len(rows), nd)
+    present = np.ascontiguousarray(present, dtype=np.uint8).reshape(len(rows), nd)
+    names, _keep = _names(device_names)
+    guess = len(rows) * (112 + sum(len(e) + 32 for e in _keep))
+    return _call(_lib().rt_format_matched, len(rows), guess, _KINDS[kind], rows.ctypes.data, avgs.ctypes.data,
+                 present.ctypes.data, len(rows), names, nd)
+
+
+def format_matched_batch(kind: str, batch: MatchedBatch, device_names: Sequence[str]) -> Messages:
+    """Groups as they come out of ``rt_match_add`` (match.MatchedBatch)."""
+    rows = np.zeros(len(batch), dtype=MATCHED_ROW_DTYPE)
+    for f in ("ts_us", "duration_us", "frequency"):
+        rows[f] = batch.groups[f]
+    return format_matched(kind, rows, batch.avgs, batch.present, device_names)
+
+
+# ---------------------------------------------------------------------------
+# records / objects -> rows
+# ---------------------------------------------------------------------------
+def signal_rows(signals: Iterable[Signal], device_names: List[str]) -> np.ndarray:
+    """Signal objects -> SIGNAL_ROW_DTYPE; unknown device names are appended to ``device_names``."""
+    signals = list(signals)
+    index = {d: i for i, d in enumerate(device_names)}
+    rows = np.zeros(len(signals), dtype=SIGNAL_ROW_DTYPE)
+    for i, s in enumerate(signals):
+        if s.device not in index:
+            index[s.device] = len(device_names)
+            device_names.append(s.device)
+        rows[i] = (index[s.device], 0, datetime_to_us(s.ts), s.duration // _US, s.frequency, s.max, s.avg, s.std, s.noise, s.snr)
+    return rows
+
+
+def rows_from_analysis(rec: np.ndarray, decoder, ts_start_us: Sequence[int]) -> np.ndarray:
+    """rt_record array of one analysis call -> SIGNAL_ROW_DTYPE (device = stream index), vectorised:
+    the conversion of ``analyze._RecordDecoder`` without a Python object per signal.  Shadowed records
+    are dropped (the reference never hands them to a consumer, analyze.py:248-251)."""
+    r = rec[rec["shadowed"] == 0]
+    rows = np.zeros(len(r), dtype=SIGNAL_ROW_DTYPE)
+    if not len(r):
+        return rows
+    t_start, duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = decoder.decode(r)
+
+    def to_us(x):
+        uniq, inv = np.unique(x, return_inverse=True)
+        return np.array([_dt.timedelta(seconds=float(v)) // _US for v in uniq], dtype=np.int64)[inv]
+
+    rows["device"] = r["stream"]
+    rows["ts_us"] = np.asarray(ts_start_us, dtype=np.int64)[r["stream"]] + to_us(t_start)
+    rows["duration_us"] = to_us(duration_s)
+    rows["frequency"] = frequency
+    for name, col in (("max_dbw", max_dbw), ("avg_dbw", avg_dbw), ("std_db", std_db), ("noise_dbw", noise_dbw),
+                      ("snr_db", snr_db)):
+        rows[name] = np.asarray(col, dtype=np.float64)  # float(np.float32): exact widening, as Signal() does
+    return rows
+
+
+def _matched_arrays(msig: MatchedSignal):
+    row = np.zeros(1, dtype=MATCHED_ROW_DTYPE)
+    row[0] = (datetime_to_us(msig.ts), msig.duration // _US, msig.frequency)
+    avgs = msig._avgs
+    present = np.array([[a is not None for a in avgs]], dtype=np.uint8)
+    vals = np.array([[a if a is not None else np.nan for a in avgs]], dtype=np.float64)
+    return row, vals.reshape(1, len(avgs)), present.reshape(1, len(avgs))
+
+
+def serialise(kind: str, message) -> bytes:
+    """One ``Signal`` / ``MatchedSignal`` -> its CSV row (without line terminator), JSON document or CBOR message."""
+    if isinstance(message, Signal):
+        names = [message.device]
+        out = format_signals(kind, signal_rows([message], names), names)[0]
+    elif isinstance(message, MatchedSignal):
+        row, vals, present = _matched_arrays(message)
+        out = format_matched(kind, row, vals, present, message.devices[: vals.shape[1]])[0]
+    else:
+        raise TypeError(f"cannot serialise {type(message)}")
+    return out[:-2] if kind == "csv" else out
+
+
+def mqtt_messages(message, prefix: str = "/radiotracking") -> List[Tuple[str, Any]]:
+    """What ``MQTTConsumer.add`` publishes for one message (consume.py:127-160): topic
+    ``<prefix>/device/<device>`` for a Signal, ``<prefix>/matched`` for a MatchingSignal, then
+    ``/json`` (str), ``/csv`` (str, first line of the row) and ``/cbor`` (bytes)."""
+    if isinstance(message, Signal):
+        path = f"{prefix}/device/{message.device}"
+    elif isinstance(message, MatchedSignal):
+        path = f"{prefix}/matched"
+    else:
+        return []
+    csv_row = serialise("csv", message).decode("utf-8")
+    return [
+        (path + "/json", serialise("json", message).decode("ascii")),
+        (path + "/csv", csv_row.splitlines()[0] if csv_row else csv_row),
+        (path + "/cbor", serialise("cbor", message)),
+    ]
+
+
+class CSVConsumer:
+    """Drop-in for ``radiotracking.consume.CSVConsumer`` (consume.py:165-199): writes the header once,
+    then one ``;``-separated row per message of type ``cls``; other messages are ignored."""
+
+    def __init__(self, out, cls: Type, header: Optional[List[str]] = None):
+        self.out = out
+        self.cls = cls
+        if header:
+            self.out.write(self._header_row(header))
+        self.out.flush()
+
+    @staticmethod
+    def _header_row(header: Sequence[Any]) -> str:
+        cells = []
+        for h in header:
+            h = "" if h is None else str(h)
+            if any(c in h for c in ';"\r\n'):
+                h = '"' + h.replace('"', '""') + '"'
+            cells.append(h)
+        return ";".join(cells) + "\r\n"
+
+    def add(self, signal) -> None:
+        if isinstance(signal, self.cls):
+            self.out.write(serialise("csv", signal).decode("utf-8") + "\r\n")
+            self.out.flush()
+
+    def add_rows(self, rows: np.ndarray, device_names: Sequence[str]) -> int:
+        """Batch entry for Signal rows (``rows_from_analysis`` / ``signal_rows``)."""
+        msgs = format_signals("csv", rows, device_names)
+        self.out.write(msgs.data.decode("utf-8"))
+        self.out.flush()
+        return len(msgs)
+
+    def add_matched(self, batch: MatchedBatch, device_names: Sequence[str]) -> int:
+        msgs = format_matched_batch("csv", batch, device_names)
+        self.out.write(msgs.data.decode("utf-8"))
+        self.out.flush()
+        return len(msgs)

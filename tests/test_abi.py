@@ -30,12 +30,15 @@ def test_header_and_binding_agree():
 
     assert _declared_symbols() == sorted(_native.ABI_SYMBOLS)
     assert _declared_symbols("rt_match.h") == sorted(match.MATCH_SYMBOLS)
+    from pyradiotracking_amd import consume
+
+    assert _declared_symbols("rt_format.h") == sorted(consume.FORMAT_SYMBOLS)
 
 
 def test_every_declared_symbol_is_exported(lib):
     raw = C.CDLL(_native.LIB_PATH)
     headers = [h for h in os.listdir(os.path.join(REPO, "include")) if h.endswith(".h")]
-    assert sorted(headers) == ["rt_analyze.h", "rt_match.h"]
+    assert sorted(headers) == ["rt_analyze.h", "rt_format.h", "rt_match.h"]
     for header in headers:
         for name in _declared_symbols(header):
             assert hasattr(raw, name), name
@@ -49,6 +52,9 @@ def test_record_layout_matches_header():
     assert C.sizeof(_native.RtCallInfo) == 48
     assert match.SIGNAL_DTYPE.itemsize == 40 and match.MATCHED_DTYPE.itemsize == 32
     assert C.sizeof(match.RtMatchConfig) == 40
+    from pyradiotracking_amd import consume
+
+    assert consume.SIGNAL_ROW_DTYPE.itemsize == 72 and consume.MATCHED_ROW_DTYPE.itemsize == 24
 
 
 def test_code_object_targets_gfx950():

@@ -1,0 +1,243 @@
+"""Record serialisers: the native CSV / JSON formatter against payloads published
+by the reference's own consumers (tests/golden/consume_cases.npz, made by make_golden_consume.py), the
+drop-in CSVConsumer against the reference's file contents, and CBOR against RFC 8949 (cbor2 is not
+installed here, so CBOR parity with the reference is unpinned; see the golden script's header).
+Host code only: runs without a GPU."""
+import csv
+import datetime
+import io
+import json
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from pyradiotracking_amd import MatchedSignal, MatchingSignal, Signal, build
+from pyradiotracking_amd import consume as rtc
+from pyradiotracking_amd.match import us_to_datetime
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "consume_cases.npz"))
+US = datetime.timedelta(microseconds=1)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build_library()
+
+
+def signal_rows():
+    names = [str(x) for x in G["devices"]]
+    rows = np.zeros(len(G["sig_ts_us"]), dtype=rtc.SIGNAL_ROW_DTYPE)
+    rows["device"] = [names.index(str(d)) for d in G["sig_device"]]
+    rows["ts_us"], rows["duration_us"], rows["frequency"] = G["sig_ts_us"], G["sig_dur_us"], G["sig_freq"]
+    for k, f in enumerate(("max_dbw", "avg_dbw", "std_db", "noise_dbw", "snr_db")):
+        rows[f] = G["sig_vals"][:, k]
+    return rows, names
+
+
+def matched_rows():
+    rows = np.zeros(len(G["m_ts_us"]), dtype=rtc.MATCHED_ROW_DTYPE)
+    rows["ts_us"], rows["duration_us"], rows["frequency"] = G["m_ts_us"], G["m_dur_us"], G["m_freq"]
+    return rows, G["m_avgs"], G["m_present"], [str(x) for x in G["m_devices"]]
+
+
+def test_signal_json_and_csv_equal_the_reference_payloads():
+    rows, names = signal_rows()
+    js = rtc.format_signals("json", rows, names)
+    cs = rtc.format_signals("csv", rows, names)
+    assert len(js) == len(cs) == len(rows) == 260
+    for i in range(len(rows)):
+        assert js[i].decode("ascii") == str(G["sig_json"][i]), i
+        row = cs[i].decode("utf-8")
+        assert row.endswith("\r\n")
+        # MQTT publishes `getvalue().splitlines()[0]` (consume.py:150)
+        assert row[:-2].splitlines()[0] == str(G["sig_csv"][i]), i
+
+
+def test_matched_json_and_csv_equal_the_reference_payloads():
+    rows, avgs, present, names = matched_rows()
+    js = rtc.format_matched("json", rows, avgs, present, names)
+    cs = rtc.format_matched("csv", rows, avgs, present, names)
+    for i in range(len(rows)):
+        assert js[i].decode("ascii") == str(G["m_json"][i]), i
+        assert cs[i].decode("utf-8")[:-2] == str(G["m_csv"][i]), i
+
+
+def _signals():
+    rows, names = signal_rows()
+    return [Signal(names[r["device"]], us_to_datetime(r["ts_us"]), r["frequency"], int(r["duration_us"]) * US, r["max_dbw"],
+                   r["avg_dbw"], r["std_db"], r["noise_dbw"], r["snr_db"]) for r in rows]
+
+
+def test_csv_consumer_writes_the_reference_file():
+    out = io.StringIO()
+    c = rtc.CSVConsumer(out, cls=Signal, header=Signal.header)
+    for s in _signals():
+        c.add(s)
+        c.add("not a signal")  # consume.py:194: other types are ignored
+    assert out.getvalue() == str(G["sig_csv_file"])
+    # batch entry: the same file from arrays
+    out2 = io.StringIO()
+    c2 = rtc.CSVConsumer(out2, cls=Signal, header=Signal.header)
+    rows, names = signal_rows()
+    assert c2.add_rows(rows, names) == len(rows)
+    assert out2.getvalue() == str(G["sig_csv_file"])
+    # what was written parses back with the csv module to the as_list values
+    back = list(csv.reader(io.StringIO(out.getvalue(), newline=""), dialect="excel", delimiter=";"))
+    assert back[0] == Signal.header and len(back) == 1 + len(rows)
+    assert back[1][0] == names[rows["device"][0]] and float(back[1][2]) == rows["frequency"][0]
+
+
+def _matched_objects():
+    rows, avgs, present, names = matched_rows()
+    out = []
+    for r, a, p in zip(rows, avgs, present):
+        out.append(MatchingSignal.from_aggregate(names, us_to_datetime(r["ts_us"]), r["frequency"], int(r["duration_us"]) * US,
+                                                 [float(x) if q else None for x, q in zip(a, p)]))
+    return out, names
+
+
+def test_matched_csv_consumer_and_mqtt_messages():
+    groups, names = _matched_objects()
+    out = io.StringIO()
+    c = rtc.CSVConsumer(out, cls=MatchingSignal, header=MatchingSignal(names).header)
+    for g in groups:
+        c.add(g)
+    c.add(_signals()[0])  # a Signal is not a MatchingSignal
+    assert out.getvalue() == str(G["m_csv_file"])
+    for i, g in enumerate(groups):
+        msgs = rtc.mqtt_messages(g, prefix="station/radiotracking")
+        assert [t for t, _ in msgs] == [str(t) for t in G["m_topics"][i]]
+        assert msgs[0][1] == str(G["m_json"][i]) and msgs[1][1] == str(G["m_csv"][i])
+    sigs = _signals()
+    for i in (0, 1, 7, 203, 215, 231, 259):
+        msgs = rtc.mqtt_messages(sigs[i], prefix="station/radiotracking")
+        assert [t for t, _ in msgs] == [str(t) for t in G["sig_topics"][i]]
+        assert msgs[0][1] == str(G["sig_json"][i]) and msgs[1][1] == str(G["sig_csv"][i])
+        assert isinstance(msgs[2][1], bytes) and msgs[2][1][0] == 0x89
+    assert rtc.mqtt_messages("something else") == []
+
+
+def test_value_converters():
+    assert rtc.csvify(datetime.timedelta(milliseconds=20)) == 0.02 and rtc.csvify(5) == 5
+    assert rtc.jsonify(datetime.timedelta(seconds=2)) == 2.0
+    assert rtc.jsonify(datetime.datetime(2024, 1, 1, tzinfo=datetime.timezone.utc)) == "2024-01-01T00:00:00+00:00"
+    with pytest.raises(TypeError):
+        rtc.jsonify(object())
+    # json.dumps(as_dict, default=jsonify) of the message types equals the native document
+    s = _signals()[3]
+    assert json.dumps(s.as_dict, default=rtc.jsonify) == rtc.serialise("json", s).decode()
+    g = _matched_objects()[0][5]
+    assert json.dumps(g.as_dict, default=rtc.jsonify) == rtc.serialise("json", g).decode()
+
+
+# ---------------------------------------------------------------------------
+# CBOR: decoded with a minimal RFC 8949 reader written for this test
+# ---------------------------------------------------------------------------
+def cbor_item(b, i=0):
+    ib = b[i]
+    major, info = ib >> 5, ib & 31
+    i += 1
+    if major == 7:
+        if info == 22:
+            return None, i
+        if info == 25:
+            return struct.unpack(">e", b[i:i + 2])[0], i + 2
+        if info == 27:
+            return struct.unpack(">d", b[i:i + 8])[0], i + 8
+        raise AssertionError(f"unexpected simple/float {info}")
+    if info < 24:
+        val = info
+    else:
+        n = {24: 1, 25: 2, 26: 4, 27: 8}[info]
+        val = int.from_bytes(b[i:i + n], "big")
+        i += n
+    if major == 0:
+        return val, i
+    if major == 1:
+        return -1 - val, i
+    if major == 3:
+        return b[i:i + val].decode("utf-8"), i + val
+    if major == 4:
+        items = []
+        for _ in range(val):
+            x, i = cbor_item(b, i)
+            items.append(x)
+        return items, i
+    if major == 6:
+        x, i = cbor_item(b, i)
+        return ("tag", val, x), i
+    raise AssertionError(f"unexpected major type {major}")
+
+
+def same_float(a, b):
+    return (math.isnan(a) and math.isnan(b)) or (a == b and math.copysign(1, a) == math.copysign(1, b))
+
+
+def test_cbor_messages_decode_to_as_list():
+    rows, names = signal_rows()
+    msgs = rtc.format_signals("cbor", rows, names)
+    for i, r in enumerate(rows):
+        item, end = cbor_item(msgs[i])
+        assert end == len(msgs[i]) and len(item) == 9
+        assert item[0] == names[r["device"]]
+        tag, num, ts = item[1]
+        assert (tag, num) == ("tag", 1)
+        sec, us = divmod(int(r["ts_us"]), 10**6)
+        if us == 0:
+            assert isinstance(ts, int) and ts == sec  # cbor2: an int when microsecond == 0
+        else:
+            assert isinstance(ts, float) and ts == sec + us / 1000000
+        assert same_float(item[2], r["frequency"])
+        assert item[3][:2] == ("tag", 1337) and item[3][2] == int(r["duration_us"]) / 10**6
+        for k, f in enumerate(("max_dbw", "avg_dbw", "std_db", "noise_dbw", "snr_db")):
+            assert same_float(item[4 + k], r[f])
+    mrows, avgs, present, mnames = matched_rows()
+    mm = rtc.format_matched("cbor", mrows, avgs, present, mnames)
+    for i, r in enumerate(mrows):
+        item, end = cbor_item(mm[i])
+        assert end == len(mm[i]) and len(item) == 3 + len(mnames)
+        assert item[3:] == [float(a) if p else None for a, p in zip(avgs[i], present[i])]
+
+
+def test_cbor_known_answers_of_rfc8949():
+    """Appendix A of RFC 8949: 1.1 -> fb3ff199999999999a, epoch 1363896240 -> c11a514b67b0,
+    1363896240.5 -> c1fb41d452d9ec200000, NaN -> f97e00, Infinity -> f97c00, -Infinity -> f9fc00, null -> f6."""
+    rows = np.zeros(2, dtype=rtc.SIGNAL_ROW_DTYPE)
+    rows["ts_us"] = [1363896240 * 10**6, 1363896240 * 10**6 + 500000]
+    rows["duration_us"] = [1100000, 0]
+    rows["frequency"] = [1.1, 100000.0]
+    rows["max_dbw"] = [np.nan, 1.0e300]
+    rows["avg_dbw"] = [np.inf, -4.1]
+    rows["std_db"] = [-np.inf, 0.0]
+    rows["noise_dbw"] = [-0.0, 5.960464477539063e-8]
+    rows["snr_db"] = [1.5, 3.4028234663852886e38]
+    msgs = rtc.format_signals("cbor", rows, ["a"])
+    assert msgs[0].hex() == ("89" "6161" "c11a514b67b0" "fb3ff199999999999a" "d90539fb3ff199999999999a" "f97e00" "f97c00" "f9fc00"
+                             "fb8000000000000000" "fb3ff8000000000000")
+    assert msgs[1].hex() == ("89" "6161" "c1fb41d452d9ec200000" "fb40f86a0000000000" "d90539fb0000000000000000" "fb7e37e43c8800759c"
+                             "fbc010666666666666" "fb0000000000000000" "fb3e70000000000000" "fb47efffffe0000000")
+    m = rtc.format_matched("cbor", np.array([(10**6, 2 * 10**6, 1.1)], dtype=rtc.MATCHED_ROW_DTYPE), np.array([[1.5, np.nan]]),
+                           np.array([[1, 0]], dtype=np.uint8), ["x", "y"])
+    assert m[0].hex() == "85" "c101" "fb3ff199999999999a" "d90539fb4000000000000000" "fb3ff8000000000000" "f6"
+    wide = rtc.format_matched("cbor", np.zeros(1, dtype=rtc.MATCHED_ROW_DTYPE), np.zeros((1, 30)), np.zeros((1, 30), dtype=np.uint8),
+                              [str(i) for i in range(30)])
+    assert wide[0][:2].hex() == "9821"  # array of 33 items: one-byte length
+    assert wide[0][2:].hex() == "c100" "fb0000000000000000" "d90539fb0000000000000000" + "f6" * 30
+
+
+def test_errors_and_empty_batches():
+    from pyradiotracking_amd import _native
+
+    assert len(rtc.format_signals("csv", np.zeros(0, dtype=rtc.SIGNAL_ROW_DTYPE), ["0"])) == 0
+    bad = np.zeros(1, dtype=rtc.SIGNAL_ROW_DTYPE)
+    bad["device"] = 3
+    with pytest.raises(_native.NativeError):
+        rtc.format_signals("csv", bad, ["0"])
+    with pytest.raises(KeyError):
+        rtc.format_signals("xml", bad, ["0"])
+    with pytest.raises(TypeError):
+        rtc.serialise("csv", 5)

@@ -548,3 +548,38 @@ def test_analysis_records_feed_the_matcher():
                 want_groups.append((rtm.datetime_to_us(ts), freq, dur // datetime.timedelta(microseconds=1), avgs))
     assert got_groups == want_groups
     assert len(got_groups) > 10 and any(sum(a is not None for a in g[3]) >= 3 for g in got_groups)
+
+
+def test_analysis_records_to_csv_and_json_rows():
+    """rt_fetch -> rows_from_analysis -> rt_format_signals against the standard library formatting the
+    Signal objects of the same records (what the reference's consumers do, consume.py:141-151, 195)."""
+    _need_gpu()
+    import csv
+    import io
+    import json
+
+    from pyradiotracking_amd import consume as rtc
+    from pyradiotracking_amd.match import datetime_to_us
+
+    fs, nperseg, window = 2048000, 256, "hamming"
+    n_streams, blen = 5, 2400 * nperseg
+    w = oracle.window_coefficients(window, nperseg)
+    rng = np.random.default_rng(77)
+    iq = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 14, dur_ms=(9, 30))), 40 + s)
+                   for s in range(n_streams)])
+    devices = [f"sdr{d}" for d in range(n_streams)]
+    b = BatchSignalAnalyzer(devices, sdr_callback_length=blen, mode="sparse", sample_rate=fs, fft_nperseg=nperseg, fft_window=window,
+                            calibration_db=1.5)
+    b.enqueue(iq)
+    rec = b.fetch_records()
+    ts0 = [gu.TS0 + datetime.timedelta(seconds=0.25 * s, microseconds=s) for s in range(n_streams)]
+    rows = rtc.rows_from_analysis(rec, b.decoder, [datetime_to_us(t) for t in ts0])
+    sigs = b.decoder.signals(rec[rec["shadowed"] == 0], devices, ts0)
+    assert len(rows) == len(sigs) > 10
+    got_csv = rtc.format_signals("csv", rows, devices)
+    got_json = rtc.format_signals("json", rows, devices)
+    for i, s in enumerate(sigs):
+        buf = io.StringIO()
+        csv.writer(buf, dialect="excel", delimiter=";").writerow([rtc.csvify(v) for v in s.as_list])
+        assert got_csv[i].decode() == buf.getvalue()
+        assert got_json[i].decode() == json.dumps(s.as_dict, default=rtc.jsonify)
