@@ -156,6 +156,10 @@ def main():
     bytes_per_sample = 2 if u8 else BYTES_PER_SAMPLE
     achieved = samples_per_step_gpu * bytes_per_sample / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
+    # BASELINE.json configs by their geometry (per-GPU stream counts of configs 4 and 5 are the 8-GPU shares or more)
+    config_name = {(2048000, 256, "hamming", 2048000): "config2", (2400000, 1024, "hann", 2400000): "config3",
+                   (2048000, 256, "hamming", 524288): "config4 (B = 524288)",
+                   (3200000, 4096, "hamming", 3200000): "config5"}.get((fs, nperseg, args.window, blen), "custom")
     default_workload = (S, fs, blen, nperseg, args.window, args.segs_per_chunk, args.mode, args.input) == (256, 2048000, 2048000, 256, "hamming", 0, "auto", "c64")
     traffic = PMC_TRAFFIC_DEFAULT["bytes_per_launch"] if default_workload else None
     out = {
@@ -172,7 +176,7 @@ def main():
         "dtype": "f32" if not u8 else "f32 (uint8 IQ converted in the load)",
         "data": "synthetic",
         "config": {
-            "workload": f"config2: {S} streams/GPU x {fs} SPS x {args.seconds:g} s {'uint8 I/Q' if u8 else 'complex64'}, nperseg {nperseg} {args.window}, 4-8 sparse 15 ms pulses/stream",
+            "workload": f"{config_name}: {S} streams/GPU x {fs} SPS x {args.seconds:g} s {'uint8 I/Q' if u8 else 'complex64'}, nperseg {nperseg} {args.window}, {'tag trains, 8-16 tags/stream' if args.trains else '4-8 sparse 15 ms pulses/stream'}",
             "streams_per_gpu": S,
             "samples_per_stream": blen,
             "segments_per_stream": n_seg,
