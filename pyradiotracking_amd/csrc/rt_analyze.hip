@@ -219,6 +219,7 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.rec_offset = sl.h_rec_offset;
     a.rec_count = sl.h_rec_count;
     a.counters = sl.d_counters;
+    a.host_counters = sl.h_counters;
     return a;
 }
 
@@ -234,7 +235,7 @@ int ensure_dense_spec(rt_handle *h) {
     return RT_OK;
 }
 
-// the counter words -> pinned host memory (records and per-stream tables are already there)
+// calls without a detect kernel (empty spectrogram): counter words -> pinned host memory by a copy
 int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
     RT_HIP(h, hipMemcpyAsync(sl.h_counters, sl.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     return RT_OK;
@@ -250,9 +251,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
     }
     const int blocks = h->cfg.n_streams * sp.blocks_per_stream;
     const int S = h->cfg.n_streams;
-    // hot_count / raw_count are left zero by their last readers (detect_bucket<true>,
-    // finalize_records); only the four counter words need a reset
-    hipLaunchKernelGGL(reset_counters, dim3(1), dim3(1), 0, h->s_scan, sl.d_counters);
+    // hot_count / raw_count and the four counter words are left zero by their last readers
+    // (detect_bucket<true>, finalize_records / detect_dense: close_call)
     if (dense) {
         int rc = ensure_dense_spec(h);
         if (rc != RT_OK) return rc;
@@ -283,8 +283,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
         hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), h->lds_final, sd, a);
     }
     RT_HIP(h, hipGetLastError());
-    int rc = enqueue_readback(h, sl, sd);
-    if (rc != RT_OK) return rc;
+    // no readback: the call's last workgroup wrote the counter words to pinned host memory
     RT_HIP(h, hipEventRecord(sl.ev_done, sd));
     return RT_OK;
 }
@@ -293,7 +292,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
 // before its scratch is rewritten (its results, if never fetched, are dropped)
 int claim_slot(rt_handle *h, Slot **out) {
     Slot &sl = h->slot[h->n_calls % kSlots];
-    if (sl.call.seq) RT_HIP(h, hipStreamWaitEvent(h->s_scan, sl.ev_done, 0));
+    // (everything of this handle runs in order on one stream, so the slot's previous GPU work is over
+    // before anything enqueued from here on starts: no event wait needed)
     sl.call = CallCtx{};
     sl.call.seq = h->n_calls + 1;
     *out = &sl;
@@ -644,8 +644,10 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
         hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
         RT_HIP(h, hipGetLastError());
     }
-    rc = enqueue_readback(h, sl, h->s_scan);
-    if (rc != RT_OK) return rc;
+    if (n_seg == 0) {
+        rc = enqueue_readback(h, sl, h->s_scan);
+        if (rc != RT_OK) return rc;
+    }
     RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
     c.pending = true;
     h->n_calls++;

@@ -687,7 +687,8 @@ struct DetectArgs {
     int32_t rec_cap;           // per stream
     int32_t *rec_offset;       // [S]
     int32_t *rec_count;        // [S]
-    unsigned long long *counters;  // [0] records allocated, [1] hot total, [2] flags
+    unsigned long long *counters;  // [0] records allocated, [1] hot total, [2] flags, [3] workgroups done (close_call)
+    unsigned long long *host_counters;  // pinned host copy of the four words, written by the call's last workgroup
 };
 
 constexpr unsigned long long kFlagHotOverflow = 1ull;
@@ -800,6 +801,23 @@ __device__ __forceinline__ RunStats run_stats_wave(int n, Cell cell) {
     r.mean_p = (float)(ps / (double)n);
     r.std_db = (float)sqrt(pa / (double)n);
     return r;
+}
+
+// Last step of a call's last kernel (finalize_records / detect_dense), thread 0 of every workgroup:
+// the workgroup that takes the last ticket copies the counter words to pinned host memory and
+// leaves them zero for the slot's next call -- no reset launch before a call, no copy after it.
+__device__ __forceinline__ void close_call(const DetectArgs &a) {
+    __threadfence();
+    const unsigned long long ticket = atomicAdd(&a.counters[3], 1ull);
+    if (ticket + 1 == (unsigned long long)gridDim.x) {
+        __threadfence();
+        for (int i = 0; i < 3; ++i) {
+            a.host_counters[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a.host_counters[3] = ticket + 1;
+        __hip_atomic_store(&a.counters[3], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // order the stream's records by (fi, start), apply the shadow filter against
@@ -964,14 +982,19 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     const DetectParams &dp = a.dp;
 
     // row means of the bucket's bins: np.mean(row) (analyze.py:375) from the scan's partial sums
+#ifndef RT_DETECT_ABLATE
+#define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort
+#endif
     for (int r = lane; r < F / kBuckets && (!LARGE || wave == 0); r += 64) {
         const int bin = bkt + kBuckets * r;
+        if (RT_DETECT_ABLATE == 1) { avg[r] = 1e-20f; continue; }
         avg[r] = (float)row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + bin, a.chunks, F) / (float)T;
     }
     const uint2 *src = a.hot + (int64_t)sb * a.hot_cap;
     if constexpr (!LARGE) {
         // <= 1024 cells: sort in registers
-        switch (n2) {
+        switch (RT_DETECT_ABLATE == 2 ? 0 : n2) {
+            case 0: for (int i = lane; i < n; i += 64) { keys[i] = src[i].x; vals[i] = __uint_as_float(src[i].y); } break;
             case 64: sort_bucket_regs<1>(src, n, lane, keys, vals); break;
             case 128: sort_bucket_regs<2>(src, n, lane, keys, vals); break;
             case 256: sort_bucket_regs<4>(src, n, lane, keys, vals); break;
@@ -979,6 +1002,7 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
             default: sort_bucket_regs<16>(src, n, lane, keys, vals); break;
         }
         wave_sync();
+        if (RT_DETECT_ABLATE == 3) return;
     } else {
         const int tid = threadIdx.x;
         for (int i = tid; i < n2; i += 256) {
@@ -1121,15 +1145,6 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     }
 }
 
-// first kernel of a call on its slot: zero the slot's counter words (the previous call's were
-// copied to the host long ago).  One thread.
-__global__ void reset_counters(unsigned long long *counters) {
-    counters[0] = 0ull;
-    counters[1] = 0ull;
-    counters[2] = 0ull;
-    counters[3] = 0ull;
-}
-
 // One workgroup per stream: order the stream's records by (fi, start), shadow verdicts, publish.
 __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1146,6 +1161,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
         if (threadIdx.x == 0) {
             a.rec_offset[s] = 0;
             a.rec_count[s] = 0;
+            close_call(a);
         }
         return;
     }
@@ -1160,6 +1176,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     }
     __syncthreads();
     publish_records(a, l, s, n);
+    if (threadIdx.x == 0) close_call(a);  // thread 0 made this workgroup's counter updates
 }
 
 // Device form of rt::scan_dense_row (same decisions): the row is read in blocks of 16 time
@@ -1274,6 +1291,7 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     }
     __syncthreads();
     publish_records(a, l, s, nrec);
+    if (tid == 0) close_call(a);
 }
 
 }  // namespace rt
