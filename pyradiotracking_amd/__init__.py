@@ -14,6 +14,7 @@ here, so these are kept field-for-field compatible.  ``MatchedSignal`` /
 cross-SDR matcher (``pyradiotracking_amd.match``).
 """
 import datetime as _dt
+import enum as _enum
 import statistics as _statistics
 from typing import Any, Dict, List, Optional, Union
 
@@ -21,7 +22,7 @@ import numpy as np
 
 __version__ = "0.1.0"
 
-__all__ = ["dB", "from_dB", "Signal", "MatchedSignal", "MatchingSignal", "__version__"]
+__all__ = ["dB", "from_dB", "Signal", "StateMessage", "MatchedSignal", "MatchingSignal", "__version__"]
 
 
 def dB(val):
@@ -109,6 +110,35 @@ class Signal:
 
     def __hash__(self):
         return hash(tuple(self.as_list))
+
+
+class StateMessage:
+    """Liveness message of one analyzer (radiotracking/__init__.py:61-93): the analysis callback puts a
+    STARTED message on the queue with its first buffer, RUNNING ones every ``state_update_s`` seconds
+    after that and STOPPED when it gives up (analyze.py:180-190, 210-213, 226-229)."""
+
+    class State(_enum.Enum):
+        STOPPED = 0
+        RUNNING = 1
+        STARTED = 2
+
+    header: List[str] = ["Device", "Time", "State"]
+
+    def __init__(self, device: str, ts: _dt.datetime, state):
+        self.device = device
+        self.ts = ts
+        self.state = state if isinstance(state, StateMessage.State) else StateMessage.State(int(state))
+
+    @property
+    def as_list(self) -> List[Any]:
+        return [self.device, self.ts, self.state.value]
+
+    @property
+    def as_dict(self) -> Dict[str, Any]:
+        return dict(zip(self.header, self.as_list))
+
+    def __repr__(self) -> str:
+        return f"StateMessage({self.device}, {self.ts}, {self.state})"
 
 
 class MatchedSignal:

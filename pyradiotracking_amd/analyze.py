@@ -30,7 +30,7 @@ import pytz
 import scipy.fft
 import scipy.signal
 
-from . import Signal, dB, from_dB
+from . import Signal, StateMessage, dB, from_dB
 from . import _native
 
 logger = logging.getLogger(__name__)
@@ -360,6 +360,8 @@ class SignalAnalyzer:
         self.state_update_s = state_update_s
         self.signal_queue = signal_queue
         self.last_data_ts = last_data_ts
+        self.last_state: Optional[StateMessage] = None
+        self.sdr = None  # the caller's SDR handle, if it wants cancel_read_async() on a fatal clock drift
 
         self._spectrogram_last = None  # only used by extract_signals() called directly
         self._ts = None
@@ -381,12 +383,26 @@ class SignalAnalyzer:
         self._decoder = self._batch._decoder
 
     # -- the callback (analyze.py:192-268) -----------------------------------
-    def process_samples(self, buffer: np.ndarray, context=None):
-        """Analyse one buffer; detected signals go to ``signal_queue`` in the
-        reference's order.  complex128 buffers (what pyrtlsdr delivers) are
-        analysed in complex64 -- the GPU path is single precision."""
+    def update_state(self, ts: datetime.datetime, state: "StateMessage.State") -> None:
+        """Put a ``StateMessage`` on the queue unless the same state was reported less than
+        ``state_update_s`` seconds ago (analyze.py:180-190)."""
+        ts = ts.astimezone(pytz.utc)
+        last = self.last_state
+        if last and last.state == state and last.ts + datetime.timedelta(seconds=self.state_update_s) >= ts:
+            return
+        self.last_state = StateMessage(self.device, ts, state)
+        if self.signal_queue is not None:
+            self.signal_queue.put(self.last_state)
+
+    def _clock(self, n_samples: int):
+        """Book-keeping at the head of the callback (analyze.py:204-231): liveness, heartbeat value,
+        running clock, drift check.  Returns ``ts_start`` of the buffer."""
         ts_recv = datetime.datetime.now()
-        buffer_len_dt = datetime.timedelta(seconds=len(buffer) / self.sample_rate)  # :205
+        buffer_len_dt = datetime.timedelta(seconds=n_samples / self.sample_rate)  # :205
+        if self.last_data_ts is None or not self.last_data_ts.value:  # :210-213
+            self.update_state(datetime.datetime.now(), StateMessage.State.STARTED)
+        else:
+            self.update_state(ts_recv, StateMessage.State.RUNNING)
         if self.last_data_ts is not None:
             self.last_data_ts.value = datetime.datetime.timestamp(ts_recv)  # :214
         if not self._ts:  # :218-221
@@ -394,12 +410,22 @@ class SignalAnalyzer:
         else:
             self._ts += buffer_len_dt
         clock_drift = (ts_recv - self._ts).total_seconds()
-        if clock_drift > 2 * buffer_len_dt.total_seconds():  # :226
+        if clock_drift > 2 * buffer_len_dt.total_seconds():  # :226-229
             logger.warning(
                 f"SDR {self.device} total clock drift ({clock_drift:.5f} s) is larger than two blocks, "
-                "signal detection is degraded."
+                "signal detection is degraded. Terminating..."
             )
-        ts_start = self._ts - buffer_len_dt  # :231
+            self.update_state(datetime.datetime.now(), StateMessage.State.STOPPED)
+            if self.sdr is not None:
+                self.sdr.cancel_read_async()
+        return self._ts - buffer_len_dt  # :231
+
+    def process_samples(self, buffer: np.ndarray, context=None):
+        """Analyse one buffer; state messages and detected signals go to ``signal_queue`` in the
+        reference's order.  complex128 buffers (what pyrtlsdr delivers) are analysed in complex64 --
+        the GPU path is single precision.  The SIGALRM watchdog of the reference
+        (analyze.py:208) belongs to the process that owns the SDR and is not re-armed here."""
+        ts_start = self._clock(len(buffer))
         filtered = self.analyze_buffer(buffer, ts_start)
         [self.consume_signal(s) for s in filtered]  # :251
         return None
@@ -411,15 +437,7 @@ class SignalAnalyzer:
         scan kernel's load."""
         raw = np.ascontiguousarray(raw, dtype=np.uint8)
         n = raw.size // 2
-        ts_recv = datetime.datetime.now()
-        buffer_len_dt = datetime.timedelta(seconds=n / self.sample_rate)
-        if self.last_data_ts is not None:
-            self.last_data_ts.value = datetime.datetime.timestamp(ts_recv)
-        if not self._ts:
-            self._ts = ts_recv
-        else:
-            self._ts += buffer_len_dt
-        ts_start = self._ts - buffer_len_dt
+        ts_start = self._clock(n)
         if n > self._batch.sdr_callback_length:
             raise ValueError("buffer longer than sdr_callback_length")
         self._batch.enqueue_bytes(raw.reshape(1, -1))

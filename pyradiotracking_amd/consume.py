@@ -21,7 +21,12 @@ from typing import Any, Iterable, List, Optional, Sequence, Tuple, Type
 
 import numpy as np
 
-from . import MatchedSignal, Signal
+import csv as _csv
+import io as _io
+import json as _json
+import struct as _struct
+
+from . import MatchedSignal, Signal, StateMessage
 from . import _native
 from .match import MatchedBatch, datetime_to_us
 
@@ -196,9 +201,40 @@ def serialise(kind: str, message) -> bytes:
     elif isinstance(message, MatchedSignal):
         row, vals, present = _matched_arrays(message)
         out = format_matched(kind, row, vals, present, message.devices[: vals.shape[1]])[0]
+    elif isinstance(message, StateMessage):
+        return _serialise_state(kind, message)
     else:
         raise TypeError(f"cannot serialise {type(message)}")
     return out[:-2] if kind == "csv" else out
+
+
+def _serialise_state(kind: str, msg: StateMessage) -> bytes:
+    """A StateMessage (one per analyzer and minute; as_list = [device, ts, state.value],
+    __init__.py:84-90) through the standard library, CBOR by hand (array, text, tag 1, uint)."""
+    if kind == "csv":
+        buf = _io.StringIO()
+        _csv.writer(buf, dialect="excel", delimiter=";").writerow([csvify(v) for v in msg.as_list])
+        return buf.getvalue()[:-2].encode("utf-8")
+    if kind == "json":
+        return _json.dumps(msg.as_dict, default=jsonify).encode("ascii")
+    if kind != "cbor":
+        raise KeyError(kind)
+
+    def head(major: int, v: int) -> bytes:
+        if v < 24:
+            return bytes([major << 5 | v])
+        for info, fmt in ((24, ">B"), (25, ">H"), (26, ">I"), (27, ">Q")):
+            if v < 1 << (8 * _struct.calcsize(fmt)):
+                return bytes([major << 5 | info]) + _struct.pack(fmt, v)
+        raise OverflowError(v)
+
+    name = str(msg.device).encode("utf-8")
+    sec, us = divmod(datetime_to_us(msg.ts), 10**6)
+    if us:
+        stamp = _struct.pack(">Bd", 0xFB, sec + us / 1000000)
+    else:
+        stamp = head(0, sec) if sec >= 0 else head(1, -1 - sec)
+    return head(4, 3) + head(3, len(name)) + name + head(6, 1) + stamp + head(0, msg.state.value)
 
 
 def mqtt_messages(message, prefix: str = "/radiotracking") -> List[Tuple[str, Any]]:
@@ -209,6 +245,8 @@ def mqtt_messages(message, prefix: str = "/radiotracking") -> List[Tuple[str, An
         path = f"{prefix}/device/{message.device}"
     elif isinstance(message, MatchedSignal):
         path = f"{prefix}/matched"
+    elif isinstance(message, StateMessage):
+        path = f"{prefix}/state"
     else:
         return []
     csv_row = serialise("csv", message).decode("utf-8")

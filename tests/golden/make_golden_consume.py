@@ -124,7 +124,26 @@ def main():
         m_jsons.append(published[0][1])
         m_csvs.append(published[1][1])
 
+    # state messages (analyze.py:180-190) through the same consumers
+    state_file = io.StringIO()
+    state_csv = ref_consume.CSVConsumer(state_file, cls=radiotracking.StateMessage, header=radiotracking.StateMessage.header)
+    st_in, st_topics, st_json, st_csv, st_repr = [], [], [], [], []
+    for i, (dev, state) in enumerate([("0", 2), ("0", 1), ("1", 0), ("rtl;sdr", 1), ("0", 1)]):
+        ts_us = 1704067200_000000 + i * 60_000000 + (0 if i == 1 else 123456 * i)
+        m = radiotracking.StateMessage(dev, EPOCH + ts_us * US, state)
+        published.clear()
+        mq.add(m)
+        state_csv.add(m)
+        st_in.append((dev, ts_us, state))
+        st_topics.append([t for t, _ in published])
+        st_json.append(published[0][1])
+        st_csv.append(published[1][1])
+        st_repr.append(repr(m))
+
     out = dict(
+        st_device=np.array([x[0] for x in st_in]), st_ts_us=np.array([x[1] for x in st_in], dtype=np.int64),
+        st_state=np.array([x[2] for x in st_in], dtype=np.int32), st_topics=np.array(st_topics), st_json=np.array(st_json),
+        st_csv=np.array(st_csv), st_repr=np.array(st_repr), st_csv_file=np.array(state_file.getvalue()),
         devices=np.array(devices), sig_device=np.array([s[0] for s in sigs]),
         sig_ts_us=np.array([s[1] for s in sigs], dtype=np.int64), sig_dur_us=np.array([s[2] for s in sigs], dtype=np.int64),
         sig_freq=np.array([s[3] for s in sigs], dtype=np.float64), sig_vals=np.array([s[4:] for s in sigs], dtype=np.float64),

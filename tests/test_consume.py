@@ -241,3 +241,26 @@ def test_errors_and_empty_batches():
         rtc.format_signals("xml", bad, ["0"])
     with pytest.raises(TypeError):
         rtc.serialise("csv", 5)
+
+
+def test_state_messages_format_like_the_reference():
+    from pyradiotracking_amd import StateMessage
+
+    out = io.StringIO()
+    c = rtc.CSVConsumer(out, cls=StateMessage, header=StateMessage.header)
+    for i in range(len(G["st_ts_us"])):
+        m = StateMessage(str(G["st_device"][i]), us_to_datetime(G["st_ts_us"][i]), int(G["st_state"][i]))
+        assert repr(m) == str(G["st_repr"][i])
+        assert m.as_dict == {"Device": m.device, "Time": m.ts, "State": m.state.value}
+        msgs = rtc.mqtt_messages(m, prefix="station/radiotracking")
+        assert [t for t, _ in msgs] == [str(t) for t in G["st_topics"][i]]
+        assert msgs[0][1] == str(G["st_json"][i]) and msgs[1][1] == str(G["st_csv"][i])
+        item, end = cbor_item(msgs[2][1])
+        assert end == len(msgs[2][1]) and item[0] == m.device and item[2] == m.state.value
+        sec, us = divmod(int(G["st_ts_us"][i]), 10**6)
+        assert item[1] == ("tag", 1, sec if us == 0 else sec + us / 1000000)
+        c.add(m)
+    c.add(_signals()[0])
+    assert out.getvalue() == str(G["st_csv_file"])
+    assert StateMessage("x", us_to_datetime(0), StateMessage.State.RUNNING).state is StateMessage.State(1)
+    assert StateMessage("x", us_to_datetime(0), "2").state is StateMessage.State.STARTED

@@ -126,8 +126,13 @@ def test_golden_iq_case(name, mode):
 
 
 def test_process_samples_queue_contract():
-    """process_samples puts the filtered Signals on the queue, in order."""
+    """process_samples puts a StateMessage (STARTED, later RUNNING at most every state_update_s) and the
+    filtered Signals on the queue, in the reference's order (analyze.py:204-251)."""
     _need_gpu()
+    import multiprocessing
+
+    from pyradiotracking_amd import Signal, StateMessage
+
     meta, kwargs, buffers, ts_starts, expected = gu.iq_case("cfg1_tone")
 
     class Q:
@@ -138,17 +143,42 @@ def test_process_samples_queue_contract():
             self.items.append(x)
 
     q = Q()
-    an = SignalAnalyzer("0", signal_queue=q, **kwargs)
+    beat = multiprocessing.Value("d", 0.0)
+    an = SignalAnalyzer("0", signal_queue=q, last_data_ts=beat, state_update_s=60, **kwargs)
     assert an.process_samples(buffers[0], None) is None
-    assert len(q.items) == 1 and q.items[0].frequency == 150200390.625
-    assert abs(q.items[0].max - (-72.80327606201172)) < POWER_TOL_DB
-    assert q.items[0].duration == datetime.timedelta(microseconds=21333)
-    assert str(q.items[0]).startswith("Signal<SDR 0, 150.200 MHz, 21.33 ms, -72.8 dBW>")
+    assert [type(x) for x in q.items] == [StateMessage, Signal]
+    assert q.items[0].state is StateMessage.State.STARTED and q.items[0].device == "0" and beat.value > 0
+    sig = q.items[1]
+    assert sig.frequency == 150200390.625
+    assert abs(sig.max - (-72.80327606201172)) < POWER_TOL_DB
+    assert sig.duration == datetime.timedelta(microseconds=21333)
+    assert str(sig).startswith("Signal<SDR 0, 150.200 MHz, 21.33 ms, -72.8 dBW>")
+    # second buffer: state RUNNING is new -> reported once, then suppressed for state_update_s
+    q.items.clear()
+    an._ts = None  # test buffers arrive faster than real time: keep the drift check out of this
+    an.process_samples(buffers[0], None)
+    an._ts = None
+    an.process_samples(buffers[0], None)
+    states = [x for x in q.items if isinstance(x, StateMessage)]
+    assert [s.state for s in states] == [StateMessage.State.RUNNING]
     # complex128 input (what pyrtlsdr delivers) is accepted and analysed in complex64
     q.items.clear()
     an.reset()
+    an._ts = None
     an.process_samples(buffers[0].astype(np.complex128), None)
-    assert len(q.items) == 1
+    assert len([x for x in q.items if isinstance(x, Signal)]) == 1
+    # a clock that lags more than two buffers behind: STOPPED is reported and the SDR read cancelled
+    class Sdr:
+        cancelled = 0
+
+        def cancel_read_async(self):
+            self.cancelled += 1
+
+    an.sdr = Sdr()
+    an._ts = datetime.datetime.now() - datetime.timedelta(seconds=10)
+    q.items.clear()
+    an.process_samples(buffers[0], None)
+    assert an.sdr.cancelled == 1 and any(isinstance(x, StateMessage) and x.state is StateMessage.State.STOPPED for x in q.items)
 
 
 # ---------------------------------------------------------------------------
