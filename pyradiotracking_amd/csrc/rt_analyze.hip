@@ -458,7 +458,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     RT_CREATE_HIP(hipMalloc(&h->d_window, sizeof(float) * N));
     RT_CREATE_HIP(hipMalloc(&h->d_tw1, sizeof(cf) * tw1.size()));
     RT_CREATE_HIP(hipMalloc(&h->d_tw2, sizeof(cf) * tw2.size()));
-    RT_CREATE_HIP(hipMemcpy(h->d_window, cfg->window, sizeof(float) * N, hipMemcpyHostToDevice));
+    {
+        // |X|^2 * scale is computed as |X'|^2 with X' the transform of the segment under sqrt(scale) * window:
+        // one multiplication per output cell less in the scan kernel (each coefficient rounded once, from double)
+        std::vector<float> ws((size_t)N);
+        const double root = std::sqrt((double)cfg->scale);
+        for (int i = 0; i < N; ++i) ws[(size_t)i] = (float)((double)cfg->window[i] * root);
+        RT_CREATE_HIP(hipMemcpy(h->d_window, ws.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+    }
     RT_CREATE_HIP(hipMemcpy(h->d_tw1, tw1.data(), sizeof(cf) * tw1.size(), hipMemcpyHostToDevice));
     RT_CREATE_HIP(hipMemcpy(h->d_tw2, tw2.data(), sizeof(cf) * tw2.size(), hipMemcpyHostToDevice));
 

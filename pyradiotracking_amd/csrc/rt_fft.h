@@ -90,6 +90,43 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
     v[4] = y4; v[5] = y5; v[6] = y6; v[7] = y7;
 }
 
+// 4-point DFT whose inputs a1 and/or a3 still lack a factor 1/sqrt2 (the W8 rotations of the 16-point
+// transform): the factor rides on the fused multiply-adds of the last butterfly level instead of
+// costing multiplications of its own.
+//   S1 = a1 scaled late, S3 = a3 scaled late; unscaled inputs are passed as they are.
+template <bool S1, bool S3>
+__device__ __forceinline__ void dft4_late_scale(cf &a0, cf &a1, cf &a2, cf &a3) {
+    constexpr float c = RT_SQRT1_2;
+    if constexpr (S1 && S3) {
+        // both odd inputs carry the factor: (a1 +- a3) unscaled, factor applied in the final level
+        const cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
+        const cf s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+        a0 = cf{__builtin_fmaf(s13.x, c, s02.x), __builtin_fmaf(s13.y, c, s02.y)};
+        a2 = cf{__builtin_fmaf(s13.x, -c, s02.x), __builtin_fmaf(s13.y, -c, s02.y)};
+        a1 = cf{__builtin_fmaf(d13.x, c, d02.x), __builtin_fmaf(d13.y, c, d02.y)};
+        a3 = cf{__builtin_fmaf(d13.x, -c, d02.x), __builtin_fmaf(d13.y, -c, d02.y)};
+    } else {
+        static_assert(!S1 && !S3, "single late factors are applied on the even input (dft4_late_even)");
+        dft4(a0, a1, a2, a3);
+    }
+}
+
+// 4-point DFT whose input a2 still lacks the factor 1/sqrt2: s02 / d02 become fused multiply-adds.
+__device__ __forceinline__ void dft4_late_even(cf &a0, cf &a1, cf &a2, cf &a3) {
+    constexpr float c = RT_SQRT1_2;
+    const cf s02{__builtin_fmaf(a2.x, c, a0.x), __builtin_fmaf(a2.y, c, a0.y)};
+    const cf d02{__builtin_fmaf(a2.x, -c, a0.x), __builtin_fmaf(a2.y, -c, a0.y)};
+    const cf s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    a0 = cadd(s02, s13);
+    a2 = csub(s02, s13);
+    a1 = cadd(d02, d13);
+    a3 = csub(d02, d13);
+}
+
+// rotations by W8^1 and W8^3 without their factor 1/sqrt2 (applied late, see above)
+__device__ __forceinline__ cf rot_w8_1(cf a) { return cadd(a, mul_mi(a)); }   // (x + y, y - x)
+__device__ __forceinline__ cf rot_w8_3(cf a) { return csub(mul_mi(a), a); }   // (y - x, -(x + y))
+
 // 16-point DFT, natural order in and out:  n = n0 + 4*n1, k = ka + 4*kb.
 __device__ __forceinline__ void dft16(cf (&v)[16]) {
     // 4-point DFTs over n1 for each n0: Z[n0][ka] lands in v[n0 + 4*ka]
@@ -97,25 +134,23 @@ __device__ __forceinline__ void dft16(cf (&v)[16]) {
     dft4(v[1], v[5], v[9], v[13]);
     dft4(v[2], v[6], v[10], v[14]);
     dft4(v[3], v[7], v[11], v[15]);
-    // twiddles W16^(n0*ka)
+    // twiddles W16^(n0*ka); the four that are W8 rotations keep their 1/sqrt2 for the next level
     const cf w1{RT_COS_PI_8, -RT_SIN_PI_8};   // W16^1
     const cf w3{RT_SIN_PI_8, -RT_COS_PI_8};   // W16^3
     v[5] = cmul(v[5], w1);                    // n0=1 ka=1 : W^1
-    v[9] = mul_w8_1(v[9]);                    // n0=1 ka=2 : W^2 = W8^1
+    v[9] = rot_w8_1(v[9]);                    // n0=1 ka=2 : W^2 = W8^1   (x 1/sqrt2 late)
     v[13] = cmul(v[13], w3);                  // n0=1 ka=3 : W^3
-    v[6] = mul_w8_1(v[6]);                    // n0=2 ka=1 : W^2
+    v[6] = rot_w8_1(v[6]);                    // n0=2 ka=1 : W^2          (x 1/sqrt2 late)
     v[10] = mul_mi(v[10]);                    // n0=2 ka=2 : W^4 = -i
-    v[14] = mul_w8_3(v[14]);                  // n0=2 ka=3 : W^6 = W8^3
+    v[14] = rot_w8_3(v[14]);                  // n0=2 ka=3 : W^6 = W8^3   (x 1/sqrt2 late)
     v[7] = cmul(v[7], w3);                    // n0=3 ka=1 : W^3
-    v[11] = mul_w8_3(v[11]);                  // n0=3 ka=2 : W^6
-    {                                         // n0=3 ka=3 : W^9 = -W^1
-        v[15] = cneg(cmul(v[15], w1));
-    }
+    v[11] = rot_w8_3(v[11]);                  // n0=3 ka=2 : W^6          (x 1/sqrt2 late)
+    v[15] = cneg(cmul(v[15], w1));            // n0=3 ka=3 : W^9 = -W^1
     // 4-point DFTs over n0 for each ka: Y[ka + 4*kb] lands in v[4*ka + kb]
     dft4(v[0], v[1], v[2], v[3]);
-    dft4(v[4], v[5], v[6], v[7]);
-    dft4(v[8], v[9], v[10], v[11]);
-    dft4(v[12], v[13], v[14], v[15]);
+    dft4_late_even(v[4], v[5], v[6], v[7]);              // v[6] lacks 1/sqrt2
+    dft4_late_scale<true, true>(v[8], v[9], v[10], v[11]);  // v[9] and v[11] lack 1/sqrt2
+    dft4_late_even(v[12], v[13], v[14], v[15]);          // v[14] lacks 1/sqrt2
     // transpose to natural order: out[ka + 4*kb] = v[4*ka + kb]
     cf t;
     t = v[1];  v[1] = v[4];   v[4] = t;

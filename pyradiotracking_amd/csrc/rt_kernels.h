@@ -49,7 +49,7 @@ struct StftParams {
     int32_t chunks;          // ceil(T / L) chunks per stream
     int32_t blocks_per_stream;
     int32_t tail_cols;       // K
-    const float *window;     // [N]
+    const float *window;     // [N] window coefficients times sqrt(scale)
     const cf *tw1;           // [LG][16]   W_N^(a*k1)
     const cf *tw2;           // [R3][16]   W_LG^(b*q1)
     float scale;
@@ -503,10 +503,10 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 >= 8) && RT_SCAN_MIN_WAVES 
         wave_sync();
         RT_ABLATE_STOP(6)  // + pass 3
 
-        // |X|^2 * scale  (scipy _spectral_py.py:2126-2128)
+        // |X|^2 * scale  (scipy _spectral_py.py:2126-2128); sqrt(scale) is folded into the window table
         float P[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[r] = __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y) * p.scale;
+        for (int r = 0; r < 16; ++r) P[r] = __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y);
 
         if (active && !halo) {
 #pragma unroll
