@@ -31,14 +31,14 @@ BYTES_PER_SAMPLE = 8  # one complex64 read
 # HBM bytes per scan-kernel launch on the default workload, from the PMC passes in
 # profiles/r01_i_pmc_traffic.txt (FETCH_SIZE x 1024 / 0.51 [gfx950 half-count, calibrated on the
 # kernel's own load stream] + WRITE_SIZE x 1024).  Only quoted for that exact workload.
-PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4454700000, "source": "profiles/r01_i_pmc_traffic.txt"}
+PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4456600000, "source": "profiles/r01_i_pmc_traffic.txt"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--sample-rate", type=int, default=2048000)
     ap.add_argument("--seconds", type=float, default=1.0, help="buffer length per stream")
