@@ -53,6 +53,9 @@ def parse():
                     help="signal_threshold_dbw (default: the reference's -90, or -80 with --input u8)")
     ap.add_argument("--trains", action="store_true",
                     help="BASELINE config 5 style input: 8-16 tags per stream, pulse trains 10-38 ms, period 0.1-1 s")
+    ap.add_argument("--settle", type=int, default=30,
+                    help="untimed steps run once during set-up, before the W warm-up steps: the GPU's clocks need ~10 "
+                         "launches after idle to settle (0.85 -> 0.77 ms per scan launch), whatever W the caller picks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--parity-streams", type=int, default=4)
@@ -134,6 +137,7 @@ def main():
             acc[2] += info.fell_back
         return rec, info, acc
 
+    run(args.settle)  # set-up: clocks to steady state (not part of the W warm-up steps, never timed)
     rec, info, _ = run(args.warmup)
     torch.cuda.synchronize()
     barrier()

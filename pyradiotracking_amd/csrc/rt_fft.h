@@ -8,29 +8,6 @@
 
 namespace rt {
 
-#ifndef RT_PK
-#define RT_PK 0  // complex values as <2 x float>: butterflies become v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
-#endif
-
-#if RT_PK
-// A complex value is one aligned VGPR pair and complex add/sub/scale/twiddle are single packed
-// instructions (two float32 lanes each, IEEE-identical per component to the scalar forms).
-typedef float cf __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
-// (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x): one packed multiply and one packed fma; the same
-// roundings as fmaf(a.x, b.x, -(a.y*b.y)), fmaf(a.x, b.y, a.y*b.x).
-__device__ __forceinline__ cf cmul(cf a, cf b) {
-    cf t = a.yy * b.yx;
-    t.x = -t.x;
-    return __builtin_elementwise_fma(a.xx, b, t);
-}
-// multiply by -i  (forward-transform quarter turn): (x + iy)(-i) = y - ix
-__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
-__device__ __forceinline__ cf cscale(cf a, float s) { return a * s; }
-__device__ __forceinline__ cf cneg(cf a) { return -a; }
-#else
 struct cf {
     float x, y;
 };
@@ -46,7 +23,6 @@ __device__ __forceinline__ cf cmul(cf a, cf b) {
 __device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
 __device__ __forceinline__ cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
 __device__ __forceinline__ cf cneg(cf a) { return cf{-a.x, -a.y}; }
-#endif
 
 // 4-point DFT in place, natural order out.
 __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3) {

@@ -184,20 +184,10 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
     }
 }
 
-#ifndef RT_SCAN_MIN_WAVES
-#define RT_SCAN_MIN_WAVES 1
-#endif
 // diagnostic builds only (tools/ablate.sh): stop the scan step after stage n, folding the live
 // values into the row sums so nothing upstream is dead code.  0 = full kernel (the product).
 #ifndef RT_ABLATE
 #define RT_ABLATE 0
-#endif
-#ifndef RT_STAGE_IN_XCH
-#define RT_STAGE_IN_XCH 0  // A/B switch: stage candidate cells in the wave's own exchange rows (40 KiB LDS, flush every
-                           // emitting step).  Measured on one box: 0.867 ms (off) vs 0.910 ms (on) vs 0.960 ms (on + 4 waves/SIMD)
-#endif
-#ifndef RT_W_REGS
-#define RT_W_REGS 0  // A/B switch: window coefficients in VGPRs (N = 256) instead of LDS -- measured: no difference
 #endif
 
 
@@ -212,25 +202,13 @@ struct iq_u8 {
     uint16_t iq;  // low byte I, high byte Q
 };
 
-#ifndef RT_NT_LOADS
-#define RT_NT_LOADS 1  // A/B switch: IQ loads carry the non-temporal hint (read once; keep L1/L2 for the tables)
-#endif
+// IQ is read exactly once: the loads carry the non-temporal hint (load-only instantiation +4..9 %)
 __device__ __forceinline__ cf load_iq(const cf *p) {
-#if RT_NT_LOADS
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
     return cf{v.x, v.y};
-#else
-    return *p;
-#endif
 }
-__device__ __forceinline__ iq_u8 load_iq(const iq_u8 *p) {
-#if RT_NT_LOADS
-    return iq_u8{__builtin_nontemporal_load(&p->iq)};
-#else
-    return *p;
-#endif
-}
+__device__ __forceinline__ iq_u8 load_iq(const iq_u8 *p) { return iq_u8{__builtin_nontemporal_load(&p->iq)}; }
 
 // pyrtlsdr's packed_bytes_to_iq is (byte / 127.5) - 1 per component (in float64); here one
 // float32 fma per component, at most one float32 ulp away, then float32 like complex64 input
@@ -241,7 +219,8 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
 }
 
 template <int R3, int MODE, bool U8 = false>
-__global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 >= 8) && RT_SCAN_MIN_WAVES < 3) ? 3 : RT_SCAN_MIN_WAVES) void stft_scan(const StftParams p) {
+__global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/SIMD where the allocation would drift above 168 VGPRs
+ void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
     constexpr int LG = 16 * R3;
@@ -254,19 +233,11 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 >= 8) && RT_SCAN_MIN_WAVES 
     const int tid = threadIdx.x;
     const int g = tid / LG;
     const int lt = tid % LG;
-#ifndef RT_BLOCK_ORDER
-#define RT_BLOCK_ORDER 1  // A/B switch: 1 = latest chunks first (all streams), 0 = stream-major ascending
-#endif
-#if RT_BLOCK_ORDER
     // Workgroups are dispatched in index order.  The ones holding a stream's last segments also write the
     // look-back tail columns and run longer; they go first so that their extra time is hidden behind the
     // rest of the launch instead of stretching its end.
     const int s = blockIdx.x % p.n_streams;
     const int cb = p.blocks_per_stream - 1 - blockIdx.x / p.n_streams;
-#else
-    const int s = blockIdx.x / p.blocks_per_stream;
-    const int cb = blockIdx.x % p.blocks_per_stream;
-#endif
     const int chunk = cb * GPW + g;
     const bool chunk_ok = chunk < p.chunks;
     const int c0 = chunk * p.segs_per_chunk;
@@ -320,28 +291,14 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 >= 8) && RT_SCAN_MIN_WAVES 
     }
     __syncthreads();
 
-    // N = 256: the 16 window coefficients of a lane fit the register budget of 3 waves/SIMD
-    // (saves four LDS reads and their exposed latency per step); larger N reads them per step
-    constexpr bool W_IN_REGS = (R3 == 1) && (RT_W_REGS != 0);
-    float wreg[16];
-    if constexpr (W_IN_REGS) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) wreg[m] = p.window[lt + LG * m];
-    }
-
     float acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
-    // Candidate staging.  While a lane group lives inside one wave (N <= 1024) the wave's own 64
-    // exchange rows (9 KiB = 1152 cells >= the 1024 a step can emit) are free between the last
-    // exchange read of a step and the next step's exchange write: cells are staged there and
-    // flushed within the step, which keeps the workgroup at 40 KiB of LDS (4 workgroups per CU).
-    constexpr bool STAGE_IN_XCH = (MODE == 0) && (LG <= 64) && (RT_STAGE_IN_XCH != 0);
-    __shared__ uint2 stage[(MODE == 0 && !STAGE_IN_XCH) ? (kBlock / 64) * kStageCap : 1];
-    uint2 *stg = STAGE_IN_XCH ? reinterpret_cast<uint2 *>(xch + (tid >> 6) * 64 * kRowF2)
-                              : stage + (MODE == 0 ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
-    constexpr int kStageLimit = STAGE_IN_XCH ? 64 * kRowF2 : kStageCap;
+    // candidate staging: 128 cells per wave, flushed with one returned atomic per bucket
+    __shared__ uint2 stage[MODE == 0 ? (kBlock / 64) * kStageCap : 1];
+    uint2 *stg = stage + (MODE == 0 ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
+    constexpr int kStageLimit = kStageCap;
     int stg_n = 0;                                                    // wave-uniform fill level
 
     const raw_t *stream_iq = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride;
@@ -400,9 +357,7 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 >= 8) && RT_SCAN_MIN_WAVES 
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             float4 w4;
-            if constexpr (W_IN_REGS) {
-                w4 = make_float4(wreg[4 * mm], wreg[4 * mm + 1], wreg[4 * mm + 2], wreg[4 * mm + 3]);
-            } else if constexpr (W_IN_LDS) {
+            if constexpr (W_IN_LDS) {
                 w4 = w_lds[mm * LG + lt];
             } else {
                 w4 = make_float4(p.window[lt + LG * (4 * mm)], p.window[lt + LG * (4 * mm + 1)],
@@ -601,10 +556,6 @@ __global__ __launch_bounds__(kBlock, ((R3 == 1 || R3 >= 8) && RT_SCAN_MIN_WAVES 
                             stg[stg_n + off] = make_uint2(key, __float_as_uint(P[r]));
                         }
                         stg_n += __builtin_popcountll(m);
-                    }
-                    if constexpr (STAGE_IN_XCH) {
-                        flush_stage(p, s, stg, stg_n);  // the rows are needed again by the next step
-                        stg_n = 0;
                     }
                 } else {
                     // more than a staging area in one step (dense input): straight to memory
