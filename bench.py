@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed steps run once during set-up, before the W warm-up steps: the GPU's clocks need ~10 "
                          "launches after idle to settle (0.85 -> 0.77 ms per scan launch), whatever W the caller picks")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="stream groups per GPU, each on its own handle / HIP stream (detect of one group overlaps the "
+                         "scan of the other); 1 = one launch sequence per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--parity-streams", type=int, default=4)
@@ -70,6 +73,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (1-GPU box): all ranks on GPU 0, control plane over gloo -- exercises the N > 1 code path
+    # (rendezvous, per-rank seeds, barrier, max-over-ranks, rank-0 print) where only one GPU exists
+    share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -79,7 +87,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from pyradiotracking_amd import synth
     from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
@@ -103,6 +114,7 @@ def main():
     if args.threshold_dbw is not None:
         kw["signal_threshold_dbw"] = args.threshold_dbw
     stream = torch.cuda.current_stream()
+    torch.cuda.synchronize()  # the IQ is complete before any lane's own stream reads it
     an = BatchSignalAnalyzer(
         [str(i) for i in range(S)],
         sdr_callback_length=blen,
@@ -110,7 +122,8 @@ def main():
         mode=args.mode,
         timing=True,
         segs_per_chunk=args.segs_per_chunk,
-        hip_stream=stream.cuda_stream,
+        hip_stream=stream.cuda_stream if args.lanes <= 1 else None,
+        lanes=args.lanes,
         **kw,
     )
 
@@ -131,7 +144,7 @@ def main():
             if i + 1 < n_steps:
                 enq(iq)
             rec = an.fetch_records()
-            info = an.native.call_info()
+            info = an.call_info()
             acc[0] += info.ms_stft
             acc[1] += info.ms_detect
             acc[2] += info.fell_back
@@ -149,7 +162,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -164,6 +177,7 @@ def main():
     config_name = {(2048000, 256, "hamming", 2048000): "config2", (2400000, 1024, "hann", 2400000): "config3",
                    (2048000, 256, "hamming", 524288): "config4 (B = 524288)",
                    (3200000, 4096, "hamming", 3200000): "config5"}.get((fs, nperseg, args.window, blen), "custom")
+    lanes = max(1, args.lanes)
     default_workload = (S, fs, blen, nperseg, args.window, args.segs_per_chunk, args.mode, args.input) == (256, 2048000, 2048000, 256, "hamming", 0, "auto", "c64")
     traffic = PMC_TRAFFIC_DEFAULT["bytes_per_launch"] if default_workload else None
     out = {
@@ -189,6 +203,7 @@ def main():
             "records_per_step": int(len(rec)),
             "candidate_cells_per_step": int(info.n_hot),
             "sharding": "streams sharded per GPU, no collective",
+            "lanes_per_gpu": args.lanes,
             "pulse_recipe": "tag trains (config 5)" if args.trains else "4-8 pulses of 15 ms",
         },
         "roofline": {
@@ -198,11 +213,16 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "traffic_unit": "bytes/launch (PMC, " + PMC_TRAFFIC_DEFAULT["source"] + ")" if traffic else None,
-            "kernel_ms": round(k_ms, 4),
-            "detect_kernel_ms": round(ms_detect / max(1, args.steps), 4),
-            "algorithmic_bytes_per_launch": samples_per_step_gpu * bytes_per_sample,
+            # per launch like `achieved`: the step's bytes split evenly over its scan launches (one per lane)
+            "traffic": traffic // lanes if traffic else None,
+            "traffic_unit": "bytes/launch (PMC on one 256-stream launch, " + PMC_TRAFFIC_DEFAULT["source"] + ")" if traffic else None,
+            "launches_per_step": lanes,
+            "kernel_ms": round(k_ms / lanes, 4),
+            "kernel_ms_note": "mean duration of one stft_scan launch (HIP events on its stream); with more than one lane the launches"
+                              " of different lanes run concurrently with each other's scan and detect kernels, which stretches each of them",
+            "detect_kernel_ms": round(ms_detect / max(1, args.steps) / lanes, 4),
+            "algorithmic_bytes_per_launch": samples_per_step_gpu * bytes_per_sample // lanes,
+            "whole_path_frac": round(value * 1e6 / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
         },
     }
 

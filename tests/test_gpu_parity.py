@@ -613,3 +613,41 @@ def test_analysis_records_to_csv_and_json_rows():
         csv.writer(buf, dialect="excel", delimiter=";").writerow([rtc.csvify(v) for v in s.as_list])
         assert got_csv[i].decode() == buf.getvalue()
         assert got_json[i].decode() == json.dumps(s.as_dict, default=rtc.jsonify)
+
+
+def test_lanes_give_the_same_records():
+    """Streams split over several native handles / HIP streams (lanes) produce the records of a single
+    handle, buffer after buffer (look-back state included), for complex64 and uint8 device input."""
+    _need_gpu()
+    import torch
+
+    fs, nperseg, window = 2048000, 256, "hamming"
+    n_streams, n_buf, blen = 7, 3, 600 * nperseg + 11
+    w = oracle.window_coefficients(window, nperseg)
+    rng = np.random.default_rng(5)
+    iq = np.stack([synth.make_stream(synth.StreamSpec(n_buf * blen, fs, synth.random_pulses(rng, n_buf * blen, fs, w, 12, dur_ms=(9, 30))), 70 + s)
+                   for s in range(n_streams)])
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window)
+    one = _batch_for(kw, n_streams, blen, "sparse")
+    three = _batch_for(kw, n_streams, blen, "sparse", lanes=3)
+    # (8-bit input at this gain is dense in places: "auto" may take the dense path, per lane)
+    two_u8 = _batch_for(dict(kw, signal_threshold_dbw=-80.0), n_streams, blen, "auto", lanes=2)
+    one_u8 = _batch_for(dict(kw, signal_threshold_dbw=-80.0), n_streams, blen, "auto")
+    total = 0
+    for k in range(n_buf):
+        chunk = np.ascontiguousarray(iq[:, k * blen:(k + 1) * blen])
+        dev = torch.from_numpy(chunk).cuda()
+        one.enqueue(dev)
+        three.enqueue(dev)
+        a, b = one.fetch_records(), three.fetch_records()
+        assert a.tobytes() == b.tobytes()
+        total += len(a)
+        raw = synth.quantize_u8(chunk, gain=2000.0)
+        one_u8.enqueue_bytes(raw)
+        two_u8.enqueue_bytes(torch.from_numpy(raw).cuda())
+        assert one_u8.fetch_records().tobytes() == two_u8.fetch_records().tobytes()
+    assert total > 20
+    info = three.call_info()
+    assert info.n_records == len(b) and info.n_hot == one.call_info().n_hot
+    with pytest.raises(ValueError):
+        _batch_for(kw, 4, blen, "sparse", lanes=2, hip_stream=torch.cuda.current_stream().cuda_stream)
