@@ -13,7 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import datetime as _dt
 import math
-from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
 
