@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -82,6 +82,11 @@ typedef struct rt_config {
     int32_t segs_per_chunk;     /* segments per lane-group chunk (0 = default)           */
     int32_t flags;              /* RT_FLAG_*                                             */
     void *hip_stream;           /* hipStream_t to launch on, or NULL for an own stream   */
+    int32_t lanes;              /* 0 / 1 = one launch sequence per call.  n > 1: the streams are split into n
+                                   contiguous groups, each analysed on its own HIP stream (hip_stream must be
+                                   NULL), so that the detection kernels and launch gaps of one group overlap the
+                                   scan of another; same records, rt_fetch still returns them in stream order     */
+    int32_t reserved;
 } rt_config;
 
 #define RT_FLAG_TIMING 1u /* record HIP events around the kernels of each call */
@@ -121,8 +126,9 @@ int rt_reset(rt_handle *h);
  * 268).  `iq_dev` is a DEVICE pointer to S*stream_stride complex64; n_samples =
  * len(buffer) (<= max_samples); stream_stride in samples (>= n_samples).
  * Asynchronous: enqueues on the handle's streams.  Results via rt_fetch.
- * Up to two calls may be in flight (enqueue call k+1 before fetching call k: its
- * scan overlaps call k's detection and record copy); a third rt_process without
+ * Up to two calls may be in flight (enqueue call k+1 before fetching call k, so the
+ * GPU never waits for the host; with cfg.lanes > 1 the lanes' kernels also overlap
+ * each other); a third rt_process without
  * an rt_fetch drops the oldest unfetched result.  `iq_dev` must stay valid and
  * unchanged until the call has been fetched.
  */

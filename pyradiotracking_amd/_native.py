@@ -49,6 +49,8 @@ class RtConfig(C.Structure):
         ("segs_per_chunk", C.c_int32),
         ("flags", C.c_int32),
         ("hip_stream", C.c_void_p),
+        ("lanes", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -242,6 +244,7 @@ class NativeAnalyzer:
         segs_per_chunk: int = 0,
         timing: bool = False,
         hip_stream: Optional[int] = None,
+        lanes: int = 1,
     ):
         self._lib = load_library()
         self._handle = C.c_void_p()
@@ -267,6 +270,7 @@ class NativeAnalyzer:
         cfg.segs_per_chunk = segs_per_chunk
         cfg.flags = RT_FLAG_TIMING if timing else 0
         cfg.hip_stream = hip_stream
+        cfg.lanes = int(lanes)
         rc = self._lib.rt_create(C.byref(cfg), C.byref(self._handle))
         if rc != RT_OK:
             self._handle = C.c_void_p()

@@ -143,10 +143,10 @@ class BatchSignalAnalyzer:
         lanes: int = 1,
         **kwargs,
     ):
-        """``lanes`` > 1 splits the streams into that many contiguous groups, each with its own native
-        handle and HIP stream: the detection kernels and launch gaps of one group then overlap the scan of
-        another (config 2: +14 % whole-path throughput with two lanes).  Streams are independent, so the
-        records are the same; they are merged back in stream order.  Needs ``hip_stream=None``."""
+        """``lanes`` > 1 (``rt_config.lanes``) splits the streams into that many contiguous groups, each
+        analysed on its own HIP stream: the detection kernels and launch gaps of one group then overlap the
+        scan of another (config 2: +14 % whole-path throughput with two lanes).  Streams are independent,
+        so the records are the same; ``rt_fetch`` returns them in stream order.  Needs ``hip_stream=None``."""
         self.devices = [str(d) for d in devices]
         self.calibration_db = calibration_db
         self.sample_rate = sample_rate
@@ -162,36 +162,30 @@ class BatchSignalAnalyzer:
         self.snr_threshold = from_dB(snr_threshold_db)  # :116
 
         win32, scale32 = stft_constants(fft_window, fft_nperseg, sample_rate)
-        n_all = len(self.devices)
-        lanes = max(1, min(int(lanes), n_all))
-        if lanes > 1 and hip_stream is not None:
+        if int(lanes) > 1 and hip_stream is not None:
             raise ValueError("lanes > 1 run on their own HIP streams: pass hip_stream=None")
-        bounds = [n_all * k // lanes for k in range(lanes + 1)]
-        self._lanes = []  # (native handle, first stream, one past the last stream)
-        for k in range(lanes):
-            handle = _native.NativeAnalyzer(
-                n_streams=bounds[k + 1] - bounds[k],
-                nperseg=fft_nperseg,
-                max_samples=self.sdr_callback_length,
-                sample_rate=sample_rate,
-                window_f32=win32,
-                scale=float(scale32),
-                # thresholds are compared against float32 data in float32
-                threshold=float(np.float32(self.signal_threshold)),
-                snr_threshold=float(np.float32(self.snr_threshold)),
-                calibration_db=calibration_db,
-                min_duration_s=self.signal_min_duration,
-                max_duration_s=self.signal_max_duration,
-                device=gpu,
-                mode={"auto": _native.RT_MODE_AUTO, "dense": _native.RT_MODE_DENSE, "sparse": _native.RT_MODE_SPARSE}[mode],
-                hot_capacity=hot_capacity,
-                record_capacity=record_capacity,
-                segs_per_chunk=segs_per_chunk,
-                timing=timing,
-                hip_stream=hip_stream,
-            )
-            self._lanes.append((handle, bounds[k], bounds[k + 1]))
-        self._native = self._lanes[0][0]
+        self._native = _native.NativeAnalyzer(
+            n_streams=len(self.devices),
+            nperseg=fft_nperseg,
+            max_samples=self.sdr_callback_length,
+            sample_rate=sample_rate,
+            window_f32=win32,
+            scale=float(scale32),
+            # thresholds are compared against float32 data in float32
+            threshold=float(np.float32(self.signal_threshold)),
+            snr_threshold=float(np.float32(self.snr_threshold)),
+            calibration_db=calibration_db,
+            min_duration_s=self.signal_min_duration,
+            max_duration_s=self.signal_max_duration,
+            device=gpu,
+            mode={"auto": _native.RT_MODE_AUTO, "dense": _native.RT_MODE_DENSE, "sparse": _native.RT_MODE_SPARSE}[mode],
+            hot_capacity=hot_capacity,
+            record_capacity=record_capacity,
+            segs_per_chunk=segs_per_chunk,
+            timing=timing,
+            hip_stream=hip_stream,
+            lanes=max(1, int(lanes)),
+        )
         self._decoder = _RecordDecoder(fft_nperseg, sample_rate, center_freq, calibration_db)
         self.decoder = self._decoder  # record -> field conversion, shared with pyradiotracking_amd.match
         self.gpu = gpu
@@ -210,36 +204,20 @@ class BatchSignalAnalyzer:
 
     def reset(self):
         """``_spectrogram_last = None`` for every stream."""
-        for handle, _, _ in self._lanes:
-            handle.reset()
+        self._native.reset()
 
     def close(self):
-        for handle, _, _ in self._lanes:
-            handle.close()
+        self._native.close()
 
     def call_info(self):
-        """Figures of the last fetched call, over all lanes: times and counts summed (``ms_stft`` is then the
-        sum of the lanes' scan launches), ``fell_back`` / ``mode_used`` of the worst lane."""
-        infos = [handle.call_info() for handle, _, _ in self._lanes]
-        out = infos[0]
-        for x in infos[1:]:
-            out.n_hot += x.n_hot
-            out.n_records += x.n_records
-            out.ms_stft += x.ms_stft
-            out.ms_detect += x.ms_detect
-            out.ms_total += x.ms_total
-            out.fell_back = max(out.fell_back, x.fell_back)
-            out.mode_used = min(out.mode_used, x.mode_used)  # RT_MODE_DENSE (1) < RT_MODE_SPARSE (2)
-        return out
+        """Figures of the last fetched call (with lanes: counts and times summed over the lanes' launches)."""
+        return self._native.call_info()
 
     def _process_device(self, ptr: int, n_samples: int, stride: Optional[int], bytes_per_sample: int, u8: bool):
-        stride = n_samples if stride is None else stride
-        for handle, s0, _ in self._lanes:
-            base = ptr + s0 * stride * bytes_per_sample
-            if u8:
-                handle.process_device_u8(base, n_samples, stride)
-            else:
-                handle.process_device(base, n_samples, stride)
+        if u8:
+            self._native.process_device_u8(ptr, n_samples, stride)
+        else:
+            self._native.process_device(ptr, n_samples, stride)
 
     def enqueue(self, iq, n_samples: Optional[int] = None, stream_stride: Optional[int] = None):
         """Start analysing one buffer per stream (asynchronous).
@@ -256,10 +234,7 @@ class BatchSignalAnalyzer:
             self.enqueue_bytes(iq)
             return
         if isinstance(iq, np.ndarray):
-            if iq.ndim == 1:
-                iq = iq[None, :]
-            for handle, s0, s1 in self._lanes:
-                handle.process_host(iq[s0:s1])
+            self._native.process_host(iq)
             return
         # torch tensor
         if iq.dim() == 1:
@@ -321,14 +296,7 @@ class BatchSignalAnalyzer:
 
     def fetch_records(self) -> np.ndarray:
         """Wait for the oldest enqueued call; structured array of ``rt_record`` ordered by stream."""
-        if len(self._lanes) == 1:
-            return self._native.fetch()
-        parts = []
-        for handle, s0, _ in self._lanes:
-            rec = handle.fetch()
-            rec["stream"] += s0
-            parts.append(rec)
-        return np.concatenate(parts)
+        return self._native.fetch()
 
     def process_batch(self, iq, ts_starts: Union[datetime.datetime, Sequence[datetime.datetime]], filtered: bool = True):
         """One buffer per stream -> per-stream lists of ``Signal``.

@@ -105,6 +105,11 @@ struct rt_handle {
 
     rt_call_info info{};
     bool timing = false;
+
+    // cfg.lanes > 1: this handle only owns `kids` (one complete handle per stream group, each with its own
+    // HIP stream) and forwards every call to them; kid k analyses streams [kid_base[k], kid_base[k + 1])
+    std::vector<rt_handle *> kids;
+    std::vector<int> kid_base;
 };
 
 namespace {
@@ -307,6 +312,19 @@ Slot *oldest_pending(rt_handle *h) {
     return best;
 }
 
+// forward one call to every lane; `call(kid, first stream of the kid)`; the first failure is reported
+template <class F>
+int for_each_lane(rt_handle *h, F call) {
+    for (size_t k = 0; k < h->kids.size(); ++k) {
+        const int rc = call(h->kids[k], (int64_t)h->kid_base[k]);
+        if (rc != RT_OK) {
+            h->err = h->kids[k]->err;
+            return rc;
+        }
+    }
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -330,6 +348,11 @@ const char *rt_last_error(rt_handle *h) { return h ? h->err.c_str() : g_create_e
 
 void rt_destroy(rt_handle *h) {
     if (!h) return;
+    if (!h->kids.empty()) {
+        for (rt_handle *k : h->kids) rt_destroy(k);
+        delete h;
+        return;
+    }
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_window);
@@ -371,6 +394,30 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         if (cfg->nperseg == 256 * r) R3 = r;
     if (!R3) return fail_create(RT_E_UNSUPPORTED, "nperseg must be one of 256, 512, 1024, 2048, 4096");
     if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_SPARSE) return fail_create(RT_E_INVALID, "bad mode");
+    if (cfg->lanes > 1 && cfg->n_streams > 1) {
+        // stream groups on their own handles and HIP streams: the detection kernels, launch gaps and last
+        // workgroup round of one group overlap the scan of another
+        if (cfg->hip_stream) return fail_create(RT_E_INVALID, "lanes > 1 run on their own HIP streams: hip_stream must be NULL");
+        const int lanes = cfg->lanes < cfg->n_streams ? cfg->lanes : cfg->n_streams;
+        rt_handle *p = new (std::nothrow) rt_handle();
+        if (!p) return fail_create(RT_E_NOMEM, "out of host memory");
+        p->cfg = *cfg;
+        for (int k = 0; k <= lanes; ++k) p->kid_base.push_back((int)((int64_t)cfg->n_streams * k / lanes));
+        for (int k = 0; k < lanes; ++k) {
+            rt_config kc = *cfg;
+            kc.lanes = 1;
+            kc.n_streams = p->kid_base[(size_t)k + 1] - p->kid_base[(size_t)k];
+            rt_handle *kid = nullptr;
+            const int rc = rt_create(&kc, &kid);
+            if (rc != RT_OK) {
+                if (p->kids.empty()) delete p; else rt_destroy(p);
+                return rc;  // g_create_error was set by the failing rt_create
+            }
+            p->kids.push_back(kid);
+        }
+        *out = p;
+        return RT_OK;
+    }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -511,9 +558,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
 
 int rt_reset(rt_handle *h) {
     if (!h) return RT_E_INVALID;
+    for (rt_handle *k : h->kids) rt_reset(k);
     h->n_seg_last = -1;
     return RT_OK;
 }
+
 
 static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride, bool u8);
 
@@ -527,6 +576,13 @@ int rt_process_u8(rt_handle *h, const void *iq_u8_dev, int64_t n_samples, int64_
 
 static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride, bool u8) {
     if (!h) return RT_E_INVALID;
+    if (!h->kids.empty()) {
+        const int64_t bytes = u8 ? 2 : (int64_t)sizeof(cf);
+        return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
+            const char *base = iq_dev ? static_cast<const char *>(iq_dev) + s0 * stream_stride * bytes : nullptr;
+            return process_impl(k, base, n_samples, stream_stride, u8);
+        });
+    }
     if (!iq_dev && n_samples > 0) {
         h->err = "null IQ pointer";
         return RT_E_INVALID;
@@ -585,6 +641,11 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
 
 int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride) {
     if (!h) return RT_E_INVALID;
+    if (!h->kids.empty())
+        return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
+            const char *base = iq_host ? static_cast<const char *>(iq_host) + s0 * stream_stride * (int64_t)sizeof(cf) : nullptr;
+            return rt_process_host(k, base, n_samples, stream_stride);
+        });
     if (n_samples < 0 || stream_stride < n_samples) {
         h->err = "bad n_samples/stream_stride";
         return RT_E_INVALID;
@@ -613,6 +674,12 @@ int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_
 int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bins, const float *last_dev,
                int32_t n_seg_last) {
     if (!h) return RT_E_INVALID;
+    if (!h->kids.empty())
+        return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
+            const float *sp = spec_dev ? spec_dev + s0 * n_seg * n_bins : nullptr;
+            const float *la = last_dev ? last_dev + s0 * n_seg_last * n_bins : nullptr;
+            return rt_extract(k, sp, n_seg, n_bins, la, n_seg_last);
+        });
     if (n_seg < 0 || n_bins < 1 || (n_seg > 0 && !spec_dev) || (last_dev && n_seg_last < 0)) {
         h->err = "bad spectrogram arguments";
         return RT_E_INVALID;
@@ -661,8 +728,9 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
     return RT_OK;
 }
 
-int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
-    if (!h || !n_out) return RT_E_INVALID;
+// rt_fetch of one (lane-less) handle.  `peek`: wait, settle fall-backs and count, but deliver nothing and
+// keep the call pending even when it has no records (the laned rt_fetch sizes all lanes before it copies).
+static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bool peek) {
     *n_out = 0;
     Slot *slp = oldest_pending(h);
     if (!slp) {
@@ -713,7 +781,9 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
     for (int s = 0; s < S; ++s) total += (size_t)sl.h_rec_count[s];
     h->info.n_records = (int64_t)total;
     *n_out = total;
-    if (total && out && cap) {
+    if (peek) {
+        // nothing is delivered
+    } else if (total && out && cap) {
         size_t w = 0;
         for (int s = 0; s < S && w < cap; ++s) {
             const int n = sl.h_rec_count[s];
@@ -732,8 +802,65 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
     return RT_OK;
 }
 
+int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
+    if (!h || !n_out) return RT_E_INVALID;
+    if (h->kids.empty()) return fetch_one(h, out, cap, n_out, false);
+    // lanes: size every lane first (a size query must leave all of them pending), then deliver in
+    // stream order with the lane's first stream added to the records' stream index
+    *n_out = 0;
+    int truncated = RT_OK;
+    size_t total = 0;
+    for (rt_handle *k : h->kids) {
+        size_t n = 0;
+        const int rc = fetch_one(k, nullptr, 0, &n, true);
+        if (rc != RT_OK && rc != RT_E_CAPACITY) {
+            h->err = k->err;
+            return rc;
+        }
+        total += n;
+    }
+    *n_out = total;
+    h->info = rt_call_info{};
+    const bool deliver = !(total && (!out || !cap));
+    size_t w = 0;
+    for (size_t i = 0; i < h->kids.size(); ++i) {
+        rt_handle *k = h->kids[i];
+        if (deliver) {
+            size_t n = 0;
+            const int rc = fetch_one(k, out ? out + w : nullptr, cap > w ? cap - w : 0, &n, false);
+            if (rc == RT_E_CAPACITY) {
+                truncated = rc;
+                h->err = k->err;
+            } else if (rc != RT_OK) {
+                h->err = k->err;
+                return rc;
+            }
+            const size_t got = (cap > w) ? (n < cap - w ? n : cap - w) : 0;
+            if (out)
+                for (size_t j = 0; j < got; ++j) out[w + j].stream += h->kid_base[i];
+            w += got;
+        }
+        const rt_call_info &ki = k->info;
+        h->info.n_seg = ki.n_seg;
+        h->info.mode_used = i == 0 ? ki.mode_used : (ki.mode_used < h->info.mode_used ? ki.mode_used : h->info.mode_used);
+        h->info.fell_back |= ki.fell_back;
+        h->info.n_hot += ki.n_hot;
+        h->info.n_records += ki.n_records;
+        h->info.ms_stft += ki.ms_stft;      // sums over the lanes' launches (they overlap in time)
+        h->info.ms_detect += ki.ms_detect;
+        h->info.ms_total += ki.ms_total;
+    }
+    return truncated;
+}
+
 int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride, float *spec_dev) {
     if (!h || !iq_dev || !spec_dev) return RT_E_INVALID;
+    if (!h->kids.empty())
+        return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
+            const int64_t T = n_samples / k->N;
+            return rt_spectrogram(k, static_cast<const char *>(iq_dev) + s0 * stream_stride * (int64_t)sizeof(cf), n_samples,
+                                  stream_stride, spec_dev + s0 * T * k->N);
+        });
     if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples) {
         h->err = "n_samples/stream_stride out of range for this handle";
         return RT_E_INVALID;
@@ -752,6 +879,11 @@ int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t 
 
 int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride) {
     if (!h || !iq_dev) return RT_E_INVALID;
+    if (!h->kids.empty())
+        return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
+            return rt_calibrate_read(k, static_cast<const char *>(iq_dev) + s0 * stream_stride * (int64_t)sizeof(cf), n_samples,
+                                     stream_stride);
+        });
     if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples) {
         h->err = "n_samples/stream_stride out of range for this handle";
         return RT_E_INVALID;

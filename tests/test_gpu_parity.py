@@ -649,5 +649,26 @@ def test_lanes_give_the_same_records():
     assert total > 20
     info = three.call_info()
     assert info.n_records == len(b) and info.n_hot == one.call_info().n_hot
+    # host buffers and the C-level size query (rt_fetch with out == NULL keeps every lane pending)
+    import ctypes as C
+
+    chunk = np.ascontiguousarray(iq[:, :blen])
+    one.reset(); three.reset()
+    one.enqueue(chunk); three.enqueue(chunk)
+    want = one.fetch_records()
+    n = C.c_size_t(0)
+    lib, hd = three.native._lib, three.native._handle
+    assert lib.rt_fetch(hd, None, 0, C.byref(n)) == 0 and n.value == len(want)
+    assert lib.rt_fetch(hd, None, 0, C.byref(n)) == 0 and n.value == len(want)  # still pending
+    assert three.fetch_records().tobytes() == want.tobytes()
+    # spectrogram through the lanes: same cells as one handle
+    d_iq = _native.DeviceBuffer(0, chunk.nbytes); d_iq.upload(chunk)
+    n_seg = blen // nperseg
+    outs = []
+    for b_ in (one, three):
+        d_out = _native.DeviceBuffer(0, n_streams * n_seg * nperseg * 4)
+        b_.native.spectrogram_device(d_iq.ptr, blen, blen, d_out.ptr)
+        outs.append(d_out.download(np.float32, n_streams * n_seg * nperseg))
+    assert outs[0].tobytes() == outs[1].tobytes()
     with pytest.raises(ValueError):
         _batch_for(kw, 4, blen, "sparse", lanes=2, hip_stream=torch.cuda.current_stream().cuda_stream)
