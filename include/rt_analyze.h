@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -120,6 +120,23 @@ void rt_destroy(rt_handle *h);
 
 /* Forget the carried look-back state (== `_spectrogram_last = None`, analyze.py:128). */
 int rt_reset(rt_handle *h);
+
+/*
+ * Forget the look-back state of ONE stream: what the reference's Runner does when it replaces a dead or
+ * timed-out SDR's analyzer by a new one (__main__.py:153-190 -> a fresh SignalAnalyzer, analyze.py:128).
+ * Takes effect with the next rt_process; the other streams keep their state.  [SURVEY 8(f) rank 4]
+ */
+int rt_reset_stream(rt_handle *h, int32_t stream);
+
+/*
+ * Per-stream thresholds: the reference runs one SignalAnalyzer per SDR, each with its own
+ * `calibration_db` (__main__.py:140-141: zip(device, calibration)), and the absolute threshold depends
+ * on it (analyze.py:115: from_dB(signal_threshold_dbw + calibration_db)).  `threshold` and
+ * `calibration_db` are HOST arrays of n_streams float32 (linear threshold; calibration in dB, used as in
+ * rt_config to order maxima in the shadow filter); either may be NULL = keep rt_config's value for every
+ * stream.  Applies to calls enqueued afterwards; synchronises with the calls in flight.  [SURVEY 8(f) rank 4]
+ */
+int rt_set_stream_params(rt_handle *h, const float *threshold, const float *calibration_db);
 
 /*
  * Analyse one buffer per stream: the body of process_samples (analyze.py:234-251,

@@ -91,6 +91,8 @@ ABI_SYMBOLS = (
     "rt_create",
     "rt_destroy",
     "rt_reset",
+    "rt_reset_stream",
+    "rt_set_stream_params",
     "rt_process",
     "rt_process_u8",
     "rt_process_host",
@@ -142,6 +144,8 @@ def load_library(path: Optional[str] = None):
     lib.rt_destroy.argtypes = [vp]
     lib.rt_destroy.restype = None
     lib.rt_reset.argtypes = [vp]
+    lib.rt_reset_stream.argtypes = [vp, C.c_int32]
+    lib.rt_set_stream_params.argtypes = [vp, vp, vp]
     lib.rt_process.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_process_u8.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_process_host.argtypes = [vp, vp, C.c_int64, C.c_int64]
@@ -298,6 +302,27 @@ class NativeAnalyzer:
 
     def reset(self):
         self._check(self._lib.rt_reset(self._handle))
+
+    def reset_stream(self, stream: int):
+        self._check(self._lib.rt_reset_stream(self._handle, int(stream)))
+
+    def set_stream_params(self, threshold: Optional[np.ndarray], calibration_db: Optional[np.ndarray]):
+        """Per-stream linear thresholds / calibration (float32 ``[S]`` each, or None = the handle's value)."""
+
+        def arr(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.shape != (self.n_streams,):
+                raise ValueError(f"expected {self.n_streams} values")
+            return a
+
+        t, c = arr(threshold), arr(calibration_db)
+        self._check(
+            self._lib.rt_set_stream_params(
+                self._handle, t.ctypes.data if t is not None else None, c.ctypes.data if c is not None else None
+            )
+        )
 
     # -- analysis ---------------------------------------------------------
     def process_device(self, iq_ptr: int, n_samples: int, stream_stride: Optional[int] = None):

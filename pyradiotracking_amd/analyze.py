@@ -62,7 +62,9 @@ def stft_constants(fft_window, nperseg: int, sample_rate):
 class _RecordDecoder:
     """rt_record arrays -> Signal field columns (analyze.py:360, 420-449)."""
 
-    def __init__(self, nperseg: int, sample_rate, center_freq, calibration_db: float):
+    def __init__(self, nperseg: int, sample_rate, center_freq, calibration_db):
+        """``calibration_db``: one value, or one per stream (the reference has one analyzer and one
+        calibration per SDR, __main__.py:140-141)."""
         self.nperseg = nperseg
         self.sample_rate = sample_rate
         self.center_freq = center_freq
@@ -80,6 +82,10 @@ class _RecordDecoder:
         t_start = np.where(start < 0, -self.times(np.abs(start)), self.times(np.maximum(start, 0)))
         duration_s = t_end - t_start
         cal = self.calibration_db
+        if np.ndim(cal):
+            # float32 dB figure minus a Python float is a float32 subtraction (NEP 50): the same bits as
+            # subtracting the calibration rounded to float32
+            cal = np.asarray(cal, dtype=np.float32)[rec["stream"]]
         with np.errstate(divide="ignore", invalid="ignore"):
             max_dbw = dB(rec["max_p"]) - cal  # float32, analyze.py:442
             avg_dbw = dB(rec["mean_p"]) - cal  # :444
@@ -123,7 +129,7 @@ class BatchSignalAnalyzer:
     def __init__(
         self,
         devices: Sequence[str],
-        calibration_db: float = 0.0,
+        calibration_db: Union[float, Sequence[float]] = 0.0,
         sample_rate: int = 300000,
         center_freq: int = 150150000,
         fft_nperseg: int = 256,
@@ -146,8 +152,18 @@ class BatchSignalAnalyzer:
         """``lanes`` > 1 (``rt_config.lanes``) splits the streams into that many contiguous groups, each
         analysed on its own HIP stream: the detection kernels and launch gaps of one group then overlap the
         scan of another (config 2: +14 % whole-path throughput with two lanes).  Streams are independent,
-        so the records are the same; ``rt_fetch`` returns them in stream order.  Needs ``hip_stream=None``."""
+        so the records are the same; ``rt_fetch`` returns them in stream order.  Needs ``hip_stream=None``.
+
+        ``calibration_db`` may be a sequence with one value per stream: every SDR of the reference has its own
+        analyzer and calibration (``__main__.py:140-141``), and with it its own absolute threshold
+        (``analyze.py:115``); the kernels then take the thresholds per stream (``rt_set_stream_params``)."""
         self.devices = [str(d) for d in devices]
+        per_stream_cal = None
+        if np.ndim(calibration_db):
+            per_stream_cal = [float(c) for c in calibration_db]
+            if len(per_stream_cal) != len(self.devices):
+                raise ValueError(f"calibration values {per_stream_cal} do not match devices {self.devices}")  # __main__.py:219
+            calibration_db = per_stream_cal[0]
         self.calibration_db = calibration_db
         self.sample_rate = sample_rate
         self.center_freq = center_freq
@@ -186,7 +202,13 @@ class BatchSignalAnalyzer:
             hip_stream=hip_stream,
             lanes=max(1, int(lanes)),
         )
-        self._decoder = _RecordDecoder(fft_nperseg, sample_rate, center_freq, calibration_db)
+        if per_stream_cal is not None:
+            self.calibration_db = per_stream_cal
+            self.signal_threshold = [from_dB(signal_threshold_dbw + c) for c in per_stream_cal]  # :115, per SDR
+            self._native.set_stream_params(
+                np.array(self.signal_threshold, dtype=np.float64).astype(np.float32), np.array(per_stream_cal, dtype=np.float32)
+            )
+        self._decoder = _RecordDecoder(fft_nperseg, sample_rate, center_freq, self.calibration_db)
         self.decoder = self._decoder  # record -> field conversion, shared with pyradiotracking_amd.match
         self.gpu = gpu
         self._hip_stream = hip_stream
@@ -205,6 +227,11 @@ class BatchSignalAnalyzer:
     def reset(self):
         """``_spectrogram_last = None`` for every stream."""
         self._native.reset()
+
+    def reset_stream(self, stream: int):
+        """``_spectrogram_last = None`` for one stream: its SDR was restarted, i.e. the reference would have
+        replaced its analyzer by a fresh one (``__main__.py:185-190``)."""
+        self._native.reset_stream(stream)
 
     def close(self):
         self._native.close()

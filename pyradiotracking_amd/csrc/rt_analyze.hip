@@ -52,6 +52,7 @@ struct CallCtx {
     bool fell_back = false;
     bool is_extract = false;
     bool u8 = false;        // IQ is interleaved uint8 (RTL-SDR wire format)
+    bool no_last = false;   // the slot's h_no_last flags apply (some stream was reset, rt_reset_stream)
 };
 
 struct Slot {
@@ -68,6 +69,7 @@ struct Slot {
     unsigned long long *h_counters = nullptr;
     int32_t *h_rec_offset = nullptr, *h_rec_count = nullptr;  // [S]
     rt_record *h_records = nullptr;                            // [pool_cap]
+    int32_t *h_no_last = nullptr;                              // pinned, [S]: streams without a previous buffer in this call
     hipEvent_t ev_begin = nullptr, ev_scan = nullptr, ev_done = nullptr;
     CallCtx call;
 };
@@ -102,6 +104,9 @@ struct rt_handle {
     uint64_t n_calls = 0;  // calls enqueued so far
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
+    std::vector<uint8_t> reset_pending;  // [S] streams whose look-back is dropped at the next rt_process
+    bool any_reset_pending = false;
+    float *d_thr_s = nullptr, *d_cal_s = nullptr;  // [S] per-stream thresholds / calibration (rt_set_stream_params)
 
     rt_call_info info{};
     bool timing = false;
@@ -181,6 +186,7 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.tw2 = h->d_tw2;
     p.scale = h->cfg.scale;
     p.thr = h->cfg.threshold;
+    p.thr_s = h->d_thr_s;
     p.psum = sl.d_psum;
     p.tail = h->d_tail[tail_write];
     p.spec = h->d_spec;
@@ -225,6 +231,9 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.rec_count = sl.h_rec_count;
     a.counters = sl.d_counters;
     a.host_counters = sl.h_counters;
+    a.thr_s = h->d_thr_s;
+    a.cal_s = h->d_cal_s;
+    a.no_last = sl.call.no_last ? sl.h_no_last : nullptr;
     return a;
 }
 
@@ -361,6 +370,8 @@ void rt_destroy(rt_handle *h) {
     for (auto &t : h->d_tail) (void)hipFree(t);
     (void)hipFree(h->d_spec);
     (void)hipFree(h->d_iq_stage);
+    (void)hipFree(h->d_thr_s);
+    (void)hipFree(h->d_cal_s);
     for (auto &sl : h->slot) {
         (void)hipFree(sl.d_hot);
         (void)hipFree(sl.d_hot_count);
@@ -374,6 +385,7 @@ void rt_destroy(rt_handle *h) {
         (void)hipHostFree(sl.h_rec_offset);
         (void)hipHostFree(sl.h_rec_count);
         (void)hipHostFree(sl.h_records);
+        (void)hipHostFree(sl.h_no_last);
         if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
         if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
@@ -489,6 +501,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     }
 
     const int S = cfg->n_streams, N = h->N, LG = h->LG;
+    h->reset_pending.assign((size_t)S, 0);
     // window and twiddle tables (twiddles in double, rounded once to float32)
     std::vector<cf> tw1((size_t)LG * 16), tw2((size_t)R3 * 16);
     const double two_pi = 6.283185307179586476925286766559;
@@ -538,6 +551,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_offset, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_count, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_records, (size_t)h->pool_cap * sizeof(rt_record)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_no_last, (size_t)S * sizeof(int32_t)));
+        std::memset(sl.h_no_last, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_begin));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_scan));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_done));
@@ -560,7 +575,50 @@ int rt_reset(rt_handle *h) {
     if (!h) return RT_E_INVALID;
     for (rt_handle *k : h->kids) rt_reset(k);
     h->n_seg_last = -1;
+    std::fill(h->reset_pending.begin(), h->reset_pending.end(), (uint8_t)0);
+    h->any_reset_pending = false;
     return RT_OK;
+}
+
+int rt_reset_stream(rt_handle *h, int32_t stream) {
+    if (!h) return RT_E_INVALID;
+    if (stream < 0 || stream >= h->cfg.n_streams) {
+        h->err = "stream index out of range";
+        return RT_E_INVALID;
+    }
+    if (!h->kids.empty()) {
+        for (size_t k = 0; k < h->kids.size(); ++k)
+            if (stream < h->kid_base[k + 1]) return rt_reset_stream(h->kids[k], stream - h->kid_base[k]);
+        return RT_E_INVALID;
+    }
+    h->reset_pending[(size_t)stream] = 1;
+    h->any_reset_pending = true;
+    return RT_OK;
+}
+
+int rt_set_stream_params(rt_handle *h, const float *threshold, const float *calibration_db) {
+    if (!h) return RT_E_INVALID;
+    if (!h->kids.empty())
+        return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
+            return rt_set_stream_params(k, threshold ? threshold + s0 : nullptr, calibration_db ? calibration_db + s0 : nullptr);
+        });
+    RT_HIP(h, hipSetDevice(h->cfg.device));
+    // kernels in flight read the arrays: let them finish first (a configuration call, not on the hot path)
+    RT_HIP(h, hipStreamSynchronize(h->s_scan));
+    const size_t bytes = (size_t)h->cfg.n_streams * sizeof(float);
+    auto put = [&](float *&dst, const float *src) -> int {
+        if (!src) {
+            if (dst) (void)hipFree(dst);
+            dst = nullptr;
+            return RT_OK;
+        }
+        if (!dst) RT_HIP(h, hipMalloc(&dst, bytes));
+        RT_HIP(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return RT_OK;
+    };
+    int rc = put(h->d_thr_s, threshold);
+    if (rc != RT_OK) return rc;
+    return put(h->d_cal_s, calibration_db);
 }
 
 
@@ -610,6 +668,14 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
     c.tail_read = h->tail_cur;
     c.tail_write = (h->tail_cur + 1) % kTails;
     c.n_seg_last = h->n_seg_last;
+    if (h->any_reset_pending) {
+        // the slot's previous call (two calls back) may still be reading its flags if it was never fetched
+        if (sl.ev_done && h->n_calls >= (uint64_t)kSlots) RT_HIP(h, hipEventSynchronize(sl.ev_done));
+        for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_no_last[s] = h->reset_pending[(size_t)s];
+        std::fill(h->reset_pending.begin(), h->reset_pending.end(), (uint8_t)0);
+        h->any_reset_pending = false;
+        c.no_last = true;
+    }
     c.mode_used = (h->cfg.mode == RT_MODE_DENSE) ? RT_MODE_DENSE : RT_MODE_SPARSE;
     if (h->cfg.mode == RT_MODE_AUTO && h->dense_sticky > 0) {
         // the input recently overflowed the candidate lists: do not pay for a sparse attempt

@@ -54,6 +54,7 @@ struct StftParams {
     const cf *tw2;           // [R3][16]   W_LG^(b*q1)
     float scale;
     float thr;
+    const float *thr_s;      // [S] per-stream thresholds (one calibration per SDR, analyze.py:115), or null: `thr` for all
     float *psum;             // [S][blocks_per_stream][N] partial row sums (one row per workgroup)
     float *tail;             // [S][K][N] trailing K columns (written)
     float *spec;             // MODE 1/2: [S][T][N]
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
     float acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float thr = p.thr_s ? p.thr_s[s] : p.thr;  // wave-uniform
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
     // candidate staging: 128 cells per wave, flushed with one returned atomic per bucket
     __shared__ uint2 stage[MODE == 0 ? (kBlock / 64) * kStageCap : 1];
@@ -528,10 +530,10 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, P[r]), P[r + 1]);
             mx = __builtin_fmaxf(mx, P[15]);
             uint32_t hot = 0;
-            if (active && !(mx < p.thr)) {
+            if (active && !(mx < thr)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (!(P[r] < p.thr)) hot |= (1u << r);
+                    if (!(P[r] < thr)) hot |= (1u << r);
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
             const uint32_t emit = (active && !halo) ? (hot | next_hot) : 0u;
@@ -640,7 +642,21 @@ struct DetectArgs {
     int32_t *rec_count;        // [S]
     unsigned long long *counters;  // [0] records allocated, [1] hot total, [2] flags, [3] workgroups done (close_call)
     unsigned long long *host_counters;  // pinned host copy of the four words, written by the call's last workgroup
+    // per-stream overrides (null = dp's value for every stream)
+    const float *thr_s;        // [S] signal_threshold of the stream's SDR (analyze.py:115)
+    const float *cal_s;        // [S] its calibration_db (orders maxima in the shadow filter)
+    const int32_t *no_last;    // [S] (host-visible) non-zero: this stream has no previous buffer in this call
+                               //     (a restarted SDR's fresh analyzer, analyze.py:128)
 };
+
+// the detect parameters as stream `s` sees them (s is workgroup- or wave-uniform: scalar loads)
+__device__ __forceinline__ DetectParams stream_params(const DetectArgs &a, int s) {
+    DetectParams dp = a.dp;
+    if (a.thr_s) dp.thr = a.thr_s[s];
+    if (a.cal_s) dp.cal_db = a.cal_s[s];
+    if (a.no_last && a.no_last[s]) dp.n_seg_last = -1;
+    return dp;
+}
 
 constexpr unsigned long long kFlagHotOverflow = 1ull;
 constexpr unsigned long long kFlagRecOverflow = 2ull;
@@ -788,9 +804,10 @@ __device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int n) {
     __syncthreads();
     const int base = *lds_base;
     if (base < 0) return;
+    const float cal_db = a.cal_s ? a.cal_s[s] : a.dp.cal_db;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         int rank, shadow;
-        rank_and_shadow(i, n, l.rec, l.ts_us, l.dur_us, a.dp.cal_db, &rank, &shadow);
+        rank_and_shadow(i, n, l.rec, l.ts_us, l.dur_us, cal_db, &rank, &shadow);
         rt_record out = l.rec[i];
         out.shadowed = shadow;
         out.reserved = 0;
@@ -1015,7 +1032,7 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     float *avg = vals + cap2;
     rt_record *cand = reinterpret_cast<rt_record *>(base + (size_t)cap2 * 8 + (((size_t)nbins_b * 4 + 15) & ~(size_t)15));
     const uint32_t tmask = (1u << a.tbits) - 1u;
-    const DetectParams &dp = a.dp;
+    const DetectParams dp = stream_params(a, s);
 
     // row means of the bucket's bins: np.mean(row) (analyze.py:375) from the scan's partial sums
 #ifndef RT_DETECT_ABLATE
@@ -1292,7 +1309,7 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     if (tid == 0) *l.count = 0;
     __syncthreads();
 
-    const DetectParams &dp = a.dp;
+    const DetectParams dp = stream_params(a, s);
     const float *sp = a.spec + (int64_t)s * T * F;
     // work items = (bin, time range): with few bins the time axis is split so that all 1024
     // threads scan (runs are owned by the range they start in)

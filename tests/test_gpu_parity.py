@@ -672,3 +672,58 @@ def test_lanes_give_the_same_records():
     assert outs[0].tobytes() == outs[1].tobytes()
     with pytest.raises(ValueError):
         _batch_for(kw, 4, blen, "sparse", lanes=2, hip_stream=torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("mode,lanes", [("sparse", 1), ("dense", 1), ("sparse", 2)])
+def test_per_stream_calibration_and_stream_restart(mode, lanes):
+    """One calibration (and with it one absolute threshold, analyze.py:115) per SDR in a batch, as the
+    reference's Runner hands them out (__main__.py:140-141), and the restart of single SDRs
+    (__main__.py:185-190: a fresh analyzer, no look-back) while the others keep their state."""
+    _need_gpu()
+    fs, nperseg, window = 2048000, 256, "hamming"
+    n_streams, n_buf, blen = 6, 3, 500 * nperseg + 5
+    cal = [0.0, 3.5, -2.0, 10.0, 0.0, -7.25]
+    w = oracle.window_coefficients(window, nperseg)
+    rng = np.random.default_rng(77)
+    iq = []
+    for s in range(n_streams):
+        pulses = synth.random_pulses(rng, n_buf * blen, fs, w, 14, dur_ms=(9, 30), peak_dbw=(-97.0, -70.0))
+        for k in range(1, n_buf):  # one pulse across every buffer boundary: the look-back matters
+            amp = synth.amp_for_peak_dbw(-65.0, w, fs)
+            pulses.append(synth.Pulse(k * blen - int(0.006 * fs), int(0.015 * fs), (0.1 + 0.05 * s) * fs, amp, 0.25))
+        iq.append(synth.make_stream(synth.StreamSpec(n_buf * blen, fs, pulses), 900 + s))
+    iq = np.stack(iq)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window)
+    b = _batch_for(kw, n_streams, blen, mode, calibration_db=cal, lanes=lanes)
+    oas = [oracle.OracleAnalyzer(device=str(s), calibration_db=cal[s], **kw) for s in range(n_streams)]
+    restarts = {1: [2, 5], 2: [0]}  # before buffer k: these streams' SDRs were restarted
+    n_total, n_negative_start, counts = 0, 0, np.zeros(n_streams, int)
+    for k in range(n_buf):
+        for s in restarts.get(k, []):
+            b.reset_stream(s)
+            oas[s].reset()
+        chunk = np.ascontiguousarray(iq[:, k * blen:(k + 1) * blen])
+        b.enqueue(chunk)
+        rec = b.fetch_records()
+        for s in range(n_streams):
+            want_all, want_kept = oas[s].process(chunk[s], gu.TS0)
+            mine = rec[rec["stream"] == s]
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want_all], f"buffer {k} stream {s}"
+            kept_ids = {id(x) for x in want_kept}
+            assert [bool(r["shadowed"]) for r in mine] == [id(x) not in kept_ids for x in want_all]
+            sigs = b._decoder.signals(mine, [str(i) for i in range(n_streams)], [gu.TS0] * n_streams)
+            for g, x in zip(sigs, want_all):
+                assert g.ts == x.ts and g.duration == x.duration and g.frequency == x.frequency
+                for name in ("max", "avg", "noise", "snr", "std"):
+                    assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB, (name, getattr(g, name), getattr(x, name))
+            n_total += len(mine)
+            counts[s] += len(mine)
+            n_negative_start += int((mine["start"] < 0).sum())
+            if k in restarts and s in restarts[k]:
+                assert not (mine["start"] < 0).any(), "a restarted stream has no previous buffer"
+    assert n_total > 30 and n_negative_start >= 6
+    assert len(set(counts.tolist())) > 1  # the thresholds really differ between the streams
+    with pytest.raises(_native.NativeError):
+        b.reset_stream(n_streams)
+    with pytest.raises(ValueError):
+        _batch_for(kw, n_streams, blen, mode, calibration_db=cal[:-1])
