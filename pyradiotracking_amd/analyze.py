@@ -10,7 +10,8 @@ are computed here with the reference's own expressions, so they are bit-exact
 by construction).
 
 Not mirrored (out of scope): opening an RTL-SDR, the
-SIGALRM watchdog, ``StateMessage`` heartbeats, process lifecycle.
+SIGALRM watchdog, the process itself (the per-stream life-cycle rules of the
+reference's Runner are in :mod:`pyradiotracking_amd.runner`).
 
 Two entry levels:
 
