@@ -526,6 +526,63 @@ def test_config2_full_size_properties():
                 assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB
 
 
+@pytest.mark.parametrize(
+    "name,fs,nperseg,window,blen,n_streams,trains",
+    [
+        ("config3", 2400000, 1024, "hann", 2400000, 512, False),   # BASELINE configs[2]: 4096 streams on one GPU; 512 here
+        ("config4", 2048000, 256, "hamming", 524288, 2048, False),  # configs[3] at the one-GPU buffer length, 1/16 of the streams
+        ("config5", 3200000, 4096, "hamming", 3200000, 256, True),  # configs[4]: 1024 streams per GPU at 8 GPUs; 256 here, dense tag trains
+    ],
+)
+def test_other_baseline_configs_full_geometry_properties(name, fs, nperseg, window, blen, n_streams, trains):
+    """The other BASELINE.json configurations at their full per-stream geometry (sample rate, nperseg, window,
+    buffer length, pulse recipe) and enough streams to fill the GPU many times over, through size-independent
+    properties: sparse == dense bit for bit, emission order, two consecutive buffers with carried look-back ==
+    per-stream oracle on sampled streams, two lanes == one lane."""
+    import torch
+
+    _need_gpu()
+    w = oracle.window_coefficients(window, nperseg)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window)
+    bufs = [synth.make_batch_device(n_streams, blen, fs, w, seed=31 + k, trains=trains) for k in range(2)]
+    # a pulse across the buffer boundary in the sampled streams: carried look-back at full size
+    sampled = (0, n_streams // 3, n_streams - 1)
+    amp = synth.amp_for_peak_dbw(-66.0, w, fs)
+    n_a, n_b = int(0.006 * fs), int(0.009 * fs)
+    for s in sampled:
+        f = (0.11 + 0.0007 * s) * fs
+        t = torch.arange(-n_a, n_b, device="cuda", dtype=torch.float64)
+        tone = (torch.complex(torch.cos(2 * np.pi * f * t / fs), torch.sin(2 * np.pi * f * t / fs)) * amp).to(torch.complex64)
+        bufs[0][s, blen - n_a:] += tone[:n_a]
+        bufs[1][s, :n_b] += tone[n_a:]
+    sparse = _batch_for(kw, n_streams, blen, "sparse")
+    dense = _batch_for(kw, n_streams, blen, "dense")
+    lanes2 = _batch_for(kw, n_streams, blen, "sparse", lanes=2)
+    oas = {s: oracle.OracleAnalyzer(device=str(s), **kw) for s in sampled}
+    n_neg = 0
+    for k, iq in enumerate(bufs):
+        for b in (sparse, dense, lanes2):
+            b.enqueue(iq)
+        rec_s, rec_d, rec_l = sparse.fetch_records(), dense.fetch_records(), lanes2.fetch_records()
+        assert sparse.native.call_info().fell_back == 0
+        assert len(rec_s) > n_streams and rec_s.tobytes() == rec_d.tobytes() == rec_l.tobytes(), f"{name} buffer {k}"
+        key = rec_s["stream"].astype(np.int64) * 2**40 + rec_s["fi"].astype(np.int64) * 2**20 + (rec_s["start"].astype(np.int64) + 2**19)
+        assert np.all(np.diff(key) > 0)
+        for s in sampled:
+            want, kept = oas[s].process(iq[s].cpu().numpy(), gu.TS0)
+            mine = rec_s[rec_s["stream"] == s]
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want], f"{name} buffer {k} stream {s}"
+            kept_ids = {id(x) for x in kept}
+            assert [bool(r["shadowed"]) for r in mine] == [id(x) not in kept_ids for x in want]
+            sigs = sparse._decoder.signals(mine, [str(s)] * n_streams, [gu.TS0] * n_streams)
+            for g, x in zip(sigs, want):
+                assert g.ts == x.ts and g.duration == x.duration and g.frequency == x.frequency
+                for fld in ("max", "avg", "noise", "snr", "std"):
+                    assert abs(getattr(g, fld) - getattr(x, fld)) < POWER_TOL_DB, (name, s, fld)
+            n_neg += int((mine["start"] < 0).sum())
+    assert n_neg >= len(sampled)  # the planted cross-buffer pulses were found with their look-back part
+
+
 # ---------------------------------------------------------------------------
 # analysis -> matcher on record arrays (SURVEY 8(f) rank 2)
 # ---------------------------------------------------------------------------

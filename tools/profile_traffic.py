@@ -28,7 +28,7 @@ def main():
     from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
 
     S = int(os.environ.get("RT_PROF_STREAMS", "256"))
-    fs, nperseg = 2048000, 256
+    fs, nperseg = int(os.environ.get("RT_PROF_FS", "2048000")), int(os.environ.get("RT_PROF_NPERSEG", "256"))
     blen = int(os.environ.get("RT_PROF_SAMPLES", str(fs)))
     cal = int(os.environ.get("RT_PROF_CAL", "3"))
     steps = int(os.environ.get("RT_PROF_STEPS", "3"))
@@ -43,7 +43,7 @@ def main():
     dev = _native.DeviceBuffer(0, S * blen * 8)
     for s in range(S):
         _native.load_library().rt_dev_upload(0, dev.ptr + s * blen * 8, base[s % 8].ctypes.data, blen * 8)
-    an = BatchSignalAnalyzer([str(i) for i in range(S)], sdr_callback_length=blen, sample_rate=fs, mode="sparse")
+    an = BatchSignalAnalyzer([str(i) for i in range(S)], sdr_callback_length=blen, sample_rate=fs, fft_nperseg=nperseg, mode="sparse")
     for _ in range(cal):
         an.native.calibrate_read(dev.ptr, blen, blen)
     n_hot = n_rec = 0
