@@ -147,7 +147,8 @@ int rt_set_stream_params(rt_handle *h, const float *threshold, const float *cali
  * GPU never waits for the host; with cfg.lanes > 1 the lanes' kernels also overlap
  * each other); a third rt_process without
  * an rt_fetch drops the oldest unfetched result.  `iq_dev` must stay valid and
- * unchanged until the call has been fetched.
+ * unchanged until the call has been fetched.  `iq_dev` must be 8-byte aligned (whole complex64
+ * samples; rt_process_u8: 2-byte aligned) -- anything else is refused with RT_E_INVALID, not launched.
  */
 int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stream_stride);
 

@@ -649,6 +649,12 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         h->err = "n_samples/stream_stride out of range for this handle";
         return RT_E_INVALID;
     }
+    // the scan kernel loads whole samples (8-byte complex64 / 2-byte I,Q pairs): a misaligned pointer would
+    // fault on the device, so it is refused here
+    if (reinterpret_cast<uintptr_t>(iq_dev) % (u8 ? 2u : 8u) != 0) {
+        h->err = u8 ? "IQ pointer must be 2-byte aligned (uint8 I,Q pairs)" : "IQ pointer must be 8-byte aligned (complex64)";
+        return RT_E_INVALID;
+    }
     RT_HIP(h, hipSetDevice(h->cfg.device));
     const int T = (int)(n_samples / h->N);
     if (T == 1) {
@@ -753,6 +759,10 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
     if (n_seg == 1) {
         h->err = "exactly one segment: the reference raises IndexError (times[1])";
         return RT_E_ONE_SEGMENT;
+    }
+    if (reinterpret_cast<uintptr_t>(spec_dev) % 4u != 0 || reinterpret_cast<uintptr_t>(last_dev) % 4u != 0) {
+        h->err = "spectrogram pointers must be 4-byte aligned (float32)";
+        return RT_E_INVALID;
     }
     if ((int64_t)n_seg * n_bins > 0x7FFFFFFFll) {
         h->err = "spectrogram too large";
@@ -927,8 +937,9 @@ int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t 
             return rt_spectrogram(k, static_cast<const char *>(iq_dev) + s0 * stream_stride * (int64_t)sizeof(cf), n_samples,
                                   stream_stride, spec_dev + s0 * T * k->N);
         });
-    if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples) {
-        h->err = "n_samples/stream_stride out of range for this handle";
+    if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples ||
+        reinterpret_cast<uintptr_t>(iq_dev) % 8u != 0 || reinterpret_cast<uintptr_t>(spec_dev) % 4u != 0) {
+        h->err = "n_samples/stream_stride out of range for this handle, or misaligned pointer";
         return RT_E_INVALID;
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
@@ -950,8 +961,8 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
             return rt_calibrate_read(k, static_cast<const char *>(iq_dev) + s0 * stream_stride * (int64_t)sizeof(cf), n_samples,
                                      stream_stride);
         });
-    if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples) {
-        h->err = "n_samples/stream_stride out of range for this handle";
+    if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples || reinterpret_cast<uintptr_t>(iq_dev) % 8u != 0) {
+        h->err = "n_samples/stream_stride out of range for this handle, or misaligned pointer";
         return RT_E_INVALID;
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));

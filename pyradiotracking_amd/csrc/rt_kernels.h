@@ -315,9 +315,10 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
     {
         int seg0 = c0 + L - i_first;
         seg0 = seg0 < seg_hi ? seg0 : seg_hi;
-#ifdef RT_EXP_ALIAS  // diagnostic build (tools/variant.sh alias -DRT_EXP_ALIAS=1): every load hits the same 64 segments of
-                     // stream 0 (L2-resident) -- the scan kernel without HBM, i.e. its arithmetic + LDS floor
-        const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(seg0 & 63) * N + lt;
+#ifdef RT_EXP_ALIAS  // diagnostic build (tools/variant.sh alias -DRT_EXP_ALIAS=63): every load hits the same 64 segments of
+                     // stream 0 (L2-resident) -- the scan kernel without HBM, i.e. its arithmetic + LDS floor; a mask of
+                     // 8191 keeps a whole stream (16 MB at nperseg 256: misses L2, stays in the Infinity Cache)
+        const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(seg0 & RT_EXP_ALIAS) * N + lt;
 #else
         const raw_t *src = stream_iq + (int64_t)seg0 * N + lt;
 #endif
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             int seg1 = (i < L) ? seg - 1 : seg;
             seg1 = seg1 < seg_hi ? seg1 : seg_hi;
 #ifdef RT_EXP_ALIAS
-            const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(seg1 & 63) * N + lt;
+            const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(seg1 & RT_EXP_ALIAS) * N + lt;
 #else
             const raw_t *src = stream_iq + (int64_t)seg1 * N + lt;
 #endif

@@ -471,6 +471,26 @@ def test_degenerate_lengths():
         an.analyze_buffer(np.zeros(5000, np.complex64), gu.TS0)
 
 
+def test_misaligned_device_pointers_are_refused():
+    """A pointer the kernels cannot load whole samples from is refused on the host (RT_E_INVALID), not
+    launched: complex64 needs 8-byte alignment, uint8 I/Q pairs 2-byte alignment."""
+    _need_gpu()
+    blen = 4096
+    b = _batch_for(dict(sample_rate=2048000), 2, blen, "sparse")
+    dev = _native.DeviceBuffer(0, 2 * (blen + 8) * 8)
+    dev.upload(np.zeros(2 * (blen + 8), np.complex64))
+    for off in (1, 2, 4):
+        with pytest.raises(_native.NativeError) as e:
+            b.enqueue(dev.ptr + off, n_samples=blen, stream_stride=blen)
+        assert e.value.code == _native.RT_E_INVALID and "aligned" in str(e.value)
+    with pytest.raises(_native.NativeError):
+        b.enqueue_bytes(dev.ptr + 1, n_samples=blen, stream_stride=blen)
+    b.enqueue(dev.ptr + 8, n_samples=blen, stream_stride=blen)  # any whole-sample offset is fine
+    assert len(b.fetch_records()) == 0
+    b.enqueue_bytes(dev.ptr + 2, n_samples=blen, stream_stride=blen)
+    b.fetch_records()
+
+
 def test_unsupported_nperseg_is_refused():
     _need_gpu()
     with pytest.raises(_native.NativeError) as ei:
