@@ -1,6 +1,6 @@
 """CPU restatement of the reference's cross-SDR matcher.
 
-TEST INFRASTRUCTURE ONLY: imported by tests/ and tools/bench_match.py's CPU
+TEST INFRASTRUCTURE ONLY: imported by tests/ and tests/perf/bench_match.py's CPU
 baseline, never by the product (pyradiotracking_amd.match calls the C-ABI of
 include/rt_match.h).
 

@@ -3,7 +3,7 @@
 drop-in class fed Signal by Signal, and the CPU restatement of the reference (oracle/match_oracle.py,
 the same Python-level algorithm the reference runs).  Host code only.
 
-    python tools/bench_match.py [n_signals] [n_devices] [n_tags]
+    python tests/perf/bench_match.py [n_signals] [n_devices] [n_tags]
 """
 import datetime
 import json
@@ -11,7 +11,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from oracle.match_oracle import MatchInput, OracleMatcher
