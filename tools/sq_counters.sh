@@ -12,6 +12,15 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD \
   --kernel-trace --output-format csv -d $out/p2 -- python3 tools/profile_traffic.py > $out/p2.json 2> $out/p2.err
 python3 tools/pmc_summary.py $out/p1 $out/p2 > $PWD/gpurun_out/sq_$tag.txt
-grep -h "stft_scan" $(ls $out/p1/*/*kernel_trace.csv | head -1) | awk -F, '{print $NF}' > /dev/null
+python3 - $out/p1 >> $PWD/gpurun_out/sq_$tag.txt <<'PY'
+import csv, glob, sys, collections
+d = collections.defaultdict(list)
+for path in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        if "rt::" in r["Kernel_Name"]:
+            d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for k, v in sorted(d.items()):
+    print(f"{k[:60]:60s} DURATION_NS  n={len(v):3d} mean={sum(v)/len(v):.1f} min={min(v):.1f} max={max(v):.1f}")
+PY
 rm -rf $out
 grep "stft_scan" $PWD/gpurun_out/sq_$tag.txt
