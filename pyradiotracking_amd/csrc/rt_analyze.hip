@@ -804,6 +804,19 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
     return RT_OK;
 }
 
+// peek-mode results of fetch_one: the call produced no usable result (the caller decides what happens to it)
+constexpr int kCallFailed = -100;          // -> RT_E_CAPACITY (candidate lists overflowed in sparse mode)
+constexpr int kCallFailedInternal = -101;  // -> RT_E_HIP
+
+// drop the oldest pending call of a handle (its GPU work is waited for first)
+static void discard_oldest(rt_handle *h) {
+    Slot *sl = oldest_pending(h);
+    if (!sl) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipEventSynchronize(sl->ev_done);
+    sl->call.pending = false;
+}
+
 // rt_fetch of one (lane-less) handle.  `peek`: wait, settle fall-backs and count, but deliver nothing and
 // keep the call pending even when it has no records (the laned rt_fetch sizes all lanes before it copies).
 static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bool peek) {
@@ -825,8 +838,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
     if ((flags & kFlagHotOverflow) && !c.is_extract) {
         if (h->cfg.mode == RT_MODE_SPARSE) {
-            c.pending = false;
             h->err = "candidate-cell capacity exceeded (hot_capacity) in sparse mode";
+            if (peek) return kCallFailed;  // the laned rt_fetch drops this call in every lane together
+            c.pending = false;
             return RT_E_CAPACITY;
         }
         // dense re-run of the same buffer with the same look-back state, after everything in flight
@@ -840,8 +854,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         flags = sl.h_counters[2];
     }
     if (flags & kFlagInconsistent) {
-        c.pending = false;
         h->err = "internal: candidate list lacks the cell preceding a run";
+        if (peek) return kCallFailedInternal;
+        c.pending = false;
         return RT_E_HIP;
     }
     if (h->timing && c.n_seg > 0) {
@@ -886,14 +901,22 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
     *n_out = 0;
     int truncated = RT_OK;
     size_t total = 0;
+    int failed = RT_OK;
     for (rt_handle *k : h->kids) {
         size_t n = 0;
         const int rc = fetch_one(k, nullptr, 0, &n, true);
-        if (rc != RT_OK && rc != RT_E_CAPACITY) {
+        if (rc != RT_OK && rc != RT_E_CAPACITY && failed == RT_OK) {
             h->err = k->err;
-            return rc;
+            failed = (rc == kCallFailed) ? RT_E_CAPACITY : (rc == kCallFailedInternal) ? RT_E_HIP : rc;
         }
         total += n;
+    }
+    if (failed != RT_OK) {
+        // one lane has no result for this call: the call is dropped in every lane, so that the lanes stay in step
+        // (the next rt_fetch belongs to the next rt_process in all of them)
+        for (rt_handle *k : h->kids) discard_oldest(k);
+        *n_out = 0;
+        return failed;
     }
     *n_out = total;
     h->info = rt_call_info{};

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU box): random geometries, thresholds, durations, calibrations, lanes and pulse
+placements (incl. pulses across buffer boundaries and at buffer ends), every stream of every case compared with the
+oracle record by record.  Not part of the pytest suite (minutes of runtime); prints one line per case and a
+summary.  usage: soak_parity.py [seconds] [seed]"""
+import datetime
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import analyze_oracle as oracle  # noqa: E402
+from pyradiotracking_amd import synth  # noqa: E402
+from pyradiotracking_amd.analyze import BatchSignalAnalyzer  # noqa: E402
+
+TS0 = datetime.datetime(2024, 1, 1)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + budget
+n_cases = n_records = n_bad = n_unexplained = n_field = 0
+case = 0
+while time.time() < t_end:
+    case += 1
+    rng = np.random.default_rng([seed0, case])
+    nperseg = int(rng.choice([256, 256, 512, 1024, 2048, 4096]))
+    fs = int(rng.choice([300000, 1024000, 2048000, 2400000, 3200000]))
+    window = rng.choice(["hamming", "hann", "blackman", "boxcar"])
+    n_seg = int(rng.integers(2, 400))
+    blen = n_seg * nperseg + int(rng.integers(0, nperseg))
+    n_streams = int(rng.integers(1, 9))
+    n_buf = int(rng.integers(2, 4))
+    hop = nperseg / fs
+    min_ms = float(rng.choice([0.0, 2 * hop * 1e3, 8.0, 5.0]))
+    max_ms = float(max(min_ms + 3 * hop * 1e3, rng.choice([10.0, 40.0, 80.0])))
+    thr = float(rng.choice([-90.0, -85.0, -100.0]))
+    snr = float(rng.choice([5.0, 0.0, 8.0]))
+    cal = [float(c) for c in rng.uniform(-6, 6, n_streams)] if rng.random() < 0.5 else 0.0
+    mode = str(rng.choice(["sparse", "dense", "auto"]))
+    lanes = int(rng.choice([1, 1, 2, 3]))
+    w = oracle.window_coefficients(window, nperseg)
+    iq = []
+    for s in range(n_streams):
+        total = n_buf * blen
+        pulses = synth.random_pulses(rng, total, fs, w, int(rng.integers(2, 12)), dur_ms=(min(0.5 * max_ms, 4.0), 1.3 * max_ms),
+                                     peak_dbw=(thr - 4.0, thr + 30.0))
+        for k in range(1, n_buf):  # across a boundary, and one that ends right at a boundary
+            amp = synth.amp_for_peak_dbw(thr + 20.0, w, fs)
+            ln = int(min(0.6 * max_ms, 12.0) * 1e-3 * fs)
+            pulses.append(synth.Pulse(max(0, k * blen - ln // 2), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.1))
+            pulses.append(synth.Pulse(max(0, k * blen - ln - int(rng.integers(0, 3)) * nperseg), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.3))
+        dc = complex(2e-3, -1e-3) if rng.random() < 0.3 else 0j
+        iq.append(synth.make_stream(synth.StreamSpec(total, fs, pulses, dc=dc), 1000 * case + s))
+    iq = np.stack(iq)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_min_duration_ms=min_ms, signal_max_duration_ms=max_ms,
+              signal_threshold_dbw=thr, snr_threshold_db=snr)
+    try:
+        b = BatchSignalAnalyzer([str(i) for i in range(n_streams)], sdr_callback_length=blen, mode=mode, lanes=lanes, calibration_db=cal,
+                                record_capacity=2048, **kw)
+    except Exception as e:  # configuration refused: report, go on
+        print(f"case {case}: create failed: {e}")
+        continue
+    cals = cal if isinstance(cal, list) else [cal] * n_streams
+    oas = [oracle.OracleAnalyzer(device=str(s), calibration_db=cals[s], **kw) for s in range(n_streams)]
+    bad = 0
+    nrec = 0
+    for k in range(n_buf):
+        chunk = np.ascontiguousarray(iq[:, k * blen:(k + 1) * blen])
+        b.enqueue(chunk)
+        try:
+            rec = b.fetch_records()
+        except Exception as e:  # e.g. more records than record_capacity: not a parity question
+            print(f"case {case}: buffer {k} skipped: {e}")
+            for s in range(n_streams):
+                oas[s].process(chunk[s], TS0)  # both sides keep this buffer as their look-back
+            continue
+        for s in range(n_streams):
+            want, kept = oas[s].process(chunk[s], TS0)
+            mine = rec[rec["stream"] == s]
+            nrec += len(want)
+            got = [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine]
+            exp = [(x.fi, x.start, x.end) for x in want]
+            if got != exp:
+                # decisions that sit on float32 round-off of the powers may flip: report them, with the margin
+                bad += 1
+                extra, missing = sorted(set(got) - set(exp)), sorted(set(exp) - set(got))
+                # margin of the decisions behind the differing runs: the cells at their ends against both thresholds
+                spec = oas[s].spec_last  # [F, T] float32 of this buffer (just stored by process())
+                thr_lin = np.float32(oracle.db_to_linear(thr + cals[s]))
+                snr_lin = np.float32(oracle.db_to_linear(snr))
+                margins = []
+                for fi, st, en in (extra + missing)[:16]:
+                    avg = spec[fi].mean()
+                    lo, hi = max(0, st - 1), min(spec.shape[1], en + 2)
+                    pw = spec[fi, lo:hi]
+                    if len(pw):
+                        margins.append(float(np.minimum(np.abs(pw / thr_lin - 1), np.abs(pw / avg / snr_lin - 1)).min()))
+                m = min(margins) if margins else float("nan")
+                # float32 round-off of the powers reaches 1e-7 x (strongest cell of the segment / this cell) in amplitude:
+                # decisions closer than 2e-4 to a threshold are not decidable in float32
+                kind = "round-off margin" if m < 2e-4 else "UNEXPLAINED"
+                n_unexplained += m >= 2e-4
+                print(f"  MISMATCH ({kind}) case {case} buf {k} stream {s}: {len(got)} vs {len(exp)} records; extra {extra[:4]} missing {missing[:4]}; "
+                      f"smallest decision margin in the differing runs {m:.2e}")
+                continue
+            kept_ids = {id(x) for x in kept}
+            if [bool(r["shadowed"]) for r in mine] != [id(x) not in kept_ids for x in want]:
+                bad += 1
+                gv = [bool(r["shadowed"]) for r in mine]
+                ov = [id(x) not in kept_ids for x in want]
+                i = [a_ != b_ for a_, b_ in zip(gv, ov)].index(True)
+                xi = want[i]
+                gdb = 10 * np.log10(mine["max_p"].astype(np.float32)) - np.float32(cals[s])
+                near = []
+                for j, xj in enumerate(want):
+                    if j != i and not (xi.ts > xj.ts + xj.duration) and not (xi.ts + xi.duration < xj.ts):
+                        near.append((abs(float(xj.max) - float(xi.max)), j, float(xj.max) - float(xi.max), float(gdb[j]) - float(gdb[i])))
+                near.sort()
+                print(f"  SHADOW MISMATCH case {case} buf {k} stream {s}: record {i} (fi {xi.fi}, {xi.start}..{xi.end}) gpu shadowed={gv[i]} oracle shadowed={ov[i]}; "
+                      f"closest overlapping maxima (oracle dB difference, gpu dB difference): {[(round(d, 7), round(g_, 7)) for _, _, d, g_ in near[:3]]}")
+                continue
+            sigs = b.decoder.signals(mine, [str(i) for i in range(n_streams)], [TS0] * n_streams)
+            for g, x in zip(sigs, want):
+                ok = g.ts == x.ts and g.duration == x.duration and g.frequency == x.frequency
+                for name in ("max", "avg", "noise", "snr", "std"):
+                    a_, b_ = getattr(g, name), getattr(x, name)
+                    ok = ok and (abs(a_ - b_) < 0.1 or (np.isnan(a_) and np.isnan(b_)))  # the north_star bar
+                if not ok:
+                    bad += 1
+                    n_field += 1
+                    print(f"  FIELD MISMATCH case {case} buf {k} stream {s}: gpu max/avg/std/noise/snr {g.max} {g.avg} {g.std} {g.noise} {g.snr} vs {x}")
+                    break
+    b.close()
+    n_cases += 1
+    n_records += nrec
+    n_bad += bad
+    print(f"case {case}: N={nperseg} fs={fs} {window} T={n_seg} S={n_streams} bufs={n_buf} min/max={min_ms:.2f}/{max_ms:.1f} ms thr={thr} snr={snr} "
+          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
+print(f"SOAK: {n_cases} cases, {n_records} oracle records, {n_bad} mismatching stream-buffers "
+      f"({n_unexplained} not explained by a float32 round-off margin, {n_field} with a field beyond 0.1 dB)")

@@ -471,6 +471,47 @@ def test_degenerate_lengths():
         an.analyze_buffer(np.zeros(5000, np.complex64), gu.TS0)
 
 
+def test_lanes_stay_in_step_after_a_sparse_overflow_in_one_lane():
+    """RT_MODE_SPARSE reports a candidate-list overflow as RT_E_CAPACITY.  With lanes the call must be dropped in
+    every lane, not only in the one that overflowed: the next fetch belongs to the next enqueue in all of them
+    (found by the randomised soak, tests/perf/soak_parity.py)."""
+    _need_gpu()
+    fs, nperseg, blen = 2048000, 256, 800 * 256
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(3)
+    quiet = [synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 5, dur_ms=(9, 12), keep_clear_tail=4 * 256)), 10 + s) for s in range(4)]
+    loud = synth.make_stream(synth.StreamSpec(blen, fs, [], noise_sigma=0.1), 99)  # every cell above -90 dBW: overflows its buckets
+    kw = dict(sample_rate=fs)
+    b = _batch_for(kw, 4, blen, "sparse", lanes=2, hot_capacity=1024)
+    ref = _batch_for(kw, 4, blen, "sparse")
+    good = np.stack(quiet)
+    bad = good.copy()
+    bad[0] = loud  # lane 0 overflows, lane 1 (streams 2, 3) does not
+    ref.enqueue(good)
+    want = ref.fetch_records()
+    assert len(want) > 0
+    for _ in range(2):
+        b.enqueue(bad)
+        with pytest.raises(_native.NativeError) as e:
+            b.fetch_records()
+        assert e.value.code == _native.RT_E_CAPACITY
+        b.reset()
+        b.enqueue(good)
+        assert b.fetch_records().tobytes() == want.tobytes()
+        b.reset()
+    # two calls in flight, the first one failing: the second one's result is still the second one's
+    b.enqueue(bad)
+    b.enqueue(good)
+    with pytest.raises(_native.NativeError):
+        b.fetch_records()
+    got = b.fetch_records()
+    ref.reset()
+    ref.enqueue(good); ref.fetch_records()
+    ref.enqueue(good)
+    want2 = ref.fetch_records()  # streams 2 and 3 saw the same two buffers in both analyzers
+    assert got[got["stream"] >= 2].tobytes() == want2[want2["stream"] >= 2].tobytes()
+
+
 def test_misaligned_device_pointers_are_refused():
     """A pointer the kernels cannot load whole samples from is refused on the host (RT_E_INVALID), not
     launched: complex64 needs 8-byte alignment, uint8 I/Q pairs 2-byte alignment."""
