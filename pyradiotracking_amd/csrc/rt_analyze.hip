@@ -92,8 +92,8 @@ struct rt_handle {
     cf *d_tw1 = nullptr, *d_tw2 = nullptr;
     float *d_tail[kTails] = {nullptr, nullptr, nullptr};
     float *d_spec = nullptr;                   // lazily allocated dense spectrogram (shared)
-    void *d_iq_stage = nullptr;                // for rt_process_host
-    size_t iq_stage_bytes = 0;
+    void *d_iq_stage[kSlots] = {nullptr, nullptr};  // for rt_process_host: one per call slot (a call's IQ must stay
+    size_t iq_stage_bytes[kSlots] = {0, 0};         // in place until it is fetched -- AUTO mode may re-run it dense)
     int64_t pool_cap = 0;
     Slot slot[kSlots];
 
@@ -369,7 +369,7 @@ void rt_destroy(rt_handle *h) {
     (void)hipFree(h->d_tw2);
     for (auto &t : h->d_tail) (void)hipFree(t);
     (void)hipFree(h->d_spec);
-    (void)hipFree(h->d_iq_stage);
+    for (auto &st : h->d_iq_stage) (void)hipFree(st);
     (void)hipFree(h->d_thr_s);
     (void)hipFree(h->d_cal_s);
     for (auto &sl : h->slot) {
@@ -724,23 +724,26 @@ int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
     const size_t bytes = (size_t)h->cfg.n_streams * (size_t)stream_stride * sizeof(cf);
-    // one staging buffer: the previous call's scan must be over before it is overwritten
-    RT_HIP(h, hipStreamSynchronize(h->s_scan));
-    if (bytes > h->iq_stage_bytes) {
-        RT_HIP(h, hipDeviceSynchronize());
-        if (h->d_iq_stage) (void)hipFree(h->d_iq_stage);
-        h->d_iq_stage = nullptr;
-        h->iq_stage_bytes = 0;
-        hipError_t e = hipMalloc(&h->d_iq_stage, bytes);
+    // One staging buffer per call slot.  The call that used this slot two calls ago is over or dropped by now
+    // (at most two are in flight); the one still in flight keeps its own buffer -- it may be re-run from it
+    // when it is fetched (AUTO mode, candidate overflow), so it must not be overwritten by this call.
+    const int which = (int)(h->n_calls % kSlots);
+    Slot &prev = h->slot[which];
+    if (prev.call.seq) RT_HIP(h, hipEventSynchronize(prev.ev_done));
+    if (bytes > h->iq_stage_bytes[which]) {
+        if (h->d_iq_stage[which]) (void)hipFree(h->d_iq_stage[which]);
+        h->d_iq_stage[which] = nullptr;
+        h->iq_stage_bytes[which] = 0;
+        hipError_t e = hipMalloc(&h->d_iq_stage[which], bytes);
         if (e != hipSuccess) {
             h->err = std::string("IQ staging buffer: ") + hipGetErrorString(e);
             return RT_E_NOMEM;
         }
-        h->iq_stage_bytes = bytes;
+        h->iq_stage_bytes[which] = bytes;
     }
     // blocking copy: the caller may reuse or free its (pageable) buffer as soon as this returns
-    if (bytes) RT_HIP(h, hipMemcpy(h->d_iq_stage, iq_host, bytes, hipMemcpyHostToDevice));
-    return rt_process(h, h->d_iq_stage, n_samples, stream_stride);
+    if (bytes) RT_HIP(h, hipMemcpy(h->d_iq_stage[which], iq_host, bytes, hipMemcpyHostToDevice));
+    return rt_process(h, h->d_iq_stage[which], n_samples, stream_stride);
 }
 
 int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bins, const float *last_dev,

@@ -39,6 +39,12 @@ while time.time() < t_end:
     cal = [float(c) for c in rng.uniform(-6, 6, n_streams)] if rng.random() < 0.5 else 0.0
     mode = str(rng.choice(["sparse", "dense", "auto"]))
     lanes = int(rng.choice([1, 1, 2, 3]))
+    pipelined = bool(rng.random() < 0.4)   # enqueue buffer k + 1 before fetching buffer k
+    vary_len = bool(rng.random() < 0.3)    # shorter buffers than sdr_callback_length
+    resets = bool(rng.random() < 0.3)      # single streams restarted between buffers (rt_reset_stream)
+    u8 = bool(rng.random() < 0.2)          # RTL-SDR wire format: uint8 I/Q converted in the scan kernel's load
+    if u8:
+        thr = -70.0
     w = oracle.window_coefficients(window, nperseg)
     iq = []
     for s in range(n_streams):
@@ -65,18 +71,69 @@ while time.time() < t_end:
     oas = [oracle.OracleAnalyzer(device=str(s), calibration_db=cals[s], **kw) for s in range(n_streams)]
     bad = 0
     nrec = 0
+    # the case as a list of events, then one pass over the GPU (fetches lag one call behind the enqueues when
+    # `pipelined`: two calls in flight)
+    events = []
     for k in range(n_buf):
-        chunk = np.ascontiguousarray(iq[:, k * blen:(k + 1) * blen])
-        b.enqueue(chunk)
+        n_k = blen if not vary_len else int(rng.integers(2 * nperseg, blen + 1))
+        chunk = np.ascontiguousarray(iq[:, k * blen:k * blen + n_k])
+        raw = None
+        if u8:
+            raw = synth.quantize_u8(chunk, gain=float(rng.choice([300.0, 2000.0])))
+            chunk = synth.u8_to_complex64_like_kernel(raw)  # what the kernel makes of the bytes: the oracle's input
+        if resets and k > 0:
+            events += [("reset", s) for s in range(n_streams) if rng.random() < 0.3]
+        events.append(("buffer", chunk, raw))
+    in_flight, results = [], []
+
+    def fetch_one():
+        chunk_ = in_flight.pop(0)
         try:
-            rec = b.fetch_records()
-        except Exception as e:  # e.g. more records than record_capacity: not a parity question
-            print(f"case {case}: buffer {k} skipped: {e}")
-            for s in range(n_streams):
-                oas[s].process(chunk[s], TS0)  # both sides keep this buffer as their look-back
+            results.append(("records", b.fetch_records(), chunk_))
+        except Exception as e:
+            results.append(("skipped", str(e), chunk_))
+
+    for ev in events:
+        if ev[0] == "reset":
+            while in_flight:  # a restart takes effect with the next rt_process: settle what is in flight first
+                fetch_one()
+            b.reset_stream(ev[1])
+            results.append(("reset", ev[1]))
             continue
+        (b.enqueue_bytes(ev[2]) if u8 else b.enqueue(ev[1]))
+        in_flight.append(ev[1])
+        if len(in_flight) > (1 if pipelined else 0):
+            fetch_one()
+    while in_flight:
+        fetch_one()
+    k = -1
+    abandoned = False
+    for res in results:
+        if abandoned:
+            print(f"case {case}: rest of the case skipped (the reference raises IndexError on this ragged sequence)")
+            break
+        if res[0] == "reset":
+            oas[res[1]].reset()
+            continue
+        k += 1
+        chunk = res[2]
+        if res[0] == "skipped":  # e.g. more records than record_capacity: not a parity question
+            print(f"case {case}: buffer {k} skipped: {res[1]}")
+            try:
+                for s in range(n_streams):
+                    oas[s].process(chunk[s], TS0)  # both sides keep this buffer as their look-back
+            except IndexError:
+                abandoned = True
+            continue
+        rec = res[1]
         for s in range(n_streams):
-            want, kept = oas[s].process(chunk[s], TS0)
+            try:
+                want, kept = oas[s].process(chunk[s], TS0)
+            except IndexError:
+                # the reference indexes the CURRENT time axis with a look-back offset (analyze.py:422-423): a run reaching
+                # further back than the current buffer has columns raises there (only possible with varying buffer lengths)
+                abandoned = True
+                break
             mine = rec[rec["stream"] == s]
             nrec += len(want)
             got = [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine]
@@ -136,6 +193,6 @@ while time.time() < t_end:
     n_records += nrec
     n_bad += bad
     print(f"case {case}: N={nperseg} fs={fs} {window} T={n_seg} S={n_streams} bufs={n_buf} min/max={min_ms:.2f}/{max_ms:.1f} ms thr={thr} snr={snr} "
-          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
+          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
 print(f"SOAK: {n_cases} cases, {n_records} oracle records, {n_bad} mismatching stream-buffers "
       f"({n_unexplained} not explained by a float32 round-off margin, {n_field} with a field beyond 0.1 dB)")

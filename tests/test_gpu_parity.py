@@ -413,6 +413,33 @@ def test_pipelined_calls_match_serial():
 # ---------------------------------------------------------------------------
 # capacity handling and degenerate inputs
 # ---------------------------------------------------------------------------
+def test_pipelined_host_buffers_survive_a_dense_rerun():
+    """Two calls in flight from host memory (rt_process_host), the first one overflowing its candidate lists:
+    AUTO mode re-runs it dense when it is fetched -- from its own staged copy of the IQ, which the second call
+    must not have overwritten (found by the randomised soak: the re-run analysed the second call's samples)."""
+    _need_gpu()
+    fs, nperseg, blen = 2048000, 256, 300 * 256
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(21)
+    kw = dict(sample_rate=fs)
+    loud = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 3, dur_ms=(9, 12), peak_dbw=(-40.0, -30.0), keep_clear_tail=1024), noise_sigma=0.1), 5 + s) for s in range(2)])
+    quiet = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 4, dur_ms=(9, 12), keep_clear_tail=1024)), 50 + s) for s in range(2)])
+    serial = _batch_for(kw, 2, blen, "auto")
+    want = []
+    for buf in (loud, quiet):
+        serial.enqueue(buf)
+        want.append(serial.fetch_records())
+    assert len(want[0]) > 0 and len(want[1]) > 0 and want[0].tobytes() != want[1].tobytes()
+    piped = _batch_for(kw, 2, blen, "auto")
+    piped.enqueue(loud)
+    piped.enqueue(quiet)  # before the first call is fetched
+    got0 = piped.fetch_records()
+    assert piped.call_info().fell_back == 1
+    got1 = piped.fetch_records()
+    assert got0.tobytes() == want[0].tobytes()
+    assert got1.tobytes() == want[1].tobytes()
+
+
 def test_sparse_overflow_falls_back_to_dense():
     _need_gpu()
     meta, kwargs, buffers, ts_starts, expected = gu.iq_case("cfg2_short")
