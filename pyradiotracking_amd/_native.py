@@ -341,15 +341,17 @@ class NativeAnalyzer:
         self._check(self._lib.rt_process_host(self._handle, a.ctypes.data, a.shape[1], a.shape[1]))
 
     def fetch(self, allow_truncated: bool = False) -> np.ndarray:
+        """Records of the oldest enqueued call.  A call whose records were truncated (``RT_E_CAPACITY``) raises
+        unless ``allow_truncated``; either way it is consumed, so the next fetch belongs to the next call."""
         n = C.c_size_t(0)
-        rc = self._lib.rt_fetch(self._handle, None, 0, C.byref(n))
-        if rc != RT_OK and not (allow_truncated and rc == RT_E_CAPACITY):
+        rc = self._lib.rt_fetch(self._handle, None, 0, C.byref(n))  # size query: the call stays pending
+        if rc != RT_OK and rc != RT_E_CAPACITY:
             self._check(rc)
         out = np.zeros(n.value, dtype=RECORD_DTYPE)
         if n.value:
             rc = self._lib.rt_fetch(self._handle, out.ctypes.data, n.value, C.byref(n))
-            if rc != RT_OK and not (allow_truncated and rc == RT_E_CAPACITY):
-                self._check(rc)
+        if rc != RT_OK and not (allow_truncated and rc == RT_E_CAPACITY):
+            self._check(rc)
         return out
 
     def extract_device(self, spec_ptr: int, n_seg: int, n_bins: int, last_ptr: Optional[int], n_seg_last: int):

@@ -413,6 +413,37 @@ def test_pipelined_calls_match_serial():
 # ---------------------------------------------------------------------------
 # capacity handling and degenerate inputs
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_a_truncated_call_is_consumed(mode):
+    """More records in a stream than record_capacity: the fetch raises RT_E_CAPACITY (or hands out the truncated
+    list on request) and the call is gone -- the next fetch belongs to the next enqueue (found by the randomised
+    soak: the Python layer left the truncated call pending, every later fetch was one call behind)."""
+    _need_gpu()
+    fs, nperseg, blen = 2048000, 256, 900 * 256
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(8)
+    kw = dict(sample_rate=fs)
+    many = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 12, dur_ms=(9, 12), keep_clear_tail=1024)), 60 + s) for s in range(3)])
+    few = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 1, dur_ms=(9, 12), keep_clear_tail=1024)), 70 + s) for s in range(3)])
+    ref = _batch_for(kw, 3, blen, mode)
+    ref.enqueue(many); n_many = len(ref.fetch_records())
+    ref.enqueue(few); want_few = ref.fetch_records()
+    cap = 8
+    assert n_many > 3 * cap and 0 < len(want_few) and max(np.bincount(want_few["stream"], minlength=3)) <= cap
+    b = _batch_for(kw, 3, blen, mode, record_capacity=cap)
+    b.enqueue(many)
+    with pytest.raises(_native.NativeError) as e:
+        b.fetch_records()
+    assert e.value.code == _native.RT_E_CAPACITY
+    b.enqueue(few)
+    assert b.fetch_records().tobytes() == want_few.tobytes()
+    b.enqueue(many)
+    part = b.native.fetch(allow_truncated=True)
+    assert 0 < len(part) <= 3 * cap
+    b.enqueue(few)
+    assert b.fetch_records().tobytes() == want_few.tobytes()
+
+
 def test_pipelined_host_buffers_survive_a_dense_rerun():
     """Two calls in flight from host memory (rt_process_host), the first one overflowing its candidate lists:
     AUTO mode re-runs it dense when it is fetched -- from its own staged copy of the IQ, which the second call
