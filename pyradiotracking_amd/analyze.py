@@ -235,7 +235,19 @@ class BatchSignalAnalyzer:
         self._native.reset_stream(stream)
 
     def close(self):
+        """Destroy the native handle (waits for everything in flight), then release the staging buffers the
+        calls in flight may have been reading."""
         self._native.close()
+        for buf in getattr(self, "_u8_stage", None) or []:
+            buf.free()
+        self._u8_stage = None
+        self._held = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def call_info(self):
         """Figures of the last fetched call (with lanes: counts and times summed over the lanes' launches)."""
@@ -300,10 +312,15 @@ class BatchSignalAnalyzer:
                 a = a[None, :]
             if a.shape[0] != len(self.devices) or a.shape[1] % 2:
                 raise ValueError("expected uint8 [S, 2*B]")
-            # staged through an own device buffer, one per slot in flight (two calls may overlap)
+            if a.shape[1] // 2 > self.sdr_callback_length:
+                raise ValueError("buffer longer than sdr_callback_length")
+            # Staged through own device buffers, one per call in flight (two may overlap).  They are allocated once,
+            # for the longest buffer the handle accepts: a call's bytes must stay in place until it is fetched (AUTO
+            # mode may re-run it from them), so growing -- and freeing -- them between calls is not an option.
             bufs = getattr(self, "_u8_stage", None)
-            if bufs is None or bufs[0].nbytes < a.nbytes:
-                bufs = [_native.DeviceBuffer(self.gpu, a.nbytes), _native.DeviceBuffer(self.gpu, a.nbytes)]
+            if bufs is None:
+                nbytes = max(4, len(self.devices) * 2 * self.sdr_callback_length)
+                bufs = [_native.DeviceBuffer(self.gpu, nbytes), _native.DeviceBuffer(self.gpu, nbytes)]
                 self._u8_stage, self._u8_turn = bufs, 0
             buf = bufs[self._u8_turn]
             self._u8_turn ^= 1

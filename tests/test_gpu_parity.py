@@ -444,6 +444,38 @@ def test_a_truncated_call_is_consumed(mode):
     assert b.fetch_records().tobytes() == want_few.tobytes()
 
 
+def test_pipelined_uint8_host_buffers_of_growing_length():
+    """uint8 host buffers of different lengths, two calls in flight, the first one re-run dense when it is fetched:
+    the staged bytes of a call stay in place (and allocated) until it is fetched (found by the randomised soak: the
+    Python layer re-allocated its staging buffers when a longer buffer arrived and the re-run read freed memory)."""
+    _need_gpu()
+    fs, nperseg, blen = 2048000, 256, 500 * 256
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(33)
+    kw = dict(sample_rate=fs, signal_threshold_dbw=-100.0)
+    iq = np.stack([synth.make_stream(synth.StreamSpec(2 * blen, fs, synth.random_pulses(rng, 2 * blen, fs, w, 8, dur_ms=(9, 12), peak_dbw=(-55.0, -45.0)), noise_sigma=0.02), 80 + s) for s in range(3)])
+    raw_short = synth.quantize_u8(np.ascontiguousarray(iq[:, : 200 * 256]))
+    raw_long = synth.quantize_u8(np.ascontiguousarray(iq[:, blen:2 * blen]))
+    serial = _batch_for(kw, 3, blen, "auto", hot_capacity=256)
+    want = []
+    for k, raw in enumerate((raw_short, raw_long, raw_short)):
+        serial.enqueue_bytes(raw)
+        want.append(serial.fetch_records())
+        # 8-bit noise at this threshold: the first call overflows and re-runs dense, the following ones start dense
+        assert serial.call_info().fell_back == (1 if k == 0 else 0) and serial.call_info().mode_used == _native.RT_MODE_DENSE
+    piped = _batch_for(kw, 3, blen, "auto", hot_capacity=256)
+    piped.enqueue_bytes(raw_short)
+    piped.enqueue_bytes(raw_long)
+    got = [piped.fetch_records()]
+    piped.enqueue_bytes(raw_short)
+    got += [piped.fetch_records(), piped.fetch_records()]
+    assert len(want[1]) > 0
+    for g, x in zip(got, want):
+        assert g.tobytes() == x.tobytes()
+    with pytest.raises(ValueError):
+        piped.enqueue_bytes(np.zeros((3, 2 * blen + 2), np.uint8))
+
+
 def test_pipelined_host_buffers_survive_a_dense_rerun():
     """Two calls in flight from host memory (rt_process_host), the first one overflowing its candidate lists:
     AUTO mode re-runs it dense when it is fetched -- from its own staged copy of the IQ, which the second call
