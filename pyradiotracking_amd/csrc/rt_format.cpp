@@ -221,7 +221,8 @@ void put_json_text(std::string &o, const char *s) {
                 case '\b': o += "\\b"; break;
                 case '\f': o += "\\f"; break;
                 default:
-                    if (c < 0x20) u16(c); else o.push_back((char)c);
+                    // CPython escapes everything outside ' '..'~' (json.encoder ESCAPE_ASCII: [^\ -~]), DEL included
+                    if (c < 0x20 || c == 0x7F) u16(c); else o.push_back((char)c);
             }
             continue;
         }

@@ -134,6 +134,26 @@ def test_value_converters():
     assert json.dumps(g.as_dict, default=rtc.jsonify) == rtc.serialise("json", g).decode()
 
 
+def test_json_and_csv_of_every_ascii_character_in_a_device_name():
+    """json.dumps (ensure_ascii) escapes everything outside ' '..'~' -- control characters AND DEL (0x7f) -- and
+    csv quotes on the delimiter, the quote character and line breaks; the native formatters must agree with the
+    standard library the reference uses for each of the 127 characters (0x7f was found by tests/perf/soak_consume.py)."""
+    import csv
+    import io
+
+    from pyradiotracking_amd import Signal
+
+    ts = datetime.datetime(2024, 1, 1, 0, 0, 1, 5, tzinfo=datetime.timezone.utc)
+    for code in list(range(1, 128)) + [0xE4, 0x2028, 0x1F4E1]:
+        name = "a" + chr(code) + "b"
+        s = Signal(name, ts, 150.1e6, datetime.timedelta(milliseconds=20), -70.5, -72.25, 1.5, -100.0, 20.0)
+        assert rtc.serialise("json", s).decode("ascii") == json.dumps(s.as_dict, default=rtc.jsonify), hex(code)
+        buf = io.StringIO()
+        csv.writer(buf, dialect="excel", delimiter=";").writerow([rtc.csvify(v) for v in s.as_list])
+        assert buf.getvalue().endswith("\r\n")
+        assert rtc.serialise("csv", s).decode("utf-8") == buf.getvalue()[:-2], hex(code)  # the row without its terminator
+
+
 # ---------------------------------------------------------------------------
 # CBOR: decoded with a minimal RFC 8949 reader written for this test
 # ---------------------------------------------------------------------------
