@@ -87,3 +87,27 @@ while time.time() < t_end:
         bad += 1
         print(f"MISMATCH dev {dev!r} ts_us {ts_us} dur_us {dur_us} vals {vals}\n   got  {got[:2]}\n   want {want[:2]}", flush=True)
 print(f"SOAK CONSUME: {n} signals, {bad} mismatching payload sets (topic, JSON, CSV)")
+
+# matched groups and state messages through the same consumers
+t_end = time.time() + budget / 3
+n = bad = 0
+while time.time() < t_end:
+    n_dev = int(rng.integers(1, 9))
+    devs = ["".join(rng.choice(alphabet, size=int(rng.integers(1, 5)))) + str(i) for i in range(n_dev)]
+    rg, mg = radiotracking.MatchingSignal(devs), mine.MatchingSignal(devs)
+    for d in rng.permutation(n_dev)[: int(rng.integers(1, n_dev + 1))]:
+        ts = EPOCH + int(rng.integers(0, 4 * 10**15)) * US
+        args = (devs[d], ts, rnd_float(), int(rng.integers(0, 10**7)) * US, rnd_float(), rnd_float(), 1.0, -100.0, 10.0)
+        rg.add_member(radiotracking.Signal(*args))
+        mg.add_member(mine.Signal(*args))
+    st_args = (devs[0], EPOCH + int(rng.integers(-10**14, 4 * 10**15)) * US, int(rng.integers(0, 3)))
+    for r, m in ((rg, mg), (radiotracking.StateMessage(*st_args), mine.StateMessage(*st_args))):
+        published.clear()
+        mq.add(r)
+        got = rtc.mqtt_messages(m, prefix="st/rt")
+        want = list(published)
+        n += 1
+        if not ([g[0] for g in got] == [w[0] for w in want] and got[0][1] == want[0][1] and got[1][1] == want[1][1]):
+            bad += 1
+            print(f"MISMATCH {type(m).__name__}\n   got  {got[:2]}\n   want {want[:2]}", flush=True)
+print(f"SOAK CONSUME: {n} matched groups / state messages, {bad} mismatching payload sets")
