@@ -76,7 +76,9 @@ class _RecordDecoder:
         # element k of  arange(N/2, B - N/2 + 1, N) / float(fs)   (_spectral_py.py:2136)
         return (self.nperseg / 2 + np.asarray(k, dtype=np.float64) * self.nperseg) / float(self.sample_rate)
 
-    def decode(self, rec: np.ndarray):
+    def decode(self, rec: np.ndarray, freqs: Optional[np.ndarray] = None):
+        """Signal field columns of ``rec``; ``freqs`` replaces the analyzer's own frequency axis (caller-supplied
+        spectrograms may have any number of bins, ``extract_signals``)."""
         start = rec["start"].astype(np.int64)
         end = rec["end"].astype(np.int64)
         t_end = self.times(end)
@@ -92,7 +94,7 @@ class _RecordDecoder:
             avg_dbw = dB(rec["mean_p"]) - cal  # :444
             noise_dbw = dB(rec["row_mean"])  # :446
             snr_db = dB(rec["mean_p"] / rec["row_mean"])  # :447
-        frequency = self.freqs[rec["fi"]] + self.center_freq  # :360
+        frequency = (self.freqs if freqs is None else np.asarray(freqs))[rec["fi"]] + self.center_freq  # :360
         return t_start, duration_s, frequency, max_dbw, avg_dbw, rec["std_db"], noise_dbw, snr_db
 
     def signals(self, rec: np.ndarray, device_names: Sequence[str], ts_starts: Sequence[datetime.datetime]) -> List[Signal]:
@@ -567,7 +569,7 @@ class SignalAnalyzer:
             if d_last:
                 d_last.free()
         self._last_records = rec
-        t_start, duration_s, _f, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = self._decoder.decode(rec)
+        t_start, duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = self._decoder.decode(rec, freqs)
         out = []
         for i in range(len(rec)):
             ts = ts_start + datetime.timedelta(seconds=float(t_start[i]))
@@ -575,7 +577,7 @@ class SignalAnalyzer:
                 Signal(
                     self.device,
                     ts.astimezone(pytz.utc),
-                    freqs[rec["fi"][i]] + self.center_freq,
+                    frequency[i],
                     datetime.timedelta(seconds=float(duration_s[i])),
                     max_dbw[i],
                     avg_dbw[i],

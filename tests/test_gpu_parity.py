@@ -200,6 +200,25 @@ def test_extract_signals_on_planted_maps(i):
     assert [s in kept for s in sigs] == list(c["kept"])
 
 
+def test_extract_signals_with_more_bins_than_nperseg():
+    """extract_signals takes the frequency axis it is given: a map with more bins than the analyzer's nperseg
+    (found by tests/perf/soak_extract.py: the record decoder indexed its own 256-bin axis)."""
+    _need_gpu()
+    fs, nperseg, F, T = 2048000, 256, 700, 90
+    an = SignalAnalyzer("0", sample_rate=fs, fft_nperseg=nperseg, sdr_callback_length=4096, signal_min_duration_ms=1.0)
+    rng = np.random.default_rng(0)
+    cur = (rng.exponential(1.0, (F, T)) * 1e-12).astype(np.float32)
+    cur[650, 20:32] = 1e-7
+    cur[3, 5:18] = 2e-7
+    freqs = np.linspace(-1e6, 1e6, F)
+    times = (nperseg / 2 + np.arange(T) * nperseg) / float(fs)
+    sigs = an.extract_signals(freqs, times, cur, gu.TS0)
+    p = oracle.ExtractParams(-90.0, 5.0, 1.0, 40.0, 0.0)
+    want = oracle.records_to_signals(oracle.extract_records(times, cur, None, p), freqs, gu.TS0, "0", 150150000)
+    assert [(s.frequency, s.ts, s.duration) for s in sigs] == [(x.frequency, x.ts, x.duration) for x in want] and len(want) == 2
+    assert sigs[1].frequency == freqs[650] + 150150000
+
+
 _extract_cache = {}
 
 
