@@ -29,7 +29,7 @@ while time.time() < t_end:
     window = rng.choice(["hamming", "hann", "blackman", "boxcar"])
     n_seg = int(rng.integers(2, 400))
     blen = n_seg * nperseg + int(rng.integers(0, nperseg))
-    n_streams = int(rng.integers(1, 9))
+    n_streams = int(rng.integers(1, 9)) if rng.random() < 0.85 else int(rng.integers(9, 41))
     n_buf = int(rng.integers(2, 4))
     hop = nperseg / fs
     min_ms = float(rng.choice([0.0, 2 * hop * 1e3, 8.0, 5.0]))
@@ -45,6 +45,8 @@ while time.time() < t_end:
     u8 = bool(rng.random() < 0.2)          # RTL-SDR wire format: uint8 I/Q converted in the scan kernel's load
     if u8:
         thr = -70.0
+    dev_tensor = bool(rng.random() < 0.3)  # torch CUDA tensors (rows padded: stream_stride > n_samples) instead of host arrays
+    chunking = int(rng.choice([0, 0, 4, 8, 16]))  # segments per lane-group chunk (0 = the library's choice)
     w = oracle.window_coefficients(window, nperseg)
     iq = []
     for s in range(n_streams):
@@ -63,7 +65,7 @@ while time.time() < t_end:
               signal_threshold_dbw=thr, snr_threshold_db=snr)
     try:
         b = BatchSignalAnalyzer([str(i) for i in range(n_streams)], sdr_callback_length=blen, mode=mode, lanes=lanes, calibration_db=cal,
-                                record_capacity=2048, **kw)
+                                record_capacity=2048, segs_per_chunk=chunking, **kw)
     except Exception as e:  # configuration refused: report, go on
         print(f"case {case}: create failed: {e}")
         continue
@@ -100,7 +102,17 @@ while time.time() < t_end:
             b.reset_stream(ev[1])
             results.append(("reset", ev[1]))
             continue
-        (b.enqueue_bytes(ev[2]) if u8 else b.enqueue(ev[1]))
+        if dev_tensor:
+            import torch
+
+            pad = int(rng.integers(0, 5)) * 8
+            src = ev[2] if u8 else ev[1]
+            wide = torch.zeros((src.shape[0], src.shape[1] + (2 * pad if u8 else pad)), dtype=torch.uint8 if u8 else torch.complex64, device="cuda")
+            view = wide[:, : src.shape[1]]
+            view.copy_(torch.from_numpy(src))
+            (b.enqueue_bytes(view) if u8 else b.enqueue(view))
+        else:
+            (b.enqueue_bytes(ev[2]) if u8 else b.enqueue(ev[1]))
         in_flight.append(ev[1])
         if len(in_flight) > (1 if pipelined else 0):
             fetch_one()
@@ -193,6 +205,6 @@ while time.time() < t_end:
     n_records += nrec
     n_bad += bad
     print(f"case {case}: N={nperseg} fs={fs} {window} T={n_seg} S={n_streams} bufs={n_buf} min/max={min_ms:.2f}/{max_ms:.1f} ms thr={thr} snr={snr} "
-          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
+          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
 print(f"SOAK: {n_cases} cases, {n_records} oracle records, {n_bad} mismatching stream-buffers "
       f"({n_unexplained} not explained by a float32 round-off margin, {n_field} with a field beyond 0.1 dB)")
