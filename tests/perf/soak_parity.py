@@ -16,6 +16,7 @@ from pyradiotracking_amd import synth  # noqa: E402
 from pyradiotracking_amd.analyze import BatchSignalAnalyzer  # noqa: E402
 
 TS0 = datetime.datetime(2024, 1, 1)
+BIG = os.environ.get("SOAK_BIG") == "1"  # long buffers (1000..8000 segments), 16..128 streams, many pulses per stream
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
@@ -28,8 +29,13 @@ while time.time() < t_end:
     fs = int(rng.choice([300000, 1024000, 2048000, 2400000, 3200000]))
     window = rng.choice(["hamming", "hann", "blackman", "boxcar"])
     n_seg = int(rng.integers(2, 400))
+    if BIG:
+        nperseg = int(rng.choice([256, 256, 1024]))
+        n_seg = int(rng.integers(1000, 8001)) * 256 // nperseg
     blen = n_seg * nperseg + int(rng.integers(0, nperseg))
     n_streams = int(rng.integers(1, 9)) if rng.random() < 0.85 else int(rng.integers(9, 41))
+    if BIG:
+        n_streams = int(rng.integers(16, 129))
     n_buf = int(rng.integers(2, 4))
     hop = nperseg / fs
     min_ms = float(rng.choice([0.0, 2 * hop * 1e3, 8.0, 5.0]))
@@ -51,7 +57,7 @@ while time.time() < t_end:
     iq = []
     for s in range(n_streams):
         total = n_buf * blen
-        pulses = synth.random_pulses(rng, total, fs, w, int(rng.integers(2, 12)), dur_ms=(min(0.5 * max_ms, 4.0), 1.3 * max_ms),
+        pulses = synth.random_pulses(rng, total, fs, w, int(rng.integers(2, 12)) * (n_buf * 8 if BIG else 1), dur_ms=(min(0.5 * max_ms, 4.0), 1.3 * max_ms),
                                      peak_dbw=(thr - 4.0, thr + 30.0))
         for k in range(1, n_buf):  # across a boundary, and one that ends right at a boundary
             amp = synth.amp_for_peak_dbw(thr + 20.0, w, fs)
