@@ -134,7 +134,8 @@ int rt_reset_stream(rt_handle *h, int32_t stream);
  * on it (analyze.py:115: from_dB(signal_threshold_dbw + calibration_db)).  `threshold` and
  * `calibration_db` are HOST arrays of n_streams float32 (linear threshold; calibration in dB, used as in
  * rt_config to order maxima in the shadow filter); either may be NULL = keep rt_config's value for every
- * stream.  Applies to calls enqueued afterwards; synchronises with the calls in flight.  [SURVEY 8(f) rank 4]
+ * stream.  Applies to calls enqueued afterwards; refused (RT_E_INVALID) while unfetched calls are pending, since
+ * AUTO mode may still re-run those with the thresholds they were enqueued with.  [SURVEY 8(f) rank 4]
  */
 int rt_set_stream_params(rt_handle *h, const float *threshold, const float *calibration_db);
 

@@ -602,6 +602,11 @@ int rt_set_stream_params(rt_handle *h, const float *threshold, const float *cali
         return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
             return rt_set_stream_params(k, threshold ? threshold + s0 : nullptr, calibration_db ? calibration_db + s0 : nullptr);
         });
+    if (oldest_pending(h)) {
+        // a pending call may still be re-run when it is fetched (AUTO mode): it must see the thresholds it was enqueued with
+        h->err = "rt_set_stream_params with unfetched calls pending: fetch them first";
+        return RT_E_INVALID;
+    }
     RT_HIP(h, hipSetDevice(h->cfg.device));
     // kernels in flight read the arrays: let them finish first (a configuration call, not on the hot path)
     RT_HIP(h, hipStreamSynchronize(h->s_scan));

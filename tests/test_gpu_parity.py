@@ -954,3 +954,11 @@ def test_per_stream_calibration_and_stream_restart(mode, lanes):
         b.reset_stream(n_streams)
     with pytest.raises(ValueError):
         _batch_for(kw, n_streams, blen, mode, calibration_db=cal[:-1])
+    # thresholds cannot change under a call that is still pending (it may be re-run when it is fetched)
+    thr = np.full(n_streams, 1e-9, np.float32)
+    b.enqueue(chunk)
+    with pytest.raises(_native.NativeError):
+        b.native.set_stream_params(thr, None)
+    b.fetch_records()
+    b.native.set_stream_params(thr, None)
+    b.native.set_stream_params(None, None)
