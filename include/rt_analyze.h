@@ -163,8 +163,15 @@ int rt_process(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t stre
  */
 int rt_process_u8(rt_handle *h, const void *iq_u8_dev, int64_t n_samples, int64_t stream_stride);
 
-/* Same with IQ in host memory (copied to an internal device buffer first). */
+/*
+ * Same with IQ in host memory: copied (blocking) to an internal device buffer first -- one per call in flight, so
+ * the caller may reuse its buffer as soon as the call returns and a call's samples stay in place until it is
+ * fetched.  rt_process_u8_host takes what librtlsdr's read callback delivers (interleaved uint8 I,Q in host
+ * memory): the direct replacement of `sdr.read_samples_async(self.process_samples, ...)` + packed_bytes_to_iq
+ * (analyze.py:157) for a binding that registers a bytes callback instead.
+ */
 int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride);
+int rt_process_u8_host(rt_handle *h, const void *iq_u8_host, int64_t n_samples, int64_t stream_stride);
 
 /*
  * Wait for the OLDEST unfetched rt_process / rt_extract and copy its records, ordered by

@@ -96,6 +96,7 @@ ABI_SYMBOLS = (
     "rt_process",
     "rt_process_u8",
     "rt_process_host",
+    "rt_process_u8_host",
     "rt_fetch",
     "rt_extract",
     "rt_spectrogram",
@@ -149,6 +150,7 @@ def load_library(path: Optional[str] = None):
     lib.rt_process.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_process_u8.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_process_host.argtypes = [vp, vp, C.c_int64, C.c_int64]
+    lib.rt_process_u8_host.argtypes = [vp, vp, C.c_int64, C.c_int64]
     lib.rt_fetch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.rt_extract.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, C.c_int32]
     lib.rt_spectrogram.argtypes = [vp, vp, C.c_int64, C.c_int64, vp]
@@ -339,6 +341,15 @@ class NativeAnalyzer:
             raise ValueError(f"expected {self.n_streams} streams, got {a.shape[0]}")
         self._keep = a  # async H2D copy reads it until the fetch
         self._check(self._lib.rt_process_host(self._handle, a.ctypes.data, a.shape[1], a.shape[1]))
+
+    def process_host_u8(self, raw: np.ndarray):
+        """``[S, 2*B]`` uint8 (interleaved I, Q) in host memory; staged by the library (one buffer per call in flight)."""
+        a = np.ascontiguousarray(raw, dtype=np.uint8)
+        if a.ndim == 1:
+            a = a[None, :]
+        if a.shape[0] != self.n_streams or a.shape[1] % 2:
+            raise ValueError(f"expected uint8 [{self.n_streams}, 2*B]")
+        self._check(self._lib.rt_process_u8_host(self._handle, a.ctypes.data, a.shape[1] // 2, a.shape[1] // 2))
 
     def fetch(self, allow_truncated: bool = False) -> np.ndarray:
         """Records of the oldest enqueued call.  A call whose records were truncated (``RT_E_CAPACITY``) raises

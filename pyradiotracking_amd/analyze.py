@@ -237,12 +237,9 @@ class BatchSignalAnalyzer:
         self._native.reset_stream(stream)
 
     def close(self):
-        """Destroy the native handle (waits for everything in flight), then release the staging buffers the
+        """Destroy the native handle (waits for everything in flight), then let go of the device tensors the
         calls in flight may have been reading."""
         self._native.close()
-        for buf in getattr(self, "_u8_stage", None) or []:
-            buf.free()
-        self._u8_stage = None
         self._held = []
 
     def __del__(self):
@@ -316,18 +313,8 @@ class BatchSignalAnalyzer:
                 raise ValueError("expected uint8 [S, 2*B]")
             if a.shape[1] // 2 > self.sdr_callback_length:
                 raise ValueError("buffer longer than sdr_callback_length")
-            # Staged through own device buffers, one per call in flight (two may overlap).  They are allocated once,
-            # for the longest buffer the handle accepts: a call's bytes must stay in place until it is fetched (AUTO
-            # mode may re-run it from them), so growing -- and freeing -- them between calls is not an option.
-            bufs = getattr(self, "_u8_stage", None)
-            if bufs is None:
-                nbytes = max(4, len(self.devices) * 2 * self.sdr_callback_length)
-                bufs = [_native.DeviceBuffer(self.gpu, nbytes), _native.DeviceBuffer(self.gpu, nbytes)]
-                self._u8_stage, self._u8_turn = bufs, 0
-            buf = bufs[self._u8_turn]
-            self._u8_turn ^= 1
-            buf.upload(a)
-            self._process_device(buf.ptr, a.shape[1] // 2, a.shape[1] // 2, 2, True)
+            # staged by the library: one device buffer per call in flight, kept until the call is fetched
+            self._native.process_host_u8(a)
             return
         if raw.dim() == 1:
             raw = raw[None, :]

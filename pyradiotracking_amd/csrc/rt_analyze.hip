@@ -716,19 +716,20 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
     return RT_OK;
 }
 
-int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride) {
+static int process_host_impl(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride, bool u8) {
     if (!h) return RT_E_INVALID;
+    const size_t sample_bytes = u8 ? 2 : sizeof(cf);
     if (!h->kids.empty())
         return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
-            const char *base = iq_host ? static_cast<const char *>(iq_host) + s0 * stream_stride * (int64_t)sizeof(cf) : nullptr;
-            return rt_process_host(k, base, n_samples, stream_stride);
+            const char *base = iq_host ? static_cast<const char *>(iq_host) + s0 * stream_stride * (int64_t)sample_bytes : nullptr;
+            return process_host_impl(k, base, n_samples, stream_stride, u8);
         });
-    if (n_samples < 0 || stream_stride < n_samples) {
-        h->err = "bad n_samples/stream_stride";
+    if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples || (!iq_host && n_samples > 0)) {
+        h->err = "n_samples/stream_stride out of range for this handle, or null IQ pointer";
         return RT_E_INVALID;
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
-    const size_t bytes = (size_t)h->cfg.n_streams * (size_t)stream_stride * sizeof(cf);
+    const size_t bytes = (size_t)h->cfg.n_streams * (size_t)stream_stride * sample_bytes;
     // One staging buffer per call slot.  The call that used this slot two calls ago is over or dropped by now
     // (at most two are in flight); the one still in flight keeps its own buffer -- it may be re-run from it
     // when it is fetched (AUTO mode, candidate overflow), so it must not be overwritten by this call.
@@ -748,7 +749,15 @@ int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_
     }
     // blocking copy: the caller may reuse or free its (pageable) buffer as soon as this returns
     if (bytes) RT_HIP(h, hipMemcpy(h->d_iq_stage[which], iq_host, bytes, hipMemcpyHostToDevice));
-    return rt_process(h, h->d_iq_stage[which], n_samples, stream_stride);
+    return process_impl(h, h->d_iq_stage[which], n_samples, stream_stride, u8);
+}
+
+int rt_process_host(rt_handle *h, const void *iq_host, int64_t n_samples, int64_t stream_stride) {
+    return process_host_impl(h, iq_host, n_samples, stream_stride, false);
+}
+
+int rt_process_u8_host(rt_handle *h, const void *iq_u8_host, int64_t n_samples, int64_t stream_stride) {
+    return process_host_impl(h, iq_u8_host, n_samples, stream_stride, true);
 }
 
 int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bins, const float *last_dev,
