@@ -67,6 +67,17 @@ while time.time() < t_end:
         dc = complex(2e-3, -1e-3) if rng.random() < 0.3 else 0j
         iq.append(synth.make_stream(synth.StreamSpec(total, fs, pulses, dc=dc), 1000 * case + s))
     iq = np.stack(iq)
+    poison = os.environ.get("SOAK_POISON") == "1" and not u8 and rng.random() < 0.5
+    if poison:
+        # NaN samples (SOAK_POISON_KIND=nan, the default): a NaN segment and NaN row means in every bin, the same on both
+        # sides.  Inf / huge samples (SOAK_POISON_KIND=all) overflow inside the FFT: whether a bin ends up Inf or NaN -- and
+        # with it whether a row mean is Inf (rejects every other cell of the row) or NaN (accepts them) -- depends on the
+        # order of pocketfft's additions, so the reference itself is not a stable yardstick there; that kind only checks
+        # that nothing crashes.
+        for _ in range(int(rng.integers(1, 4))):
+            iq[int(rng.integers(0, n_streams)), int(rng.integers(0, iq.shape[1]))] = rng.choice(
+                np.array([np.nan, complex(np.nan, 1.0)] if os.environ.get("SOAK_POISON_KIND", "nan") == "nan"
+                         else [np.nan, np.inf, complex(0, -np.inf), 1e30, complex(np.nan, 1.0), 3e38], dtype=np.complex64))
     kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_min_duration_ms=min_ms, signal_max_duration_ms=max_ms,
               signal_threshold_dbw=thr, snr_threshold_db=snr)
     try:
@@ -211,6 +222,6 @@ while time.time() < t_end:
     n_records += nrec
     n_bad += bad
     print(f"case {case}: N={nperseg} fs={fs} {window} T={n_seg} S={n_streams} bufs={n_buf} min/max={min_ms:.2f}/{max_ms:.1f} ms thr={thr} snr={snr} "
-          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
+          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''}{' poisoned' if poison else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
 print(f"SOAK: {n_cases} cases, {n_records} oracle records, {n_bad} mismatching stream-buffers "
       f"({n_unexplained} not explained by a float32 round-off margin, {n_field} with a field beyond 0.1 dB)")
