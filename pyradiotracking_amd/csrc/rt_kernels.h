@@ -815,9 +815,20 @@ __device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int n) {
     const int base = *lds_base;
     if (base < 0) return;
     const float cal_db = a.cal_s ? a.cal_s[s] : a.dp.cal_db;
+    // rt::rank_and_shadow with the dBW figure of every record's maximum computed once (parked in the record's
+    // unused `reserved` word) instead of twice per pair: the shadow test is O(n^2) per stream
+    for (int i = threadIdx.x; i < n; i += blockDim.x) l.rec[i].reserved = __float_as_int(db10(l.rec[i].max_p) - cal_db);
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int rank, shadow;
-        rank_and_shadow(i, n, l.rec, l.ts_us, l.dur_us, cal_db, &rank, &shadow);
+        const int32_t fi = l.rec[i].fi, st = l.rec[i].start;
+        const float mx_i = __int_as_float(l.rec[i].reserved);
+        const long long ts_i = l.ts_us[i], dur_i = l.dur_us[i];
+        int rank = 0, shadow = 0;
+        for (int j = 0; j < n; ++j) {
+            const rt_record &rj = l.rec[j];
+            if (rj.fi < fi || (rj.fi == fi && rj.start < st)) ++rank;
+            if (shadowed_by(ts_i, dur_i, mx_i, l.ts_us[j], l.dur_us[j], __int_as_float(rj.reserved))) shadow = 1;
+        }
         rt_record out = l.rec[i];
         out.shadowed = shadow;
         out.reserved = 0;
@@ -1278,26 +1289,54 @@ __device__ __forceinline__ bool scan_dense_row_blocked(const DetectParams &p, co
     // belongs to the thread of the earlier range (which follows it past its own end).
     bool in_cont = (t_begin > 0) && cell_above(row[(int64_t)(t_begin - 1) * stride], avg, p.thr, p.snr);
     int b = -1;
+    // The predicate is evaluated for a block of 16 cells without branches into a bit mask; the run logic then
+    // only visits the cells where the mask changes (a cell-by-cell state machine cost ~100 instructions per
+    // cell and wave, mostly scalar control flow: SQ_ACTIVE_INST_ANY at the issue limit, detect_dense 1.4 ms).
+    uint32_t prev = in_cont ? 1u : 0u;  // was the cell before this block above?
     for (int t0 = t_begin; t0 < T; t0 += B) {
         float v[B];
 #pragma unroll
         for (int k = 0; k < B; ++k) v[k] = (t0 + k < T) ? row[(int64_t)(t0 + k) * stride] : 0.f;
-        bool done = false;
+        const int nv = (T - t0 < B) ? (T - t0) : B;  // valid cells of the block
+        uint32_t m = 0;
 #pragma unroll
         for (int k = 0; k < B; ++k) {
-            const int t = t0 + k;
-            if (t >= T || done) break;
-            const bool ab = cell_above(v[k], avg, p.thr, p.snr);
-            if (in_cont) {
-                if (!ab) in_cont = false;
-            } else if (ab) {
-                if (b < 0 && t < t_end) b = t;
+            const bool ab = !(v[k] < p.thr) & !(v[k] / avg < p.snr);  // == cell_above(), without the early exits
+            m |= (ab ? 1u : 0u) << k;
+        }
+        const uint32_t valid = (1u << nv) - 1u;
+        m &= valid;
+        uint32_t tr = (m ^ ((m << 1) | prev)) & valid;  // bit k: cell k differs from the cell before it
+        prev = (m >> (nv - 1)) & 1u;
+        const int kc = t_end - 1 - t0;  // the last cell of the own range (may lie in an earlier or a later block)
+        int pos = 0;
+        bool done = false;
+        for (;;) {
+            const int kt = tr ? __builtin_ctz(tr) : nv;  // next change of state, or the end of the block
+            // cells pos..kt-1 keep the state: with nothing open, the first of them at or past the end of the own
+            // range ends the scan (`t + 1 >= t_end && b < 0` of the cell-by-cell form)
+            const int chk = pos > kc ? pos : kc;
+            if (b < 0 && chk < kt) {
+                done = true;
+                break;
+            }
+            if (kt >= nv) break;
+            const int t = t0 + kt;
+            if ((m >> kt) & 1u) {
+                if (t < t_end) b = t;  // a run starts in the own range
+            } else if (in_cont) {
+                in_cont = false;  // the run that was open at t_begin (an earlier range's) ends
             } else if (b >= 0) {
                 const int rb = b;
                 b = -1;
                 on_run(rb, t, avg);
             }
-            if (t + 1 >= t_end && b < 0) done = true;  // own range finished, nothing open
+            tr &= tr - 1u;
+            pos = kt + 1;
+            if (kt >= kc && b < 0) {
+                done = true;
+                break;
+            }
         }
         if (done) break;
     }

@@ -43,7 +43,8 @@ def main():
     dev = _native.DeviceBuffer(0, S * blen * 8)
     for s in range(S):
         _native.load_library().rt_dev_upload(0, dev.ptr + s * blen * 8, base[s % 8].ctypes.data, blen * 8)
-    an = BatchSignalAnalyzer([str(i) for i in range(S)], sdr_callback_length=blen, sample_rate=fs, fft_nperseg=nperseg, mode="sparse")
+    an = BatchSignalAnalyzer([str(i) for i in range(S)], sdr_callback_length=blen, sample_rate=fs, fft_nperseg=nperseg, mode=os.environ.get("RT_PROF_MODE", "sparse"),
+                             signal_threshold_dbw=float(os.environ.get("RT_PROF_THRESHOLD_DBW", "-90")))
     for _ in range(cal):
         an.native.calibrate_read(dev.ptr, blen, blen)
     n_hot = n_rec = 0
