@@ -302,6 +302,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
     uint2 *stg = stage + (MODE == 0 ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
     constexpr int kStageLimit = kStageCap;
     int stg_n = 0;                                                    // wave-uniform fill level
+    bool gave_up = false;  // wave-uniform: a candidate list of this stream has overflowed, the call will be re-run dense
 
     const raw_t *stream_iq = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride;
     const int i_first = (MODE == 0 || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
             const uint32_t emit = (active && !halo) ? (hot | next_hot) : 0u;
-            if (__builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare
+            if (!gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare
                 // Candidates are staged per wave in LDS and flushed with ONE returned atomic per
                 // flush: an atomic per cell would stall on vmcnt(0) and drain the prefetch.
                 int need = 0;  // cells this wave emits in this step (scalar arithmetic on ballots)
@@ -570,9 +571,15 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
                         stg_n += __builtin_popcountll(m);
                     }
                 } else {
-                    // more than a staging area in one step (dense input): straight to memory
+                    // more than a staging area in one step (dense input): straight to memory -- unless one of the
+                    // stream's lists has overflowed already (count > capacity): then the call is re-run dense
+                    // (AUTO) or fails (SPARSE) whatever else is emitted, and an atomic per cell on the 16 counters
+                    // of a stream (2 M cells, ~10 ms per batch of all-hot input) would only delay that
+                    const int lane_ = threadIdx.x & 63;
+                    const uint32_t cnt = lane_ < kBuckets ? __hip_atomic_load(&p.hot_count[s * kBuckets + lane_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    gave_up = __builtin_amdgcn_ballot_w64(cnt > (uint32_t)p.hot_cap) != 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16 && !gave_up; ++r) {
                         if (emit & (1u << r)) {
                             const int bin = bin_of<R3>(lt, r);
                             const int bkt = bin & (kBuckets - 1);
