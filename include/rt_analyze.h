@@ -51,7 +51,8 @@ typedef enum rt_status {
 /* how the batch is analysed */
 typedef enum rt_mode {
     RT_MODE_AUTO = 0,   /* fused sparse path; re-runs a buffer dense when its candidate
-                           lists overflow and then stays dense for the next 16 buffers */
+                           lists overflow and then stays dense for the next 16 buffers
+                           (32, 64 ... 1024 while the sparse probes keep overflowing) */
     RT_MODE_DENSE = 1,  /* materialise the power spectrogram (any input)        */
     RT_MODE_SPARSE = 2  /* fused sparse path only; overflow -> RT_E_CAPACITY    */
 } rt_mode;

@@ -101,6 +101,7 @@ struct rt_handle {
     size_t lds_large = 0, lds_small = 0, lds_final = 0, lds_dense = 0;
 
     int dense_sticky = 0;  // AUTO mode: calls left to run dense directly after a sparse overflow
+    int sticky_len = 16;   // ... how many that is: doubles (up to 1024) while the sparse probes keep overflowing
     uint64_t n_calls = 0;  // calls enqueued so far
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
@@ -864,12 +865,15 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         RT_HIP(h, hipDeviceSynchronize());
         c.fell_back = true;
         c.mode_used = RT_MODE_DENSE;
-        h->dense_sticky = 16;
+        // stay dense for a while; every further failed probe doubles the while (a probe costs a wasted scan)
+        h->dense_sticky = h->sticky_len;
+        h->sticky_len = std::min(h->sticky_len * 2, 1024);
         int rc = enqueue_analysis(h, sl, true);
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventSynchronize(sl.ev_done));
         flags = sl.h_counters[2];
     }
+    if (c.mode_used == RT_MODE_SPARSE && !c.is_extract && !c.fell_back && c.n_seg > 0) h->sticky_len = 16;  // a sparse call went through
     if (flags & kFlagInconsistent) {
         h->err = "internal: candidate list lacks the cell preceding a run";
         if (peek) return kCallFailedInternal;

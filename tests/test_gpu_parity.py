@@ -547,6 +547,15 @@ def test_sparse_overflow_falls_back_to_dense():
     auto.fetch_records()
     info = auto.native.call_info()
     assert info.mode_used == _native.RT_MODE_DENSE and info.fell_back == 0
+    # ... 16 buffers, then a sparse probe (which overflows again here), then 32 buffers, 64, ...
+    fresh = _batch_for(kwargs, 1, blen, "auto", hot_capacity=64)
+    probes = []
+    for k in range(1 + 16 + 1 + 32 + 1 + 3):
+        fresh.enqueue(buffers[0].reshape(1, -1))
+        fresh.fetch_records()
+        if fresh.native.call_info().fell_back:
+            probes.append(k)
+    assert probes == [0, 17, 50]
 
 
 def test_dense_input_everything_above_threshold():
