@@ -513,7 +513,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         }
     for (int b = 0; b < R3; ++b)
         for (int q1 = 0; q1 < 16; ++q1) {
-            const double ang = -two_pi * (double)((b * q1) % LG) / (double)LG;
+            // W_LG^(b q1), times the phase W16^(-s q1) that undoes the column rotation s = x1_rotation(b) of exchange 1
+            // (rt_kernels.h): together W_LG^((b - s R3) q1), the exponent reduced in integers
+            const int s1 = ((16 / R3 - 2) * b) & 15;
+            const int e = (((b - s1 * R3) * q1) % LG + LG) % LG;
+            const double ang = -two_pi * (double)e / (double)LG;
             tw2[(size_t)b * 16 + q1] = cf{(float)std::cos(ang), (float)std::sin(ang)};
         }
     RT_CREATE_HIP(hipMalloc(&h->d_window, sizeof(float) * N));

@@ -172,6 +172,22 @@ __device__ __forceinline__ cf group_sum(cf v, cf *red /* [kBlock/64] LDS */) {
     return v;
 }
 
+// Exchange layouts for R3 > 1 (tools/lds_banks.py models them with the gfx950 bank rules: every ds_write_b64 and
+// ds_read_b128 of both exchanges is conflict-free; the plain [row][column] layout was 2-way conflicted on every store).
+//   exchange 1: element (a = b + R3*c, k1) goes to row k1*R3 + b, physical column (c + s1(b)) & 15 with
+//               s1(b) = (16/R3 - 2) * b.  The reader takes the row as it lies: a sequence rotated by s is a phase
+//               W16^(s*q1) on its transform, and that phase is folded into the pass-2 twiddle table (host side).
+//   exchange 2: the R3-wide column groups u of the rows of one k1 are rotated by sh(k1) = (k1*R3/8) mod (16/R3);
+//               pass 3 transforms inside the groups, so the rotation only renumbers its output registers (bin_of).
+template <int R3>
+__device__ __forceinline__ int x1_rotation(int b) {
+    return ((16 / R3 - 2) * b) & 15;
+}
+template <int R3>
+__device__ __forceinline__ int x2_rotation(int k1) {
+    return (k1 * R3 / 8) & (16 / R3 - 1);
+}
+
 // bin index of result register r in lane `lt` of a group after the last pass
 template <int R3>
 __device__ __forceinline__ int bin_of(int lt, int r) {
@@ -180,7 +196,7 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
     } else {
         constexpr int G = 16 / R3;
         const int k1 = lt / R3, qg = lt % R3;
-        const int u = r / R3, q2 = r % R3;
+        const int u = (r / R3 - x2_rotation<R3>(k1)) & (G - 1), q2 = r % R3;
         return k1 + 16 * (qg * G + u) + 256 * q2;
     }
 }
@@ -210,6 +226,35 @@ __device__ __forceinline__ cf load_iq(const cf *p) {
     return cf{v.x, v.y};
 }
 __device__ __forceinline__ iq_u8 load_iq(const iq_u8 *p) { return iq_u8{__builtin_nontemporal_load(&p->iq)}; }
+
+// Buffer loads (wave-uniform descriptor in SGPRs + one 32-bit lane offset + a scalar offset): the 16 loads of a
+// segment share ONE address VGPR.  With flat addresses hipcc keeps a 64-bit pointer per 4 KiB of immediate range
+// -- at nperseg 4096 eight register pairs recomputed in every step plus sixteen for the window, which is what
+// pushed that kernel into scratch spills.  Out-of-range lanes read zero (num_records), so no index clamping.
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+typedef float buf_f2 __attribute__((ext_vector_type(2)));
+__device__ buf_f2 raw_buffer_load_f2(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ float raw_buffer_load_f1(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ short raw_buffer_load_i16(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i16");
+
+// `base` must be wave-uniform (the descriptor lives in SGPRs)
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));  // stride 0, no swizzle
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;  // gfx9 raw buffer: DATA_FORMAT 32
+    return r;
+}
+constexpr int kAuxNT = 2;  // non-temporal
+__device__ __forceinline__ cf buf_load_iq(rsrc_t r, int voff, int soff, cf) {
+    const buf_f2 v = raw_buffer_load_f2(r, voff, soff, kAuxNT);
+    return cf{v.x, v.y};
+}
+__device__ __forceinline__ iq_u8 buf_load_iq(rsrc_t r, int voff, int soff, iq_u8) {
+    return iq_u8{(uint16_t)raw_buffer_load_i16(r, voff, soff, kAuxNT)};
+}
 
 // pyrtlsdr's packed_bytes_to_iq is (byte / 127.5) - 1 per component (in float64); here one
 // float32 fma per component, at most one float32 ulp away, then float32 like complex64 input
@@ -313,19 +358,36 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
     // idle groups / past-the-end steps read valid memory and discard it.
     const int seg_hi = T - 1;
     raw_t nxt[16];
-    {
-        int seg0 = c0 + L - i_first;
-        seg0 = seg0 < seg_hi ? seg0 : seg_hi;
+    // LG >= 64: a lane group is one or more whole waves, so the segment index is wave-uniform and the loads go
+    // through a buffer descriptor per segment (a past-the-end segment gets an empty one: its lanes read zeros,
+    // which idle groups discard).  Smaller groups share a wave with other chunks: flat loads, indices clamped.
+    constexpr bool BUF_LOADS = (LG >= 64);
+    const int chunk_u = BUF_LOADS ? __builtin_amdgcn_readfirstlane(chunk) : 0;
+    auto request_segment = [&](int seg_req) {
+        if constexpr (BUF_LOADS) {
+            const int sg = __builtin_amdgcn_readfirstlane(chunk_u * L + (seg_req - c0));  // == seg_req, in SGPRs
+#ifdef RT_EXP_ALIAS
+            const raw_t *base = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(sg & RT_EXP_ALIAS) * N;
+            const rsrc_t r = make_rsrc(base, (uint32_t)(N * sizeof(raw_t)));
+#else
+            const rsrc_t r = make_rsrc(stream_iq + (int64_t)sg * N, sg < T ? (uint32_t)(N * sizeof(raw_t)) : 0u);
+#endif
+#pragma unroll
+            for (int m = 0; m < 16; ++m) nxt[m] = buf_load_iq(r, lt * (int)sizeof(raw_t), LG * m * (int)sizeof(raw_t), raw_t{});
+        } else {
+            const int sc = seg_req < seg_hi ? seg_req : seg_hi;
 #ifdef RT_EXP_ALIAS  // diagnostic build (tools/variant.sh alias -DRT_EXP_ALIAS=63): every load hits the same 64 segments of
                      // stream 0 (L2-resident) -- the scan kernel without HBM, i.e. its arithmetic + LDS floor; a mask of
                      // 8191 keeps a whole stream (16 MB at nperseg 256: misses L2, stays in the Infinity Cache)
-        const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(seg0 & RT_EXP_ALIAS) * N + lt;
+            const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(sc & RT_EXP_ALIAS) * N + lt;
 #else
-        const raw_t *src = stream_iq + (int64_t)seg0 * N + lt;
+            const raw_t *src = stream_iq + (int64_t)sc * N + lt;
 #endif
 #pragma unroll
-        for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
-    }
+            for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
+        }
+    };
+    request_segment(c0 + L - i_first);
 
     for (int i = i_first; i <= L; ++i) {
         const int seg = c0 + L - i;
@@ -335,18 +397,18 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
         cf v[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = to_cf(nxt[m]);
-        {
-            // next step's segment (the last step re-reads its own: harmless, keeps the loop uniform)
-            int seg1 = (i < L) ? seg - 1 : seg;
-            seg1 = seg1 < seg_hi ? seg1 : seg_hi;
-#ifdef RT_EXP_ALIAS
-            const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(seg1 & RT_EXP_ALIAS) * N + lt;
-#else
-            const raw_t *src = stream_iq + (int64_t)seg1 * N + lt;
-#endif
+        // N = 4096: the window comes from L2.  Vector-memory operations return in order, so these loads must be
+        // issued BEFORE the next segment's: waiting for them afterwards (`s_waitcnt vmcnt(0)`) would wait for the
+        // whole prefetch, i.e. expose an HBM round trip in every step (it did: 1.01 ms per launch).
+        float wreg[W_IN_LDS ? 1 : 16];
+        if constexpr (!W_IN_LDS) {
+            const rsrc_t rw = make_rsrc(p.window, (uint32_t)(N * sizeof(float)));
 #pragma unroll
-            for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
+            for (int m = 0; m < 16; ++m) wreg[m] = raw_buffer_load_f1(rw, lt * 4, LG * m * 4, 0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the order of the two groups of loads
         }
+        // next step's segment (the last step re-reads its own: harmless, keeps the loop uniform)
+        request_segment((i < L) ? seg - 1 : seg);
 
         if constexpr (MODE == 3) {
             // traffic calibration: the scan's exact load stream, nothing else
@@ -373,8 +435,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             if constexpr (W_IN_LDS) {
                 w4 = w_lds[mm * LG + lt];
             } else {
-                w4 = make_float4(p.window[lt + LG * (4 * mm)], p.window[lt + LG * (4 * mm + 1)],
-                                 p.window[lt + LG * (4 * mm + 2)], p.window[lt + LG * (4 * mm + 3)]);
+                w4 = make_float4(wreg[4 * mm], wreg[4 * mm + 1], wreg[4 * mm + 2], wreg[4 * mm + 3]);
             }
             v[4 * mm + 0] = cscale(csub(v[4 * mm + 0], mean), w4.x);
             v[4 * mm + 1] = cscale(csub(v[4 * mm + 1], mean), w4.y);
@@ -416,7 +477,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
         RT_ABLATE_STOP(2)  // + pass 1 and twiddles
         // exchange 1: element (a = lt, k1) -> row k1*R3 + b, column c
         {
-            const int b = lt % R3, c = lt / R3;
+            const int b = lt % R3, c = (lt / R3 + x1_rotation<R3>(lt % R3)) & 15;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) gx[(k1 * R3 + b) * kRowF2 + c] = v[k1];
         }
@@ -447,10 +508,10 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             // rows: the rows those very lanes read in exchange 1), so wave-level ordering is enough.
             wave_sync();
             {
-                const int k1 = lt / R3, b = lt % R3;
+                const int k1 = lt / R3, b = lt % R3, sh = x2_rotation<R3>(lt / R3);
 #pragma unroll
                 for (int q1 = 0; q1 < 16; ++q1)
-                    gx[(k1 * R3 + q1 / G) * kRowF2 + (q1 % G) * R3 + b] = v[q1];
+                    gx[(k1 * R3 + q1 / G) * kRowF2 + ((q1 % G + sh) & (G - 1)) * R3 + b] = v[q1];
             }
             wave_sync();
             {
