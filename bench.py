@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: IQ MSamples/s analysed by the signal-analysis path.
 
-Workload (BASELINE.json configs[1]): per GPU, 256 synthetic complex64 streams at
-2.048 MSPS, one second each (B = 2 048 000, T = 8000), nperseg 256 hamming,
-4-8 sparse 15 ms pulses per stream, resident in HBM.  A step = one pass of the
-whole path (fused STFT/scan kernel + detect kernels + records copied to the
-host) over that batch; consecutive steps are pipelined two deep inside the
-library (scan of step i+1 overlaps detect/fetch of step i).  With N > 1 every rank analyses its own 256 streams
-(weak scaling, no data-path collective); value = samples of all ranks / max
-time over ranks.
+Default workload (BASELINE.json configs[1], "config2"): per GPU, 256 synthetic complex64
+streams at 2.048 MSPS, one second each (B = 2 048 000, T = 8000), nperseg 256 hamming,
+4-8 sparse 15 ms pulses per stream, resident in HBM; with N > 1 every rank analyses its
+own 256 streams (weak scaling).  A step = one pass of the whole path (fused STFT/scan
+kernel + detect kernels + records on the host) over the rank's batch; consecutive steps
+are pipelined two deep inside the library.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel
-(stft_scan) at 8 algorithmic bytes per IQ sample against the 8 TB/s HBM peak,
-from HIP events recorded on the launch stream around every launch of the timed
-region.  `cpu_baseline` is the oracle (port of the reference's SciPy/NumPy
-path) on this node's host cores, N = 1 only.
+``--workload config3|config4|config5`` run the other BASELINE configurations as ONE fixed
+stream population sharded over the ranks with ``shard.stream_range`` (strong scaling:
+config 4 = 32 768 streams x 524 288 samples, config 5 = 8 192 streams of tag trains at
+nperseg 4096).  A stream's content depends on (seed, global stream number) only, so the
+population -- and the total number of records, which is printed -- is the same at every N.
+
+There is no collective on the data path.  The control plane (rendezvous, barrier, the
+max-over-ranks of one double, record counts) runs over gloo at every N.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (stft_scan) at 8
+algorithmic bytes per IQ sample against the 8 TB/s HBM peak, from HIP events recorded on
+the launch stream around every launch of the timed region; `kernel_ms_isolated` is the
+same kernel in a one-lane pass after the timed region (one launch per step, nothing
+beside it).  `cpu_baseline` is the oracle (port of the reference's SciPy/NumPy path) on
+this node's host cores, N = 1 only; `parity` compares sampled streams with it.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,10 +37,15 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE = 8  # one complex64 read
-# HBM bytes per scan-kernel launch on the default workload, from the PMC passes in
-# profiles/r01_i_pmc_traffic.txt (FETCH_SIZE x 1024 / 0.51 [gfx950 half-count, calibrated on the
-# kernel's own load stream] + WRITE_SIZE x 1024).  Only quoted for that exact workload.
-PMC_TRAFFIC_DEFAULT = {"bytes_per_launch": 4456600000, "source": "profiles/r01_i_pmc_traffic.txt"}
+PMC_TRAFFIC_FILE = os.path.join(REPO, "profiles", "pmc_traffic.json")  # written by tools/profile_round.sh
+
+# BASELINE.json configs.  "streams" = per GPU (weak scaling); "total" = one population sharded over the ranks (strong)
+WORKLOADS = {
+    "config2": dict(streams=256, sample_rate=2048000, samples=2048000, nperseg=256, window="hamming", trains=False),
+    "config3": dict(total=4096, sample_rate=2400000, samples=2400000, nperseg=1024, window="hann", trains=False),
+    "config4": dict(total=32768, sample_rate=2048000, samples=524288, nperseg=256, window="hamming", trains=False),
+    "config5": dict(total=8192, sample_rate=3200000, samples=3200000, nperseg=4096, window="hamming", trains=True),
+}
 
 
 def parse():
@@ -39,11 +53,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--sample-rate", type=int, default=2048000)
-    ap.add_argument("--seconds", type=float, default=1.0, help="buffer length per stream")
-    ap.add_argument("--nperseg", type=int, default=256)
-    ap.add_argument("--window", default="hamming")
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS),
+                    help="BASELINE.json configuration; config2 (default) is weak-scaled, the others shard one fixed population")
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (makes the run weak-scaled)")
+    ap.add_argument("--total-streams", type=int, default=None, help="population size of a strong-scaled workload")
+    ap.add_argument("--sample-rate", type=int, default=None)
+    ap.add_argument("--seconds", type=float, default=None, help="buffer length per stream")
+    ap.add_argument("--nperseg", type=int, default=None)
+    ap.add_argument("--window", default=None)
     ap.add_argument("--mode", default="auto", choices=["auto", "dense", "sparse"])
     ap.add_argument("--segs-per-chunk", type=int, default=0)
     ap.add_argument("--input", default="c64", choices=["c64", "u8"],
@@ -51,7 +68,7 @@ def parse():
                          "(interleaved uint8, converted inside the scan kernel; SURVEY 8(f) rank 1)")
     ap.add_argument("--threshold-dbw", type=float, default=None,
                     help="signal_threshold_dbw (default: the reference's -90, or -80 with --input u8)")
-    ap.add_argument("--trains", action="store_true",
+    ap.add_argument("--trains", action="store_true", default=None,
                     help="BASELINE config 5 style input: 8-16 tags per stream, pulse trains 10-38 ms, period 0.1-1 s")
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed steps run once during set-up, before the W warm-up steps: the GPU's clocks need ~10 "
@@ -59,10 +76,64 @@ def parse():
     ap.add_argument("--lanes", type=int, default=2,
                     help="stream groups per GPU, each on its own handle / HIP stream (detect of one group overlaps the "
                          "scan of the other); 1 = one launch sequence per step")
+    ap.add_argument("--isolated-steps", type=int, default=50,
+                    help="steps of the one-lane pass after the timed region that measures the scan launch alone (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
-    ap.add_argument("--parity-streams", type=int, default=4)
+    ap.add_argument("--parity-streams", type=int, default=16)
     return ap.parse_args()
+
+
+def resolve_workload(args, world):
+    """-> dict(name, scaling, total (population or None), sample_rate, samples, nperseg, window, trains)"""
+    w = dict(WORKLOADS[args.workload])
+    custom = False
+    for key, val in (("sample_rate", args.sample_rate), ("nperseg", args.nperseg), ("window", args.window), ("trains", args.trains)):
+        if val is not None and val != w[key]:
+            w[key] = val
+            custom = True
+    if args.seconds is not None:
+        samples = int(round(args.seconds * w["sample_rate"]))
+        custom |= samples != w["samples"]
+        w["samples"] = samples
+    elif args.sample_rate is not None and args.workload == "config2":
+        w["samples"] = w["sample_rate"]  # one second (the reference's default callback length)
+    if args.streams is not None:  # per GPU: weak scaling
+        w.pop("total", None)
+        w["streams"] = args.streams
+    if args.total_streams is not None:
+        w.pop("streams", None)
+        w["total"] = args.total_streams
+    w["scaling"] = "strong" if "total" in w else "weak"
+    # name by geometry (the flags of tools/run_configs.sh describe BASELINE configs too)
+    by_geometry = {(v["sample_rate"], v["nperseg"], v["window"], v["samples"], v["trains"]): k for k, v in WORKLOADS.items()}
+    w["name"] = by_geometry.get((w["sample_rate"], w["nperseg"], w["window"], w["samples"], w["trains"]), "custom")
+    return w
+
+
+def sources_sha256():
+    """Hash of the kernel sources this run was built from (ties profiles/pmc_traffic.json to them)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "pyradiotracking_amd", "csrc")
+    for name in ("rt_kernels.h", "rt_analyze.hip", "rt_fft.h", "rt_core.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(default_workload, lanes):
+    """HBM bytes per scan launch from the committed PMC passes -- only for the exact workload and the exact kernel
+    sources they were measured on; otherwise null with the reason."""
+    if not default_workload:
+        return None, "PMC traffic is only on file for the default workload"
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/pmc_traffic.json missing"
+    if doc.get("sources_sha256") != sources_sha256():
+        return None, "kernel sources changed since profiles/pmc_traffic.json was measured (run tools/profile_round.sh)"
+    return int(doc["bytes_per_launch_256_streams"]) // lanes, "bytes/launch: PMC FETCH_SIZE (calibrated on the kernel's own load stream) + WRITE_SIZE on one 256-stream launch, split over the lanes; " + doc.get("source", "profiles/pmc_traffic.json")
 
 
 def main():
@@ -73,8 +144,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hook (1-GPU box): all ranks on GPU 0, control plane over gloo -- exercises the N > 1 code path
-    # (rendezvous, per-rank seeds, barrier, max-over-ranks, rank-0 print) where only one GPU exists
+    # test hook (1-GPU box): all ranks on GPU 0 -- exercises the N > 1 code path (rendezvous, sharding, barrier,
+    # max-over-ranks, rank-0 print) where only one GPU exists
     share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
@@ -86,52 +157,64 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # control plane only (a barrier, one double, record counts): gloo at every N; the data path has no collective
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from pyradiotracking_amd import synth
+    from pyradiotracking_amd import shard, synth
     from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
 
-    fs, nperseg = args.sample_rate, args.nperseg
-    blen = int(round(args.seconds * fs))
+    wl = resolve_workload(args, world)
+    fs, nperseg, blen = wl["sample_rate"], wl["nperseg"], wl["samples"]
     n_seg = blen // nperseg
-    S = args.streams
-    win = window_coefficients(args.window, nperseg)
-    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=args.window)
+    if wl["scaling"] == "strong":
+        lo, hi = shard.stream_range(rank, world, wl["total"])
+        total_streams = wl["total"]
+    else:
+        lo, hi = rank * wl["streams"], (rank + 1) * wl["streams"]
+        total_streams = wl["streams"] * world
+    S = hi - lo
+    if S < 1:
+        raise SystemExit(f"rank {rank} has no streams ({total_streams} streams over {world} ranks)")
+    win = window_coefficients(wl["window"], nperseg)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=wl["window"])
     u8 = args.input == "u8"
+    dev = f"cuda:{local_rank}"
+    seed = 1000
     if u8:
         # 8-bit front end: noise ~1.5 LSB rms, pulses 18..32 dB above the -80 dBW threshold
         kw["signal_threshold_dbw"] = -80.0
-        iq_c = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}",
-                                       noise_sigma=0.012, peak_dbw=(-62.0, -48.0))
+        iq_c = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, noise_sigma=0.012, peak_dbw=(-62.0, -48.0),
+                                       first_stream=lo)
         iq = synth.quantize_u8_device(iq_c)
         del iq_c
     else:
-        iq = synth.make_batch_device(S, blen, fs, win, seed=1000 + rank, device=f"cuda:{local_rank}", trains=args.trains)
+        iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=wl["trains"], first_stream=lo)
     if args.threshold_dbw is not None:
         kw["signal_threshold_dbw"] = args.threshold_dbw
     stream = torch.cuda.current_stream()
     torch.cuda.synchronize()  # the IQ is complete before any lane's own stream reads it
-    an = BatchSignalAnalyzer(
-        [str(i) for i in range(S)],
-        sdr_callback_length=blen,
-        gpu=local_rank,
-        mode=args.mode,
-        timing=True,
-        segs_per_chunk=args.segs_per_chunk,
-        hip_stream=stream.cuda_stream if args.lanes <= 1 else None,
-        lanes=args.lanes,
-        **kw,
-    )
+
+    def analyzer(lanes):
+        return BatchSignalAnalyzer(
+            [str(i) for i in range(lo, hi)],
+            sdr_callback_length=blen,
+            gpu=local_rank,
+            mode=args.mode,
+            timing=True,
+            segs_per_chunk=args.segs_per_chunk,
+            hip_stream=stream.cuda_stream if lanes <= 1 else None,
+            lanes=lanes,
+            **kw,
+        )
+
+    an = analyzer(args.lanes)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def run(n_steps):
+    def run(an, n_steps):
         """n_steps full steps (enqueue + fetch each).  The handle keeps two calls in flight, so
         step i+1 is enqueued before step i is fetched: its scan overlaps step i's detect kernels,
         record copy and host-side fetch.  Every step's work completes inside this function."""
@@ -150,36 +233,69 @@ def main():
             acc[2] += info.fell_back
         return rec, info, acc
 
-    run(args.settle)  # set-up: clocks to steady state (not part of the W warm-up steps, never timed)
-    rec, info, _ = run(args.warmup)
+    run(an, args.settle)  # set-up: clocks to steady state (not part of the W warm-up steps, never timed)
+    rec, info, _ = run(an, args.warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rec, info, (ms_stft, ms_detect, fell_back) = run(args.steps)
+    rec, info, (ms_stft, ms_detect, fell_back) = run(an, args.steps)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    n_records = int(len(rec))
+    n_hot = int(info.n_hot)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        c = torch.tensor([n_records, n_hot, fell_back], dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_records_total, n_hot_total, fell_back = (int(v) for v in c)
+    else:
+        n_records_total, n_hot_total = n_records, n_hot
 
-    samples_per_step_gpu = S * n_seg * nperseg  # samples actually transformed (T6)
-    total_samples = samples_per_step_gpu * world * args.steps
+    samples_per_step_rank = S * n_seg * nperseg  # samples actually transformed (T6)
+    total_samples = total_streams * n_seg * nperseg * args.steps
     value = total_samples / elapsed / 1e6
-    k_ms = ms_stft / max(1, args.steps)
-    bytes_per_sample = 2 if u8 else BYTES_PER_SAMPLE
-    achieved = samples_per_step_gpu * bytes_per_sample / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-
-    # BASELINE.json configs by their geometry (per-GPU stream counts of configs 4 and 5 are the 8-GPU shares or more)
-    config_name = {(2048000, 256, "hamming", 2048000): "config2", (2400000, 1024, "hann", 2400000): "config3",
-                   (2048000, 256, "hamming", 524288): "config4 (B = 524288)",
-                   (3200000, 4096, "hamming", 3200000): "config5"}.get((fs, nperseg, args.window, blen), "custom")
     lanes = max(1, args.lanes)
-    default_workload = (S, fs, blen, nperseg, args.window, args.segs_per_chunk, args.mode, args.input) == (256, 2048000, 2048000, 256, "hamming", 0, "auto", "c64")
-    traffic = PMC_TRAFFIC_DEFAULT["bytes_per_launch"] if default_workload else None
+    k_ms = ms_stft / max(1, args.steps) / lanes  # mean duration of one launch (rank 0's launches)
+    bytes_per_sample = 2 if u8 else BYTES_PER_SAMPLE
+    bytes_per_launch = samples_per_step_rank * bytes_per_sample // lanes
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+
+    default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw) == ("config2", 256, 0, "auto", "c64", None)
+    traffic, traffic_note = pmc_traffic(default_workload, lanes)
+
+    # parity + CPU baseline (untimed).  N = 1: the oracle on the host cores over a bounded sample (the baseline) and the
+    # records of >= 16 sampled streams against it; N > 1: every rank checks the first and last stream of its shard.
+    parity = base = None
+    if not args.no_cpu_baseline and not u8:
+        if world == 1:
+            base, parity = cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed=True)
+        else:
+            _, parity = cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed=False)
+            c = torch.tensor([parity["streams_checked"], parity["streams_mismatched"]], dtype=torch.int64)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            parity["streams_checked"], parity["streams_mismatched"] = int(c[0]), int(c[1])
+            parity["note"] = "first and last stream of every rank's shard"
+
+    # the scan launch alone: one lane, one launch per step, nothing running beside it
+    iso_ms = None
+    if args.isolated_steps > 0 and not (lanes == 1):
+        an.close()
+        del an
+        an1 = analyzer(1)
+        run(an1, max(5, args.settle))  # the CPU baseline left the GPU idle: clocks back to steady state first
+        _, _, (ms1, _, _) = run(an1, args.isolated_steps)
+        iso_ms = ms1 / args.isolated_steps
+        an1.close()
+    elif lanes == 1:
+        iso_ms = k_ms
+
+    part = (f"{total_streams} streams sharded over {world} GPU(s) ({S} on rank 0)" if wl["scaling"] == "strong"
+            else f"{S} streams/GPU")
     out = {
         "metric": "IQ MSamples/s analysed (STFT + detect + records), detected-signal parity vs CPU",
         "value": round(value, 1),
@@ -189,22 +305,25 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": wl["scaling"],
         "vs_baseline": None,
         "dtype": "f32" if not u8 else "f32 (uint8 IQ converted in the load)",
         "data": "synthetic",
         "config": {
-            "workload": f"{config_name}: {S} streams/GPU x {fs} SPS x {args.seconds:g} s {'uint8 I/Q' if u8 else 'complex64'}, nperseg {nperseg} {args.window}, {'tag trains, 8-16 tags/stream' if args.trains else '4-8 sparse 15 ms pulses/stream'}",
-            "streams_per_gpu": S,
+            "workload": f"{wl['name']}: {part} x {fs} SPS x {blen} samples {'uint8 I/Q' if u8 else 'complex64'}, nperseg {nperseg} {wl['window']}, "
+                        f"{'tag trains, 8-16 tags/stream' if wl['trains'] else '4-8 sparse 15 ms pulses/stream'}",
+            "streams_total": total_streams,
+            "streams_rank0": S,
             "samples_per_stream": blen,
             "segments_per_stream": n_seg,
             "mode": {1: "dense", 2: "sparse"}.get(info.mode_used, "?"),
             "fallbacks": fell_back,
-            "records_per_step": int(len(rec)),
-            "candidate_cells_per_step": int(info.n_hot),
-            "sharding": "streams sharded per GPU, no collective",
+            "records_per_step": n_records_total,
+            "candidate_cells_per_step": n_hot_total,
+            "sharding": "contiguous stream blocks per GPU (shard.stream_range), no collective; control plane on gloo",
             "lanes_per_gpu": args.lanes,
-            "pulse_recipe": "tag trains (config 5)" if args.trains else "4-8 pulses of 15 ms",
+            "settle_steps": args.settle,
+            "population_seed": seed,
         },
         "roofline": {
             "bound": "hbm",
@@ -213,21 +332,24 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # per launch like `achieved`: the step's bytes split evenly over its scan launches (one per lane)
-            "traffic": traffic // lanes if traffic else None,
-            "traffic_unit": "bytes/launch (PMC on one 256-stream launch, " + PMC_TRAFFIC_DEFAULT["source"] + ")" if traffic else None,
+            "traffic": traffic,
+            "traffic_note": traffic_note,
             "launches_per_step": lanes,
-            "kernel_ms": round(k_ms / lanes, 4),
-            "kernel_ms_note": "mean duration of one stft_scan launch (HIP events on its stream); with more than one lane the launches"
-                              " of different lanes run concurrently with each other's scan and detect kernels, which stretches each of them",
+            "kernel_ms": round(k_ms, 4),
+            "kernel_ms_note": "mean duration of one stft_scan launch over the timed region (HIP events on its stream); with more than one lane "
+                              "the launches of different lanes run concurrently with each other's scan and detect kernels, which stretches each of them",
+            "kernel_ms_isolated": round(iso_ms, 4) if iso_ms else None,
+            "frac_isolated": round(samples_per_step_rank * bytes_per_sample / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms else None,
+            "isolated_note": f"one launch over all {S} streams of the rank, one lane, {args.isolated_steps} steps after the timed region",
             "detect_kernel_ms": round(ms_detect / max(1, args.steps) / lanes, 4),
-            "algorithmic_bytes_per_launch": samples_per_step_gpu * bytes_per_sample // lanes,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
             "whole_path_frac": round(value * 1e6 / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
         },
     }
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not u8:
-        out["cpu_baseline"], out["parity"] = cpu_baseline(args, iq, rec, kw, blen, n_seg, nperseg)
+    if base is not None:
+        out["cpu_baseline"] = base
+    if parity is not None:
+        out["parity"] = parity
 
     if world > 1:
         dist.barrier()
@@ -236,8 +358,9 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(args, iq, rec, kw, blen, n_seg, nperseg):
-    """Oracle on the host cores over a bounded sample of the same IQ bits."""
+def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed):
+    """The oracle on the host cores over a bounded sample of the same IQ bits (``timed``), and the GPU records of the
+    sampled parity streams against it: count, bin, start, end, shadow verdict exact, the five dB figures within 0.1 dB."""
     import numpy as np
 
     from oracle import cpu_bench
@@ -246,35 +369,59 @@ def cpu_baseline(args, iq, rec, kw, blen, n_seg, nperseg):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    workers = max(1, min(cores, 64))
-    n = args.cpu_streams or min(iq.shape[0], max(2 * workers, 32))
-    host = iq[:n].cpu().numpy()
+    S = iq.shape[0]
+    if timed:
+        workers = max(1, min(cores, 64))
+        n = min(S, args.cpu_streams or max(2 * workers, 32))
+        # parity streams: first and last of the batch plus an even spread; the CPU sample = those + the next ones up to n
+        k = min(S, max(args.parity_streams, 2))
+        parity_ids = sorted({int(round(i * (S - 1) / max(1, k - 1))) for i in range(k)})
+    else:
+        workers = 2
+        parity_ids = sorted({0, S - 1})
+        n = len(parity_ids)
+    rows = list(parity_ids) + [i for i in range(S) if i not in set(parity_ids)][: max(0, n - len(parity_ids))]
+    host = iq[rows].cpu().numpy()
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(tmpdir, f"rt_bench_iq_{os.getpid()}.npy")
     np.save(path, host)
     try:
-        res = cpu_bench.run(path, n, kw, workers)
+        res = cpu_bench.run(path, len(rows), kw, workers, parity=range(len(parity_ids)))
     finally:
         os.unlink(path)
-    samples = n * n_seg * nperseg
-    per_core = n_seg * nperseg / (sum(res["per_stream_s"]) / n) / 1e6
-    base = {
-        "value": round(samples / res["wall_s"] / 1e6, 2),
-        "unit": "MSamples/s",
-        "cores": workers,
-        "kind": "port",
-        "sample": f"{n} of the {iq.shape[0]} streams (same IQ bits, {blen} samples each), one oracle process per core; "
-        f"single-core rate {per_core:.1f} MSamples/s",
-    }
-    # parity of the GPU records against the oracle on the sampled streams
+    base = None
+    if timed:
+        samples = len(rows) * n_seg * nperseg
+        per_core = n_seg * nperseg / (sum(res["per_stream_s"]) / len(rows)) / 1e6
+        base = {
+            "value": round(samples / res["wall_s"] / 1e6, 2),
+            "unit": "MSamples/s",
+            "cores": workers,
+            "kind": "port",
+            "sample": f"{len(rows)} of the {S} streams (same IQ bits, {blen} samples each), one oracle process per core; "
+            f"single-core rate {per_core:.1f} MSamples/s",
+        }
+    # the bench analyses the same resident buffer in every step: its records are those of that buffer arriving after
+    # itself (look-back live), which is what the oracle's second pass over the parity streams returns
+    dec = an.decoder
     checked = mismatched = 0
-    for s in range(min(n, max(args.parity_streams, 1))):
+    worst_db = 0.0
+    for j, s in enumerate(parity_ids):
         mine = rec[rec["stream"] == s]
-        got = [(int(r["fi"]), int(r["start"]), int(r["end"]), not bool(r["shadowed"])) for r in mine]
+        _, _, _, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = dec.decode(mine)
+        want = res["results"][j]
+        ok = [(int(r["fi"]), int(r["start"]), int(r["end"]), not bool(r["shadowed"])) for r in mine] == [w[:4] for w in want]
+        if ok:
+            for i, w in enumerate(want):
+                for got, ref in zip((max_dbw[i], avg_dbw[i], std_db[i], noise_dbw[i], snr_db[i]), w[4:]):
+                    d = 0.0 if (np.isnan(got) and np.isnan(ref)) else abs(float(got) - float(ref))
+                    worst_db = max(worst_db, d)
+                    ok &= d <= 0.1
         checked += 1
-        if got != res["results"][s]:
-            mismatched += 1
-    return base, {"streams_checked": checked, "streams_mismatched": mismatched, "fields": "count, bin, start, end, shadow verdict"}
+        mismatched += 0 if ok else 1
+    return base, {"streams_checked": checked, "streams_mismatched": mismatched, "records_checked": int(sum(len(res["results"][j]) for j in range(len(parity_ids)))),
+                  "fields": "count, bin, start, end, shadow verdict exact; max/avg/std/noise/snr within 0.1 dB", "worst_db_difference": round(worst_db, 6),
+                  "streams": "first, last and an even spread of the batch" if timed else "first and last of the shard"}
 
 
 if __name__ == "__main__":

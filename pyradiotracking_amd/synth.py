@@ -130,6 +130,9 @@ def random_pulses(
     return pulses
 
 
+NOISE_BLOCK = 64  # streams per noise generator state (blocks are aligned in GLOBAL stream numbering)
+
+
 def make_batch_device(
     n_streams: int,
     n_samples: int,
@@ -140,31 +143,42 @@ def make_batch_device(
     peak_dbw: Sequence[float] = (-80.0, -60.0),
     seed: int = 0,
     device="cuda",
-    chunk_streams: int = 64,
     noise_sigma: float = NOISE_SIGMA,
     trains: bool = False,
+    first_stream: int = 0,
 ):
-    """``[S, B]`` complex64 batch generated in device memory with torch.
+    """``[S, B]`` complex64 batch generated in device memory with torch: streams
+    ``first_stream .. first_stream + n_streams - 1`` of the population ``seed``.
 
-    Noise comes from a seeded ``torch.Generator`` on the device; pulses are
-    drawn on the host (NumPy, seeded per stream) and added on the device, a
-    pulse at a time (they are sparse).  Pulses never touch the last segment
-    of a buffer, so nothing straddles the end.
+    A stream's content depends on ``(seed, global stream number)`` only, so a population
+    sharded over ranks (``shard.stream_range``) is the same population whatever the number
+    of ranks: noise comes from a device ``torch.Generator`` re-seeded per aligned block of
+    ``NOISE_BLOCK`` global streams, pulses are drawn on the host (NumPy, seeded per global
+    stream) and added on the device, a pulse at a time (they are sparse).  Pulses never
+    touch the last segment of a buffer, so nothing straddles the end.
     """
     import torch
 
     dev = torch.device(device)
     out = torch.empty((n_streams, n_samples), dtype=torch.complex64, device=dev)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
     real_view = torch.view_as_real(out)  # [S, B, 2] float32
-    for s0 in range(0, n_streams, chunk_streams):
-        s1 = min(n_streams, s0 + chunk_streams)
-        real_view[s0:s1].normal_(0.0, noise_sigma, generator=gen)
+    g0, g1 = first_stream, first_stream + n_streams
+    for blk in range(g0 // NOISE_BLOCK, (g1 + NOISE_BLOCK - 1) // NOISE_BLOCK):
+        gen.manual_seed((int(seed) * 1000003 + blk) & 0x7FFFFFFFFFFFFFFF)
+        b0, b1 = blk * NOISE_BLOCK, (blk + 1) * NOISE_BLOCK
+        if b0 >= g0 and b1 <= g1:
+            real_view[b0 - g0 : b1 - g0].normal_(0.0, noise_sigma, generator=gen)
+        else:  # block cut by the shard boundary: generate it whole, keep the own part
+            tmp = torch.empty((NOISE_BLOCK, n_samples, 2), dtype=torch.float32, device=dev)
+            tmp.normal_(0.0, noise_sigma, generator=gen)
+            lo, hi = max(b0, g0), min(b1, g1)
+            real_view[lo - g0 : hi - g0] = tmp[lo - b0 : hi - b0]
+            del tmp
     nperseg = len(window)
     two_pi = 2.0 * math.pi
     for s in range(n_streams):
-        rng = np.random.default_rng([seed, s])
+        rng = np.random.default_rng([seed, first_stream + s])
         k = int(rng.integers(pulses_per_stream[0], pulses_per_stream[1] + 1))
         if trains:
             plist = tag_trains(rng, n_samples, sample_rate, window, peak_dbw=peak_dbw, keep_clear_tail=2 * nperseg)

@@ -44,3 +44,50 @@ def test_product_package_never_imports_the_oracle():
     at = bench.index("from oracle")
     assert bench.count("from oracle") == 1 and "import oracle" not in bench
     assert bench[:at].rsplit("\ndef ", 1)[-1].startswith("cpu_baseline(")
+
+
+def _bench_module():
+    sys.path.insert(0, REPO)
+    return importlib.import_module("bench")
+
+
+def test_bench_workloads_follow_baseline_configs():
+    """--workload picks the BASELINE.json geometry; config 2 is weak-scaled, the others shard one population."""
+    import argparse
+
+    bench = _bench_module()
+
+    def ns(**kw):
+        base = dict(workload="config2", streams=None, total_streams=None, sample_rate=None, seconds=None, nperseg=None, window=None, trains=None)
+        base.update(kw)
+        return argparse.Namespace(**base)
+
+    w = bench.resolve_workload(ns(), 1)
+    assert (w["name"], w["scaling"], w["streams"], w["samples"], w["nperseg"]) == ("config2", "weak", 256, 2048000, 256)
+    w = bench.resolve_workload(ns(workload="config4"), 8)
+    assert (w["name"], w["scaling"], w["total"], w["samples"], w["nperseg"]) == ("config4", "strong", 32768, 524288, 256)
+    w = bench.resolve_workload(ns(workload="config5"), 8)
+    assert (w["name"], w["scaling"], w["total"], w["nperseg"], w["trains"]) == ("config5", "strong", 8192, 4096, True)
+    w = bench.resolve_workload(ns(workload="config3"), 1)
+    assert (w["name"], w["total"], w["window"], w["sample_rate"]) == ("config3", 4096, "hann", 2400000)
+    # the geometry flags of tools/run_configs.sh name the same configurations (per-GPU stream counts: weak)
+    w = bench.resolve_workload(ns(streams=4096, sample_rate=2400000, nperseg=1024, window="hann"), 1)
+    assert (w["name"], w["scaling"], w["streams"], w["samples"]) == ("config3", "weak", 4096, 2400000)
+    w = bench.resolve_workload(ns(streams=32768, sample_rate=2048000, seconds=0.256), 1)
+    assert (w["name"], w["samples"]) == ("config4", 524288)
+    w = bench.resolve_workload(ns(nperseg=512), 1)
+    assert w["name"] == "custom"
+
+
+def test_pmc_traffic_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    import json
+
+    bench = _bench_module()
+    f = tmp_path / "pmc_traffic.json"
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(f))
+    assert bench.pmc_traffic(True, 2)[0] is None  # no file
+    f.write_text(json.dumps({"sources_sha256": "0" * 64, "bytes_per_launch_256_streams": 4456600000}))
+    assert bench.pmc_traffic(True, 2)[0] is None  # stale
+    f.write_text(json.dumps({"sources_sha256": bench.sources_sha256(), "bytes_per_launch_256_streams": 4456600000}))
+    assert bench.pmc_traffic(True, 2)[0] == 2228300000
+    assert bench.pmc_traffic(False, 2)[0] is None  # another workload
