@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -45,7 +45,10 @@ typedef enum rt_status {
     RT_E_CAPACITY = -5,     /* record capacity exceeded (results truncated)     */
     RT_E_ONE_SEGMENT = -6,  /* exactly one segment: the reference raises
                                IndexError there (analyze.py:354, times[1])      */
-    RT_E_NOMEM = -7
+    RT_E_NOMEM = -7,
+    RT_E_HOT_OVERFLOW = -8  /* RT_MODE_SPARSE only: a candidate list overflowed (hot_capacity); the
+                               call produced NO result and has been dropped -- unlike RT_E_CAPACITY,
+                               which hands out a truncated result                                  */
 } rt_status;
 
 /* how the batch is analysed */
@@ -54,7 +57,7 @@ typedef enum rt_mode {
                            lists overflow and then stays dense for the next 16 buffers
                            (32, 64 ... 1024 while the sparse probes keep overflowing) */
     RT_MODE_DENSE = 1,  /* materialise the power spectrogram (any input)        */
-    RT_MODE_SPARSE = 2  /* fused sparse path only; overflow -> RT_E_CAPACITY    */
+    RT_MODE_SPARSE = 2  /* fused sparse path only; overflow -> RT_E_HOT_OVERFLOW */
 } rt_mode;
 
 /*
@@ -180,7 +183,14 @@ int rt_process_u8_host(rt_handle *h, const void *iq_u8_host, int64_t n_samples, 
  * (analyze.py:357, 364).  Records carry the shadow verdict; none is removed.
  * *n_out receives the number of records available; at most `cap` are written.
  * With out == NULL (or cap == 0) and records available the call is only a size
- * query: the result stays pending until it is fetched with a buffer.
+ * query: the result stays pending until it is fetched with a buffer.  A fetch
+ * with a buffer consumes the call whatever `cap` is (records beyond `cap` are
+ * lost; with cfg.lanes > 1 in every lane alike).
+ * RT_E_CAPACITY: a stream had more than record_capacity records, the result is
+ * truncated (and still delivered).  RT_E_HOT_OVERFLOW (RT_MODE_SPARSE): no
+ * result, the call is consumed.
+ * If an rt_process fails, nothing stays enqueued for it (with lanes: in no lane),
+ * and the look-back state is the one before the call.
  */
 int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out);
 

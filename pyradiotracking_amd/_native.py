@@ -22,6 +22,7 @@ RT_E_HIP = -4
 RT_E_CAPACITY = -5
 RT_E_ONE_SEGMENT = -6
 RT_E_NOMEM = -7
+RT_E_HOT_OVERFLOW = -8  # RT_MODE_SPARSE: a candidate list overflowed, the call has no result and is consumed
 
 RT_MODE_AUTO, RT_MODE_DENSE, RT_MODE_SPARSE = 0, 1, 2
 RT_FLAG_TIMING = 1
@@ -352,15 +353,21 @@ class NativeAnalyzer:
         self._check(self._lib.rt_process_u8_host(self._handle, a.ctypes.data, a.shape[1] // 2, a.shape[1] // 2))
 
     def fetch(self, allow_truncated: bool = False) -> np.ndarray:
-        """Records of the oldest enqueued call.  A call whose records were truncated (``RT_E_CAPACITY``) raises
-        unless ``allow_truncated``; either way it is consumed, so the next fetch belongs to the next call."""
+        """Records of the oldest enqueued call.  A call whose records were truncated (``RT_E_CAPACITY``: a stream
+        had more than ``record_capacity`` records) raises unless ``allow_truncated`` -- then the truncated list is
+        returned and ``last_truncated`` is set; either way it is consumed, so the next fetch belongs to the next
+        call.  A call without any result (``RT_E_HOT_OVERFLOW``: sparse mode, candidate lists overflowed) always
+        raises: an empty array would read as "no signals"."""
         n = C.c_size_t(0)
+        self.last_truncated = False
         rc = self._lib.rt_fetch(self._handle, None, 0, C.byref(n))  # size query: the call stays pending
         if rc != RT_OK and rc != RT_E_CAPACITY:
-            self._check(rc)
+            self._check(rc)  # incl. RT_E_HOT_OVERFLOW: the library has dropped the call
         out = np.zeros(n.value, dtype=RECORD_DTYPE)
         if n.value:
             rc = self._lib.rt_fetch(self._handle, out.ctypes.data, n.value, C.byref(n))
+        if rc == RT_E_CAPACITY:
+            self.last_truncated = True
         if rc != RT_OK and not (allow_truncated and rc == RT_E_CAPACITY):
             self._check(rc)
         return out

@@ -60,6 +60,13 @@ def stft_constants(fft_window, nperseg: int, sample_rate):
     return np.ascontiguousarray(win.real, dtype=np.float32), np.float32(scale.real)
 
 
+class _Heartbeat:
+    """Stand-in for the ``multiprocessing.Value("d")`` the reference's Runner hands to every analyzer."""
+
+    def __init__(self):
+        self.value = 0.0
+
+
 class _RecordDecoder:
     """rt_record arrays -> Signal field columns (analyze.py:360, 420-449)."""
 
@@ -328,9 +335,11 @@ class BatchSignalAnalyzer:
         stride = (raw.stride(0) if raw.shape[0] > 1 else raw.shape[1]) // 2
         self._process_device(raw.data_ptr(), raw.shape[1] // 2, stride, 2, True)
 
-    def fetch_records(self) -> np.ndarray:
-        """Wait for the oldest enqueued call; structured array of ``rt_record`` ordered by stream."""
-        return self._native.fetch()
+    def fetch_records(self, allow_truncated: bool = False) -> np.ndarray:
+        """Wait for the oldest enqueued call; structured array of ``rt_record`` ordered by stream.  The reference
+        has no limit on signals per buffer; here a stream is cut off at ``record_capacity`` (default 1024) records:
+        that raises unless ``allow_truncated`` (then ``native.last_truncated`` tells)."""
+        return self._native.fetch(allow_truncated)
 
     def process_batch(self, iq, ts_starts: Union[datetime.datetime, Sequence[datetime.datetime]], filtered: bool = True):
         """One buffer per stream -> per-stream lists of ``Signal``.
@@ -411,7 +420,9 @@ class SignalAnalyzer:
         self.sdr_timeout_s = sdr_timeout_s
         self.state_update_s = state_update_s
         self.signal_queue = signal_queue
-        self.last_data_ts = last_data_ts
+        # the reference always gets a multiprocessing.Value("d") from its Runner (__main__.py:118); without one the
+        # heartbeat lives in a private holder, so that the first buffer reports STARTED and the later ones RUNNING
+        self.last_data_ts = last_data_ts if last_data_ts is not None else _Heartbeat()
         self.last_state: Optional[StateMessage] = None
         self.sdr = None  # the caller's SDR handle, if it wants cancel_read_async() on a fatal clock drift
 
@@ -451,12 +462,11 @@ class SignalAnalyzer:
         running clock, drift check.  Returns ``ts_start`` of the buffer."""
         ts_recv = datetime.datetime.now()
         buffer_len_dt = datetime.timedelta(seconds=n_samples / self.sample_rate)  # :205
-        if self.last_data_ts is None or not self.last_data_ts.value:  # :210-213
+        if not self.last_data_ts.value:  # :210-213
             self.update_state(datetime.datetime.now(), StateMessage.State.STARTED)
         else:
             self.update_state(ts_recv, StateMessage.State.RUNNING)
-        if self.last_data_ts is not None:
-            self.last_data_ts.value = datetime.datetime.timestamp(ts_recv)  # :214
+        self.last_data_ts.value = datetime.datetime.timestamp(ts_recv)  # :214
         if not self._ts:  # :218-221
             self._ts = ts_recv
         else:
@@ -515,6 +525,8 @@ class SignalAnalyzer:
         self._batch.reset()
         self._spectrogram_last = None
         self._ts = None
+        if isinstance(self.last_data_ts, _Heartbeat):
+            self.last_data_ts.value = 0.0
 
     # -- the reference's public helpers ---------------------------------------
     def consume_signal(self, signal: Signal):

@@ -53,6 +53,8 @@ struct CallCtx {
     bool is_extract = false;
     bool u8 = false;        // IQ is interleaved uint8 (RTL-SDR wire format)
     bool no_last = false;   // the slot's h_no_last flags apply (some stream was reset, rt_reset_stream)
+    // handle state before this call (restored when the call is rolled back: a later lane failed to enqueue)
+    int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0;
 };
 
 struct Slot {
@@ -257,8 +259,9 @@ int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
 }
 
 // enqueue scan + detect + readback for the call described by sl.call
-int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
+int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool *launched = nullptr) {
     const CallCtx &c = sl.call;
+    if (launched) *launched = false;
     StftParams sp = make_stft_params(h, sl, c.iq, c.stream_stride, c.n_seg, c.tail_write);
     if (sp.chunks > h->max_chunks) {
         h->err = "internal: chunk count exceeds scratch";
@@ -274,6 +277,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
         sp.spec = h->d_spec;
     }
     RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
+    if (launched) *launched = true;
     if (dense) {
         if (c.u8) launch_stft<1, true>(h, sp, blocks); else launch_stft<1>(h, sp, blocks);
     } else {
@@ -305,14 +309,39 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense) {
 
 // claim the slot of the next call; the GPU work of the call that used it last must be over
 // before its scratch is rewritten (its results, if never fetched, are dropped)
-int claim_slot(rt_handle *h, Slot **out) {
+int claim_slot(rt_handle *h, Slot **out, CallCtx *saved) {
     Slot &sl = h->slot[h->n_calls % kSlots];
     // (everything of this handle runs in order on one stream, so the slot's previous GPU work is over
     // before anything enqueued from here on starts: no event wait needed)
+    *saved = sl.call;  // put back if the new call fails before it has launched anything
     sl.call = CallCtx{};
     sl.call.seq = h->n_calls + 1;
     *out = &sl;
     return RT_OK;
+}
+
+// Undo the newest enqueued call of a (lane-less) handle: wait for its kernels, forget it, and put the
+// look-back bookkeeping back to what it was before the call.
+void rollback_newest(rt_handle *h) {
+    Slot *best = nullptr;
+    for (auto &sl : h->slot)
+        if (sl.call.pending && (!best || sl.call.seq > best->call.seq)) best = &sl;
+    if (!best || best->call.seq != h->n_calls) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipEventSynchronize(best->ev_done);
+    const CallCtx &c = best->call;
+    if (!c.is_extract) {
+        h->tail_cur = c.prev_tail_cur;
+        h->n_seg_last = c.prev_n_seg_last;
+        h->dense_sticky = c.prev_dense_sticky;
+        if (c.no_last) {
+            for (int s = 0; s < h->cfg.n_streams; ++s)
+                if (best->h_no_last[s]) h->reset_pending[(size_t)s] = 1;
+            h->any_reset_pending = true;
+        }
+    }
+    best->call = CallCtx{};
+    h->n_calls--;
 }
 
 Slot *oldest_pending(rt_handle *h) {
@@ -322,13 +351,17 @@ Slot *oldest_pending(rt_handle *h) {
     return best;
 }
 
-// forward one call to every lane; `call(kid, first stream of the kid)`; the first failure is reported
+// forward one call to every lane; `call(kid, first stream of the kid)`; the first failure is reported.
+// `enqueues`: the call enqueues work (rt_process*, rt_extract) -- when lane k fails, the lanes before it
+// are rolled back, so that no lane holds a pending call the others lack (FIFO fetches pair calls by position).
 template <class F>
-int for_each_lane(rt_handle *h, F call) {
+int for_each_lane(rt_handle *h, F call, bool enqueues = false) {
     for (size_t k = 0; k < h->kids.size(); ++k) {
         const int rc = call(h->kids[k], (int64_t)h->kid_base[k]);
         if (rc != RT_OK) {
             h->err = h->kids[k]->err;
+            if (enqueues)
+                for (size_t j = 0; j < k; ++j) rollback_newest(h->kids[j]);
             return rc;
         }
     }
@@ -649,7 +682,7 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
             const char *base = iq_dev ? static_cast<const char *>(iq_dev) + s0 * stream_stride * bytes : nullptr;
             return process_impl(k, base, n_samples, stream_stride, u8);
-        });
+        }, true);
     }
     if (!iq_dev && n_samples > 0) {
         h->err = "null IQ pointer";
@@ -672,10 +705,14 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         return RT_E_ONE_SEGMENT;
     }
     Slot *slp = nullptr;
-    int rc = claim_slot(h, &slp);
+    CallCtx saved;
+    int rc = claim_slot(h, &slp, &saved);
     if (rc != RT_OK) return rc;
     Slot &sl = *slp;
     CallCtx &c = sl.call;
+    c.prev_tail_cur = h->tail_cur;
+    c.prev_n_seg_last = h->n_seg_last;
+    c.prev_dense_sticky = h->dense_sticky;
     c.iq = iq_dev;
     c.u8 = u8;
     c.n_samples = n_samples;
@@ -711,8 +748,25 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
     } else {
-        rc = enqueue_analysis(h, sl, c.mode_used == RT_MODE_DENSE);
-        if (rc != RT_OK) return rc;
+        bool launched = false;
+        rc = enqueue_analysis(h, sl, c.mode_used == RT_MODE_DENSE, &launched);
+        if (rc != RT_OK) {
+            // nothing stays enqueued for a failed call.  Before the first launch the slot's scratch is untouched:
+            // the call it held (possibly still unfetched) is put back; afterwards its results are gone with it.
+            h->dense_sticky = c.prev_dense_sticky;
+            if (c.no_last) {
+                for (int s = 0; s < h->cfg.n_streams; ++s)
+                    if (sl.h_no_last[s]) h->reset_pending[(size_t)s] = 1;
+                h->any_reset_pending = true;
+            }
+            if (launched) {
+                (void)hipStreamSynchronize(h->s_scan);
+                sl.call = CallCtx{};
+            } else {
+                sl.call = saved;
+            }
+            return rc;
+        }
     }
     c.pending = true;
     h->n_calls++;
@@ -728,7 +782,7 @@ static int process_host_impl(rt_handle *h, const void *iq_host, int64_t n_sample
         return for_each_lane(h, [&](rt_handle *k, int64_t s0) {
             const char *base = iq_host ? static_cast<const char *>(iq_host) + s0 * stream_stride * (int64_t)sample_bytes : nullptr;
             return process_host_impl(k, base, n_samples, stream_stride, u8);
-        });
+        }, true);
     if (n_samples < 0 || n_samples > h->cfg.max_samples || stream_stride < n_samples || (!iq_host && n_samples > 0)) {
         h->err = "n_samples/stream_stride out of range for this handle, or null IQ pointer";
         return RT_E_INVALID;
@@ -773,7 +827,7 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
             const float *sp = spec_dev ? spec_dev + s0 * n_seg * n_bins : nullptr;
             const float *la = last_dev ? last_dev + s0 * n_seg_last * n_bins : nullptr;
             return rt_extract(k, sp, n_seg, n_bins, la, n_seg_last);
-        });
+        }, true);
     if (n_seg < 0 || n_bins < 1 || (n_seg > 0 && !spec_dev) || (last_dev && n_seg_last < 0)) {
         h->err = "bad spectrogram arguments";
         return RT_E_INVALID;
@@ -792,7 +846,8 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
     Slot *slp = nullptr;
-    int rc = claim_slot(h, &slp);
+    CallCtx saved;
+    int rc = claim_slot(h, &slp, &saved);
     if (rc != RT_OK) return rc;
     Slot &sl = *slp;
     CallCtx &c = sl.call;
@@ -827,7 +882,7 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
 }
 
 // peek-mode results of fetch_one: the call produced no usable result (the caller decides what happens to it)
-constexpr int kCallFailed = -100;          // -> RT_E_CAPACITY (candidate lists overflowed in sparse mode)
+constexpr int kCallFailed = -100;          // -> RT_E_HOT_OVERFLOW (candidate lists overflowed in sparse mode)
 constexpr int kCallFailedInternal = -101;  // -> RT_E_HIP
 
 // drop the oldest pending call of a handle (its GPU work is waited for first)
@@ -863,10 +918,12 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             h->err = "candidate-cell capacity exceeded (hot_capacity) in sparse mode";
             if (peek) return kCallFailed;  // the laned rt_fetch drops this call in every lane together
             c.pending = false;
-            return RT_E_CAPACITY;
+            return RT_E_HOT_OVERFLOW;
         }
-        // dense re-run of the same buffer with the same look-back state, after everything in flight
-        RT_HIP(h, hipDeviceSynchronize());
+        // dense re-run of the same buffer with the same look-back state.  Everything of this handle runs in
+        // order on its own stream, so the re-run queues up behind whatever is in flight there (a later call
+        // read the tail columns this call's sparse scan already wrote -- the re-run writes the same values);
+        // other lanes' streams are left alone.
         c.fell_back = true;
         c.mode_used = RT_MODE_DENSE;
         // stay dense for a while; every further failed probe doubles the while (a probe costs a wasted scan)
@@ -932,7 +989,7 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
         const int rc = fetch_one(k, nullptr, 0, &n, true);
         if (rc != RT_OK && rc != RT_E_CAPACITY && failed == RT_OK) {
             h->err = k->err;
-            failed = (rc == kCallFailed) ? RT_E_CAPACITY : (rc == kCallFailedInternal) ? RT_E_HIP : rc;
+            failed = (rc == kCallFailed) ? RT_E_HOT_OVERFLOW : (rc == kCallFailedInternal) ? RT_E_HIP : rc;
         }
         total += n;
     }
@@ -949,7 +1006,11 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
     size_t w = 0;
     for (size_t i = 0; i < h->kids.size(); ++i) {
         rt_handle *k = h->kids[i];
-        if (deliver) {
+        if (deliver && total && cap <= w) {
+            // the caller's buffer is full: this lane's records are lost, but the call is consumed here as in the
+            // lanes before it -- otherwise the lanes would be out of step from the next rt_fetch on
+            discard_oldest(k);
+        } else if (deliver) {
             size_t n = 0;
             const int rc = fetch_one(k, out ? out + w : nullptr, cap > w ? cap - w : 0, &n, false);
             if (rc == RT_E_CAPACITY) {

@@ -219,34 +219,68 @@ class BatchRunner:
         if host is not None and (host.ndim != 2 or host.shape[0] != n):
             raise ValueError(f"expected [{n}, B] buffers")
 
-        ts_starts: List[Optional[datetime.datetime]] = [None] * n
+        # which SDRs take part in this step (decided before anything is enqueued; the clocks move afterwards)
+        active = [bool(present[i] and st.alive) for i, st in enumerate(self.streams)]
+        resets = []
         for i, st in enumerate(self.streams):
-            if not (present[i] and st.alive):
-                st.stale = True
+            if not active[i]:
                 continue
-            n_samples = host.shape[1] if host is not None else int(per_gpu[st.gpu].shape[1])
             if st.stale:
                 # the stream missed a step: what the handle holds as "previous buffer" is not the one before
                 # this buffer, so no look-back (a gap in the samples; the reference would have hit its
                 # clock-drift exit or a restart on the way)
                 self.analyzers[st.gpu].reset_stream(st.slot)
-                st.stale = False
+                resets.append(i)
+
+        # enqueue on every GPU first (asynchronous), then collect.  If one GPU refuses its call, the calls
+        # already enqueued on the others are drained and dropped: rt_fetch is FIFO, a call left pending would
+        # pair every later step with the records of the step before it.  Nothing else has changed by then --
+        # the stream clocks and heartbeats only advance once every GPU has accepted the step.
+        enqueued = []
+        try:
+            for gpu, members in self._members.items():
+                if per_gpu is not None:
+                    self.analyzers[gpu].enqueue(per_gpu[gpu])
+                else:
+                    chunk = np.ascontiguousarray(host[members], dtype=np.complex64)
+                    for k, i in enumerate(members):
+                        if not active[i]:
+                            chunk[k] = 0  # no samples: zero power, below every threshold
+                    self.analyzers[gpu].enqueue(chunk)
+                enqueued.append(gpu)
+        except Exception:
+            for gpu in enqueued:
+                try:
+                    self.analyzers[gpu].fetch_records(allow_truncated=True)
+                except Exception as e:  # the step is lost anyway; keep draining the other GPUs
+                    logger.error(f"GPU {gpu}: dropping the enqueued step failed: {e}")
+            for i in resets:
+                self.streams[i].stale = True  # the look-back reset is repeated with the stream's next buffer
+            raise
+
+        ts_starts: List[Optional[datetime.datetime]] = [None] * n
+        for i, st in enumerate(self.streams):
+            if not active[i]:
+                st.stale = True
+                continue
+            st.stale = False
+            n_samples = host.shape[1] if host is not None else int(per_gpu[st.gpu].shape[1])
             ts_starts[i] = self._clock_head(st, n_samples, now)
 
-        # enqueue on every GPU first (asynchronous), then collect
-        for gpu, members in self._members.items():
-            if per_gpu is not None:
-                self.analyzers[gpu].enqueue(per_gpu[gpu])
-            else:
-                chunk = np.ascontiguousarray(host[members], dtype=np.complex64)
-                for k, i in enumerate(members):
-                    if ts_starts[i] is None:
-                        chunk[k] = 0  # no samples: zero power, below every threshold
-                self.analyzers[gpu].enqueue(chunk)
         n_signals = 0
+        first_error = None
         for gpu, members in self._members.items():
             an = self.analyzers[gpu]
-            rec = an.fetch_records()
+            try:
+                # the reference has no limit on signals per buffer; a stream beyond record_capacity keeps
+                # record_capacity of its signals instead of costing the whole station this step
+                rec = an.fetch_records(allow_truncated=True)
+            except Exception as e:  # every GPU is fetched whatever happens on one of them (FIFO, see above)
+                logger.error(f"GPU {gpu}: no records for this step: {e}")
+                first_error = first_error or e
+                continue
+            if getattr(getattr(an, "native", None), "last_truncated", False):
+                logger.warning(f"GPU {gpu}: a stream exceeded record_capacity; its signal list for this buffer is truncated")
             rec = rec[rec["shadowed"] == 0]
             keep = np.array([ts_starts[members[s]] is not None for s in rec["stream"]], dtype=bool)
             rec = rec[keep]
@@ -255,6 +289,8 @@ class BatchRunner:
             for sig in an.decoder.signals(rec, names, starts):
                 self._put(sig)  # analyze.py:251, 280
                 n_signals += 1
+        if first_error is not None:
+            raise first_error
         return n_signals
 
     # -- liveness (``__main__.py:153-190``) ------------------------------------------------------------

@@ -45,6 +45,18 @@ def _assert_signals_match(got, table, kept=None, got_kept=None, what=""):
         assert list(got_kept) == list(kept), f"{what}: shadow verdicts {list(got_kept)} != {list(kept)}"
 
 
+def _assert_repr_matches(got: str, want: str, what=""):
+    """``Signal(device, ts, frequency, duration, max, avg, std, noise, snr)``: the first four fields are exact by
+    construction (integers of hops through the reference's float64 expressions), the rest are float32 dB figures"""
+    assert got.startswith("Signal(") and got.endswith(")") and want.startswith("Signal(") and want.endswith(")")
+    g, w = got[7:-1].split(", "), want[7:-1].split(", ")
+    assert len(g) == len(w) == 9, f"{what}: {got} vs {want}"
+    assert g[:4] == w[:4], f"{what}: {got} vs {want}"
+    for a, b in zip(g[4:], w[4:]):
+        fa, fb = float(a), float(b)
+        assert (np.isnan(fa) and np.isnan(fb)) or abs(fa - fb) <= POWER_TOL_DB, f"{what}: {got} vs {want}"
+
+
 def _batch_for(kwargs, n_streams, max_samples, mode, **extra):
     kw = {k: v for k, v in kwargs.items() if k != "device"}
     return BatchSignalAnalyzer([str(i) for i in range(n_streams)], sdr_callback_length=max_samples, mode=mode, **kw, **extra)
@@ -120,9 +132,54 @@ def test_golden_iq_case(name, mode):
         for s, row in zip(sigs, exp["table"]):
             assert gu.us(s.ts - ts_utc) == int(row[0])
         _assert_signals_match(sigs, exp["table"], exp["kept"], rec["shadowed"] == 0, what=f"{name} b{b} {mode}")
+        # what the reference printed for these signals (repr(Signal), radiotracking/__init__.py:198-199): device,
+        # timestamp, frequency and duration to the character, the five float32 dB figures within the tolerance
+        assert len(sigs) == len(exp["reprs"])
+        for s, want in zip(sigs, exp["reprs"]):
+            _assert_repr_matches(repr(s), want, f"{name} b{b} {mode}")
+        # ... and for the ones that survive the shadow filter, i.e. what goes on the queue (analyze.py:248-251)
+        queued = [repr(s) for s, r in zip(sigs, rec) if not r["shadowed"]]
+        assert len(queued) == int(np.sum(exp["kept"]))
+        for got_r, want in zip(queued, [w for w, k in zip(exp["reprs"], exp["kept"]) if k]):
+            _assert_repr_matches(got_r, want, f"{name} b{b} {mode} (queued)")
         # the row means behind noise/snr
         for r in rec:
             assert abs(10 * np.log10(r["row_mean"] / exp["row_means"][r["fi"]])) < 1e-3
+
+
+def test_look_back_longer_than_a_shorter_current_buffer_is_a_pinned_deviation():
+    """DOCUMENTED DEVIATION.  With buffers of varying length the reference indexes the CURRENT
+    buffer's time axis with the look-back offset (``times[-start]``, /root/reference/radiotracking/analyze.py:422-423):
+    a run that reaches further back into the previous buffer than the current one has segments raises IndexError
+    there (the oracle, a line-by-line restatement, raises it too).  The kernels compute that time analytically
+    (``rt_core.h: start_time``) and return the signal: start_dt = -(|start| * hop + nperseg/2/fs), which is what the
+    reference's expression gives whenever it is defined.  This test pins both behaviours."""
+    _need_gpu()
+    fs, nperseg = 300000, 256
+    w = oracle.window_coefficients("hamming", nperseg)
+    n_prev, n_cur = 60 * nperseg, 12 * nperseg
+    # a ~13 ms tone that starts 14 segments before the end of the first buffer and ends one segment into the second
+    pulse = synth.Pulse(n_prev - 14 * nperseg - 40, 15 * nperseg + 80, 50e3, synth.amp_for_peak_dbw(-70.0, w, fs))
+    iq = synth.make_stream(synth.StreamSpec(n_prev + n_cur, fs, [pulse]), seed=3)
+    bufs = [iq[:n_prev], iq[n_prev:]]
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg)
+    oa = oracle.OracleAnalyzer(device="0", **kw)
+    assert oa.process(bufs[0], gu.TS0)[0] == []  # the run touches the end of the buffer: skipped (analyze.py:415)
+    with pytest.raises(IndexError):  # times[15] of a 12-segment buffer
+        oa.process(bufs[1], gu.TS0)
+    ts1 = gu.TS0 + datetime.timedelta(seconds=n_prev / fs)
+    for mode in ("sparse", "dense"):
+        an = SignalAnalyzer("0", sdr_callback_length=n_prev, mode=mode, **kw)
+        assert an.analyze_buffer(bufs[0], gu.TS0, filtered=False) == []
+        an._batch.enqueue(bufs[1].reshape(1, -1))
+        rec = an._batch.fetch_records()
+        assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in rec] == [(42, -15, 1), (43, -15, 1), (44, -15, 1)], mode
+        sigs = an._decoder.signals(rec, ["0"], [ts1])
+        start_dt = -((nperseg / 2 + 15 * nperseg) / float(fs))           # -times[15] on an axis that is long enough
+        dur = (nperseg / 2 + 1 * nperseg) / float(fs) - start_dt           # times[1] - start_dt  (:427)
+        for s in sigs:
+            assert s.ts == (ts1 + datetime.timedelta(seconds=start_dt)).astimezone(datetime.timezone.utc)
+            assert s.duration == datetime.timedelta(seconds=dur) == datetime.timedelta(microseconds=14507)
 
 
 def test_process_samples_queue_contract():
@@ -541,7 +598,11 @@ def test_sparse_overflow_falls_back_to_dense():
     only.enqueue(buffers[0].reshape(1, -1))
     with pytest.raises(_native.NativeError) as ei:
         only.fetch_records()
-    assert ei.value.code == _native.RT_E_CAPACITY
+    assert ei.value.code == _native.RT_E_HOT_OVERFLOW
+    with pytest.raises(_native.NativeError) as ei:  # no result is not "no signals": allow_truncated does not turn it into an empty list
+        only.enqueue(buffers[0].reshape(1, -1))
+        only.fetch_records(allow_truncated=True)
+    assert ei.value.code == _native.RT_E_HOT_OVERFLOW
     # after an overflow AUTO stays dense for a while (no sparse attempt + re-run per buffer)
     auto.enqueue(buffers[0].reshape(1, -1))
     auto.fetch_records()
@@ -590,7 +651,7 @@ def test_degenerate_lengths():
 
 
 def test_lanes_stay_in_step_after_a_sparse_overflow_in_one_lane():
-    """RT_MODE_SPARSE reports a candidate-list overflow as RT_E_CAPACITY.  With lanes the call must be dropped in
+    """RT_MODE_SPARSE reports a candidate-list overflow as RT_E_HOT_OVERFLOW.  With lanes the call must be dropped in
     every lane, not only in the one that overflowed: the next fetch belongs to the next enqueue in all of them
     (found by the randomised soak, tests/perf/soak_parity.py)."""
     _need_gpu()
@@ -612,7 +673,7 @@ def test_lanes_stay_in_step_after_a_sparse_overflow_in_one_lane():
         b.enqueue(bad)
         with pytest.raises(_native.NativeError) as e:
             b.fetch_records()
-        assert e.value.code == _native.RT_E_CAPACITY
+        assert e.value.code == _native.RT_E_HOT_OVERFLOW
         b.reset()
         b.enqueue(good)
         assert b.fetch_records().tobytes() == want.tobytes()
@@ -628,6 +689,46 @@ def test_lanes_stay_in_step_after_a_sparse_overflow_in_one_lane():
     ref.enqueue(good)
     want2 = ref.fetch_records()  # streams 2 and 3 saw the same two buffers in both analyzers
     assert got[got["stream"] >= 2].tobytes() == want2[want2["stream"] >= 2].tobytes()
+
+
+def test_lanes_stay_in_step_after_a_fetch_with_a_short_buffer():
+    """rt_fetch with a buffer consumes the call whatever `cap` is -- with lanes in EVERY lane, also in those whose
+    records no longer fit (the later lanes were left pending, and the next rt_fetch mixed the
+    records of two different rt_process calls).  Through the raw C-ABI, as a foreign binding would call it."""
+    _need_gpu()
+    import ctypes as C
+
+    fs, nperseg, blen = 2048000, 256, 800 * 256
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(5)
+    bufs = [np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 4, dur_ms=(9, 12), keep_clear_tail=4 * 256)), 30 + 10 * k + s)
+                      for s in range(4)]) for k in range(2)]
+    kw = dict(sample_rate=fs)
+    ref = _batch_for(kw, 4, blen, "sparse")
+    want = []
+    for buf in bufs:
+        ref.enqueue(buf)
+        want.append(ref.fetch_records())
+    n_lane0 = int(np.sum(want[0]["stream"] < 2))
+    assert n_lane0 > 1 and len(want[0]) > n_lane0 and len(want[1]) > 0
+    b = _batch_for(kw, 4, blen, "sparse", lanes=2)
+    lib, h = b.native._lib, b.native._handle
+    b.enqueue(bufs[0])
+    n = C.c_size_t(0)
+    for cap in (1, n_lane0, n_lane0 + 1):  # inside lane 0, exactly lane 0, one record into lane 1
+        out = np.zeros(cap, dtype=_native.RECORD_DTYPE)
+        assert lib.rt_fetch(h, out.ctypes.data, cap, C.byref(n)) == _native.RT_OK
+        assert n.value == len(want[0]) and out.tobytes() == want[0][:cap].tobytes()
+        # the call is gone in both lanes: the next fetch belongs to the next enqueue
+        b.reset()
+        b.enqueue(bufs[1])
+        ref.reset(); ref.enqueue(bufs[1])
+        assert b.fetch_records().tobytes() == ref.fetch_records().tobytes()
+        with pytest.raises(_native.NativeError):
+            b.fetch_records()  # nothing pending
+        b.reset()
+        b.enqueue(bufs[0])
+    assert b.fetch_records().tobytes() == want[0].tobytes()
 
 
 def test_misaligned_device_pointers_are_refused():

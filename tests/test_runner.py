@@ -34,13 +34,21 @@ class FakeBatch:
         self.devices, self.calibration_db, self.gpu, self.kw = list(devices), list(calibration_db), gpu, kw
         self.decoder = _RecordDecoder(fft_nperseg, sample_rate, center_freq, self.calibration_db)
         self.enqueued, self.resets, self.closed = [], [], False
+        self.pending, self.fail_enqueue, self.fail_fetch = 0, False, False
         self.next_records = np.zeros(0, dtype=_native.RECORD_DTYPE)
         FakeBatch.created.append(self)
 
     def enqueue(self, chunk):
+        if self.fail_enqueue:
+            raise RuntimeError(f"GPU {self.gpu} refuses")
         self.enqueued.append(np.array(chunk))
+        self.pending += 1
 
-    def fetch_records(self):
+    def fetch_records(self, allow_truncated=False):
+        assert self.pending > 0, "fetch without a pending call"
+        self.pending -= 1
+        if self.fail_fetch:
+            raise RuntimeError(f"GPU {self.gpu} has no result")
         return self.next_records
 
     def reset_stream(self, slot):
@@ -216,3 +224,77 @@ def test_runner_on_the_gpu_matches_per_sdr_oracles():
             assert abs(getattr(g, name) - getattr(x, name)) < 0.01
     assert q.states("1") == [("1", "STARTED"), ("1", "RUNNING"), ("1", "STOPPED"), ("1", "STARTED")]
     r.stop_analyzers()
+
+
+def test_a_failing_gpu_does_not_leave_the_station_one_step_behind():
+    """enqueue on every GPU, then fetch -- a failure on one GPU must not leave a call pending on another
+    (rt_fetch is FIFO: every later step would get the records of the step before), and a step that was never
+    enqueued must not advance the stream clocks."""
+    q = Q()
+    r = _runner(q, devices=list("abcd"), gpus=(0, 1))
+    g0, g1 = FakeBatch.created
+    buf = np.zeros((4, FS), np.complex64)
+    # (1) GPU 1 refuses the step: GPU 0's call is drained, no clock has moved, no heartbeat was sent
+    g1.fail_enqueue = True
+    with pytest.raises(RuntimeError, match="GPU 1 refuses"):
+        r.process(buf, now=T0)
+    assert g0.pending == 0 and g1.pending == 0
+    assert all(st.ts is None and st.last_data_ts == 0.0 for st in r.streams) and q.items == []
+    g1.fail_enqueue = False
+    assert r.process(buf, now=T0) == 0
+    assert q.states() == [(d, "STARTED") for d in "abcd"]
+    # (2) GPU 0 has no result for a step: GPU 1 is fetched all the same, its signals are published, then the error surfaces
+    rec = np.zeros(1, dtype=_native.RECORD_DTYPE)
+    rec["start"], rec["end"] = 5, 80
+    rec["max_p"] = rec["mean_p"] = rec["row_mean"] = 1e-8
+    g1.next_records = rec
+    g0.fail_fetch = True
+    q.items.clear()
+    with pytest.raises(RuntimeError, match="GPU 0 has no result"):
+        r.process(buf, now=T0 + 1)
+    assert g0.pending == 0 and g1.pending == 0
+    assert [m.device for m in q.items if isinstance(m, Signal)] == ["c"]
+    # (3) the next step is in step on both GPUs
+    g0.fail_fetch = False
+    q.items.clear()
+    assert r.process(buf, now=T0 + 2) == 1 and g0.pending == 0 and g1.pending == 0
+
+
+@pytest.mark.gpu
+def test_a_noisy_sdr_degrades_instead_of_aborting_the_step():
+    """Two analyzers (two logical GPUs, here both on GPU 0) with a tiny record_capacity: one SDR produces more
+    signals than fit.  The step goes through, the other SDRs' signals are complete, the noisy one keeps
+    record_capacity of its own, and the following steps are not one call behind."""
+    from pyradiotracking_amd import synth
+    from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
+
+    if _native.device_count() < 1:
+        pytest.fail("no GPU visible")
+    fs, nperseg, blen = 2048000, 256, 900 * 256
+    w = window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(21)
+
+    def stream(n_pulses, seed):
+        return synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, n_pulses, dur_ms=(9, 12), keep_clear_tail=1024)), seed)
+
+    steps = [np.stack([stream(12 if (s == 0 and k == 0) else 1, 100 + 10 * k + s) for s in range(4)]) for k in range(3)]
+
+    def run(record_capacity):
+        q = Q()
+        r = BatchRunner(device=list("abcd"), gpus=[0, 1], signal_queue=q, sdr_callback_length=blen, sample_rate=fs, fft_nperseg=nperseg,
+                        analyzer_factory=lambda devices, gpu=0, **kw: BatchSignalAnalyzer(devices, gpu=0, record_capacity=record_capacity, **kw))
+        r.start_analyzers()
+        per_step = []
+        for k, chunk in enumerate(steps):
+            q.items.clear()
+            r.process(chunk, now=T0 + k * blen / fs)
+            per_step.append([(m.device, m.ts, m.frequency, m.duration) for m in q.items if isinstance(m, Signal)])
+        r.stop_analyzers()
+        return per_step
+
+    full, small = run(1024), run(4)
+    assert len([x for x in full[0] if x[0] == "a"]) >= 2
+    assert [x for x in small[0] if x[0] != "a"] == [x for x in full[0] if x[0] != "a"]
+    # the noisy SDR keeps at most record_capacity signals (the shadow filter then sees the truncated list)
+    assert 0 < len([x for x in small[0] if x[0] == "a"]) <= 4
+    assert small[1:] == full[1:] and all(len(x) > 0 for x in full[1:])
