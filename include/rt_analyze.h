@@ -81,7 +81,7 @@ typedef struct rt_config {
     double min_duration_s;      /* signal_min_duration (analyze.py:113)                  */
     double max_duration_s;      /* signal_max_duration (analyze.py:114)                  */
     int32_t hot_capacity;       /* sparse path: candidate cells kept per (stream, bin mod 16 bucket) and call
-                                   (0 = default: one full bin row, 1024..8192)                                    */
+                                   (0 = default: one full bin row times max(1, nperseg / 1024), 1024..8192)      */
     int32_t record_capacity;    /* records kept per stream and call (0 = default 1024)   */
     int32_t segs_per_chunk;     /* segments per lane-group chunk (0 = default)           */
     int32_t flags;              /* RT_FLAG_*                                             */

@@ -498,9 +498,12 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         delete h;
         return fail_create(RT_E_UNSUPPORTED, "max_samples too large for 32-bit cell keys");
     }
-    // candidate cells per (stream, bucket): a full row of one bin fits by default
-    h->hot_cap = cfg->hot_capacity > 0 ? cfg->hot_capacity
-                                       : std::min(8192, std::max(kSmallBucket, next_pow2(std::max(h->max_seg, 1))));
+    // candidate cells per (stream, bucket): by default a full row of one bin fits, times nperseg / 1024 -- a bucket
+    // holds nperseg / 16 bins, and with 256 of them (nperseg 4096) a dozen tags per stream put several active
+    // bins into one bucket (config 5: up to ~1000 cells per bucket at 781 segments)
+    h->hot_cap = cfg->hot_capacity > 0
+                     ? cfg->hot_capacity
+                     : std::min(8192, std::max(kSmallBucket, next_pow2(std::max(h->max_seg, 1)) * std::max(1, h->N / 1024)));
     h->lds_dense = rec_lds_bytes(h->rec_cap);
     h->lds_final = rec_lds_bytes(h->rec_cap);
     {

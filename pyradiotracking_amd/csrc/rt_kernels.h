@@ -919,7 +919,7 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
 // sparse detection: one WAVE per (stream, bucket), bucket = bin & (kBuckets-1)
 // ---------------------------------------------------------------------------
 constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
-constexpr int kCandCapMax = 64;     // plateaus per (stream, bucket) and call (a.cand_cap <= this); more -> dense re-run (AUTO)
+constexpr int kCandCapMax = 64;     // plateaus a bucket wave stages in LDS before it finishes them (a.cand_cap <= this); no limit per bucket
 
 // Bitonic sort of 64*M (key, value) pairs held in registers, element i = m*64 + lane.
 // Compare-exchange distances >= 64 pair two registers of the same lane (no data
@@ -1195,6 +1195,40 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
         return cell_above(vals[i], avg[bin / kBuckets], dp.thr, dp.snr);
     };
 
+    // Statistics of the staged plateaus (the whole wave per plateau, canonical order of rt::run_stats), then
+    // hand them to the stream's unordered list (finalize_records orders and filters).  Called whenever the
+    // staging area is full and once at the end: a bucket may hold any number of plateaus (dense tag trains at
+    // nperseg 4096 put hundreds into one), only the stream's record_capacity limits them.
+    auto drain = [&](int ncand) {
+        wave_sync();
+        for (int c = 0; c < ncand; ++c) {
+            const int start = cand[c].start, off = cand[c].reserved, fi = cand[c].fi, end = cand[c].end;
+            PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
+            auto cell = [&](int k) -> float {
+                const int t = start + k;
+                return t < 0 ? prev(-t) : vals[off + t];
+            };
+            const RunStats st = run_stats_wave(end - start, cell);
+            if (lane == 0) {
+                cand[c].max_p = st.max_p;
+                cand[c].mean_p = st.mean_p;
+                cand[c].std_db = st.std_db;
+                cand[c].reserved = 0;
+            }
+        }
+        wave_sync();
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&a.raw_count[s], ncand);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        for (int c = lane; c < ncand; c += 64) {
+            if (slot + c < a.rec_cap)
+                a.raw[(int64_t)s * a.rec_cap + slot + c] = cand[c];
+            else
+                atomicOr(&a.counters[2], kFlagRecOverflow);
+        }
+        wave_sync();  // the staging area is free again
+    };
+
     // maximal runs of above-cells: a run's last cell learns the index of its first cell from
     // an inclusive prefix-max over "index if run start else -1" (64 cells per step + carry)
     int ncand = 0;       // wave-uniform
@@ -1235,65 +1269,37 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
                 keep = gate_run(dp, b, e, av, prev, &start);
             }
         }
-        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
-        if (km) {
-            if (keep) {
-                const int idx = ncand + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
-                if (idx < a.cand_cap) {
-                    rt_record r;
-                    r.stream = s;
-                    r.fi = fi;
-                    r.start = start;
-                    r.end = e;
-                    r.max_p = 0.f;
-                    r.mean_p = 0.f;
-                    r.std_db = 0.f;
-                    r.row_mean = av;
-                    r.shadowed = 0;
-                    r.reserved = first - b;  // cell t of this bin sits at vals[reserved + t]
-                    cand[idx] = r;
-                }
+        // stage the gated plateaus; when the staging area runs full, the staged ones are finished first
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
+        while (todo) {
+            if (ncand == a.cand_cap) {
+                drain(ncand);
+                ncand = 0;
             }
-            ncand += __builtin_popcountll(km);
+            const int room = a.cand_cap - ncand;
+            const bool mine = keep && ((todo >> lane) & 1ull);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0));
+            const bool now = mine && rank < room;
+            if (now) {
+                rt_record r;
+                r.stream = s;
+                r.fi = fi;
+                r.start = start;
+                r.end = e;
+                r.max_p = 0.f;
+                r.mean_p = 0.f;
+                r.std_db = 0.f;
+                r.row_mean = av;
+                r.shadowed = 0;
+                r.reserved = first - b;  // cell t of this bin sits at vals[reserved + t]
+                cand[ncand + rank] = r;
+            }
+            const unsigned long long done = __builtin_amdgcn_ballot_w64(now);
+            ncand += __builtin_popcountll(done);
+            todo &= ~done;
         }
     }
-    if (ncand == 0) return;
-    if (ncand > a.cand_cap) {
-        // more plateaus in one bucket than the wave can stage: treated like a candidate-list
-        // overflow (AUTO mode re-runs the batch dense, which has no such limit)
-        if (lane == 0) atomicOr(&a.counters[2], kFlagHotOverflow);
-        ncand = a.cand_cap;
-    }
-    wave_sync();
-
-    // statistics, the whole wave per plateau (canonical order of rt::run_stats)
-    for (int c = 0; c < ncand; ++c) {
-        const int start = cand[c].start, off = cand[c].reserved, fi = cand[c].fi, end = cand[c].end;
-        PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
-        auto cell = [&](int k) -> float {
-            const int t = start + k;
-            return t < 0 ? prev(-t) : vals[off + t];
-        };
-        const RunStats st = run_stats_wave(end - start, cell);
-        if (lane == 0) {
-            cand[c].max_p = st.max_p;
-            cand[c].mean_p = st.mean_p;
-            cand[c].std_db = st.std_db;
-            cand[c].reserved = 0;
-        }
-    }
-    wave_sync();
-
-    // hand the records to the stream's unordered list (finalize_records orders and filters)
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(&a.raw_count[s], ncand);
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    for (int c = lane; c < ncand; c += 64) {
-        if (slot + c < a.rec_cap)
-            a.raw[(int64_t)s * a.rec_cap + slot + c] = cand[c];
-        else
-            atomicOr(&a.counters[2], kFlagRecOverflow);
-    }
+    if (ncand) drain(ncand);
 }
 
 // One workgroup per stream: order the stream's records by (fi, start), shadow verdicts, publish.
