@@ -26,6 +26,7 @@ RT_E_HOT_OVERFLOW = -8  # RT_MODE_SPARSE: a candidate list overflowed, the call 
 
 RT_MODE_AUTO, RT_MODE_DENSE, RT_MODE_SPARSE = 0, 1, 2
 RT_FLAG_TIMING = 1
+RT_FLAG_NO_LIN_DETREND = 2  # subtract the segment mean before windowing even for hamming / hann / boxcar windows
 
 SUPPORTED_NPERSEG = (256, 512, 1024, 2048, 4096)
 
@@ -252,6 +253,7 @@ class NativeAnalyzer:
         timing: bool = False,
         hip_stream: Optional[int] = None,
         lanes: int = 1,
+        subtract_first: bool = False,
     ):
         self._lib = load_library()
         self._handle = C.c_void_p()
@@ -275,7 +277,7 @@ class NativeAnalyzer:
         cfg.hot_capacity = hot_capacity
         cfg.record_capacity = record_capacity
         cfg.segs_per_chunk = segs_per_chunk
-        cfg.flags = RT_FLAG_TIMING if timing else 0
+        cfg.flags = (RT_FLAG_TIMING if timing else 0) | (RT_FLAG_NO_LIN_DETREND if subtract_first else 0)
         cfg.hip_stream = hip_stream
         cfg.lanes = int(lanes)
         rc = self._lib.rt_create(C.byref(cfg), C.byref(self._handle))

@@ -157,9 +157,14 @@ class BatchSignalAnalyzer:
         timing: bool = False,
         hip_stream: Optional[int] = None,
         lanes: int = 1,
+        subtract_first: bool = False,
         **kwargs,
     ):
-        """``lanes`` > 1 (``rt_config.lanes``) splits the streams into that many contiguous groups, each
+        """``subtract_first``: apply SciPy's ``detrend='constant'`` in SciPy's order (segment mean subtracted before
+        the window) even for hamming / hann / boxcar windows, where the kernels by default subtract ``mean * FFT(window)``
+        from the three bins it touches instead (equal within float32 round-off, fewer operations).
+
+        ``lanes`` > 1 (``rt_config.lanes``) splits the streams into that many contiguous groups, each
         analysed on its own HIP stream: the detection kernels and launch gaps of one group then overlap the
         scan of another (config 2: +14 % whole-path throughput with two lanes).  Streams are independent,
         so the records are the same; ``rt_fetch`` returns them in stream order.  Needs ``hip_stream=None``.
@@ -211,6 +216,7 @@ class BatchSignalAnalyzer:
             timing=timing,
             hip_stream=hip_stream,
             lanes=max(1, int(lanes)),
+            subtract_first=bool(subtract_first),
         )
         if per_stream_cal is not None:
             self.calibration_db = per_stream_cal

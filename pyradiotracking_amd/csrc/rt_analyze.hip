@@ -102,6 +102,9 @@ struct rt_handle {
     int hot_cap = 8192, rec_cap = 1024, cand_cap = 32;
     size_t lds_large = 0, lds_small = 0, lds_final = 0, lds_dense = 0;
 
+    bool lin = false;      // constant detrend by linearity (cosine-sum window of order <= 1; rt_kernels.h: LIN)
+    float lin_c[3] = {0.f, 0.f, 0.f};
+
     int dense_sticky = 0;  // AUTO mode: calls left to run dense directly after a sparse overflow
     int sticky_len = 16;   // ... how many that is: doubles (up to 1024) while the sparse probes keep overflowing
     uint64_t n_calls = 0;  // calls enqueued so far
@@ -144,15 +147,24 @@ int next_pow2(int v) {
     return p;
 }
 
+template <int MODE, bool U8, bool LIN>
+void launch_stft_lin(rt_handle *h, const StftParams &p, int blocks) {
+    switch (h->R3) {
+        case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        default: hipLaunchKernelGGL((stft_scan<16, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+    }
+}
+
+// MODE 3 (load stream only) has no detrend: one instantiation
 template <int MODE, bool U8 = false>
 void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
-    switch (h->R3) {
-        case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        default: hipLaunchKernelGGL((stft_scan<16, MODE, U8>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-    }
+    if (h->lin && MODE != 3)
+        launch_stft_lin<MODE, U8, (MODE != 3)>(h, p, blocks);
+    else
+        launch_stft_lin<MODE, U8, false>(h, p, blocks);
 }
 
 int choose_chunk(const rt_handle *h, int n_seg) {
@@ -189,6 +201,7 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.tw2 = h->d_tw2;
     p.scale = h->cfg.scale;
     p.thr = h->cfg.threshold;
+    for (int i = 0; i < 3; ++i) p.lin_c[i] = h->lin_c[i];
     p.thr_s = h->d_thr_s;
     p.psum = sl.d_psum;
     p.tail = h->d_tail[tail_write];
@@ -566,6 +579,33 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         const double root = std::sqrt((double)cfg->scale);
         for (int i = 0; i < N; ++i) ws[(size_t)i] = (float)((double)cfg->window[i] * root);
         RT_CREATE_HIP(hipMemcpy(h->d_window, ws.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        // Transform of the coefficients as the kernel uses them.  If it is real and confined to bins 0 and +-1 (hamming,
+        // hann, boxcar: every cosine-sum window of order <= 1 in get_window's periodic form) the constant detrend is
+        // applied to the transform (LIN kernels); any other window keeps the subtract-first kernels.
+        double wr[3] = {0, 0, 0}, wi[3] = {0, 0, 0};  // W[0], W[1], W[N-1]
+        const int ks[3] = {0, 1, N - 1};
+        for (int j = 0; j < 3; ++j)
+            for (int n = 0; n < N; ++n) {
+                const double ang = -two_pi * (double)(((long long)ks[j] * n) % N) / (double)N;
+                wr[j] += (double)ws[(size_t)n] * std::cos(ang);
+                wi[j] += (double)ws[(size_t)n] * std::sin(ang);
+            }
+        // the window is of that form iff the three bins reproduce it:  w[n] = (W0 + W1 e^(+i t) + W_(N-1) e^(-i t)) / N
+        double wmax = 0.0, dev = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const double t = two_pi * (double)n / (double)N;
+            const double fit = (wr[0] + (wr[1] + wr[2]) * std::cos(t) - (wi[1] - wi[2]) * std::sin(t)) / N;
+            wmax = std::max(wmax, std::fabs((double)ws[(size_t)n]));
+            dev = std::max(dev, std::fabs((double)ws[(size_t)n] - fit));
+        }
+        const double w0 = std::fabs(wr[0]);
+        bool ok = w0 > 0.0 && !(cfg->flags & RT_FLAG_NO_LIN_DETREND) && dev <= 1e-6 * wmax;
+        for (int j = 0; j < 3; ++j)
+            if (std::fabs(wi[j]) > 1e-6 * w0) ok = false;  // real transform (w[n] = w[N-n])
+        h->lin = ok;
+        if (ok) {
+            for (int j = 0; j < 3; ++j) h->lin_c[j] = (float)(wr[j] / N);
+        }
     }
     RT_CREATE_HIP(hipMemcpy(h->d_tw1, tw1.data(), sizeof(cf) * tw1.size(), hipMemcpyHostToDevice));
     RT_CREATE_HIP(hipMemcpy(h->d_tw2, tw2.data(), sizeof(cf) * tw2.size(), hipMemcpyHostToDevice));

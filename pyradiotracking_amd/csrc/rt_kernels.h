@@ -54,6 +54,7 @@ struct StftParams {
     const cf *tw2;           // [R3][16]   W_LG^(b*q1)
     float scale;
     float thr;
+    float lin_c[3];          // LIN instantiations: W[0]/N, W[1]/N, W[N-1]/N of the (scaled) window's transform (real)
     const float *thr_s;      // [S] per-stream thresholds (one calibration per SDR, analyze.py:115), or null: `thr` for all
     float *psum;             // [S][blocks_per_stream][N] partial row sums (one row per workgroup)
     float *tail;             // [S][K][N] trailing K columns (written)
@@ -201,6 +202,20 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
     }
 }
 
+// inverse of bin_of for compile-time bins: the lane of a group and the result register that hold bin `bin`
+struct BinSlot {
+    int lane, reg;
+};
+template <int R3>
+constexpr BinSlot slot_of_bin(int bin) {
+    if (R3 == 1) return BinSlot{bin % 16, bin / 16};
+    constexpr int G = 16 / R3;
+    const int k1 = bin % 16, q1 = (bin / 16) % 16, q2 = bin / 256;
+    const int qg = q1 / G, u = q1 % G;
+    const int up = (u + ((k1 * R3 / 8) & (G - 1))) & (G - 1);
+    return BinSlot{k1 * R3 + qg, up * R3 + q2};
+}
+
 // diagnostic builds only (tools/ablate.sh): stop the scan step after stage n, folding the live
 // values into the row sums so nothing upstream is dead code.  0 = full kernel (the product).
 #ifndef RT_ABLATE
@@ -264,7 +279,12 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
     return cf{__builtin_fmaf((float)(x.iq & 0xFFu), c, -1.0f), __builtin_fmaf((float)(x.iq >> 8), c, -1.0f)};
 }
 
-template <int R3, int MODE, bool U8 = false>
+// LIN: constant detrend by linearity.  FFT(w (x - m)) = FFT(w x) - m W with W = FFT(w); for a cosine-sum window of
+// order <= 1 (hamming, hann, boxcar -- anything get_window() makes of them) W is real and zero outside bins 0 and +-1,
+// so "subtract the mean from every sample" (32 subtractions per lane and step, and the transform waiting for the
+// group-wide sum) becomes "subtract sum * W[k]/N from three output bins" (six fused multiply-adds, after pass 3).
+// The host picks LIN when the window qualifies (rt_create); other windows keep the subtract-first form.
+template <int R3, int MODE, bool U8 = false, bool LIN = false>
 __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/SIMD where the allocation would drift above 168 VGPRs
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
@@ -341,6 +361,19 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float thr = p.thr_s ? p.thr_s[s] : p.thr;  // wave-uniform
+    // LIN: the (lane, register) slots of bins 0, 1 and N-1, slots in one register merged: lin_k[j] is this lane's
+    // coefficient for register kLinReg[j] (zero in all but three lanes of a group)
+    constexpr BinSlot kS0 = slot_of_bin<R3>(0), kS1 = slot_of_bin<R3>(1), kS2 = slot_of_bin<R3>(N - 1);
+    constexpr int kLinIdx1 = (kS1.reg == kS0.reg) ? 0 : 1;
+    constexpr int kLinIdx2 = (kS2.reg == kS0.reg) ? 0 : (kS2.reg == kS1.reg) ? kLinIdx1 : kLinIdx1 + 1;
+    constexpr int kLinRegs = kLinIdx2 > kLinIdx1 ? kLinIdx2 + 1 : kLinIdx1 + 1;
+    constexpr int kLinReg[3] = {kS0.reg, kLinIdx1 == 1 ? kS1.reg : kS2.reg, kS2.reg};
+    float lin_k[3] = {0.f, 0.f, 0.f};
+    if constexpr (LIN) {
+        if (lt == kS0.lane) lin_k[0] += p.lin_c[0];
+        if (lt == kS1.lane) lin_k[kLinIdx1] += p.lin_c[1];
+        if (lt == kS2.lane) lin_k[kLinIdx2] += p.lin_c[2];
+    }
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
     // candidate staging: 128 cells per wave, flushed with one returned atomic per bucket
     __shared__ uint2 stage[MODE == 0 ? (kBlock / 64) * kStageCap : 1];
@@ -427,8 +460,8 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             for (int m = 0; m < 4; ++m) s4[m] = cadd(s8[m], s8[m + 4]);
             sum = cadd(cadd(s4[0], s4[2]), cadd(s4[1], s4[3]));
         }
-        sum = group_sum<LG>(sum, red);
-        const cf mean = cscale(sum, 1.0f / (float)N);
+        sum = group_sum<LG>(sum, red);  // LIN: only needed after pass 3 (for LG > 64 its barrier also frees the exchange rows)
+        const cf mean = LIN ? cf{0.f, 0.f} : cscale(sum, 1.0f / (float)N);
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             float4 w4;
@@ -437,10 +470,17 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             } else {
                 w4 = make_float4(wreg[4 * mm], wreg[4 * mm + 1], wreg[4 * mm + 2], wreg[4 * mm + 3]);
             }
-            v[4 * mm + 0] = cscale(csub(v[4 * mm + 0], mean), w4.x);
-            v[4 * mm + 1] = cscale(csub(v[4 * mm + 1], mean), w4.y);
-            v[4 * mm + 2] = cscale(csub(v[4 * mm + 2], mean), w4.z);
-            v[4 * mm + 3] = cscale(csub(v[4 * mm + 3], mean), w4.w);
+            if constexpr (LIN) {
+                v[4 * mm + 0] = cscale(v[4 * mm + 0], w4.x);
+                v[4 * mm + 1] = cscale(v[4 * mm + 1], w4.y);
+                v[4 * mm + 2] = cscale(v[4 * mm + 2], w4.z);
+                v[4 * mm + 3] = cscale(v[4 * mm + 3], w4.w);
+            } else {
+                v[4 * mm + 0] = cscale(csub(v[4 * mm + 0], mean), w4.x);
+                v[4 * mm + 1] = cscale(csub(v[4 * mm + 1], mean), w4.y);
+                v[4 * mm + 2] = cscale(csub(v[4 * mm + 2], mean), w4.z);
+                v[4 * mm + 3] = cscale(csub(v[4 * mm + 3], mean), w4.w);
+            }
         }
 
         RT_ABLATE_STOP(1)  // loads + detrend + window
@@ -532,6 +572,14 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
         wave_sync();
         RT_ABLATE_STOP(6)  // + pass 3
 
+        if constexpr (LIN) {
+            // X[k] -= (sum x) * W[k]/N for k in {0, 1, N-1}: the constant detrend, applied to the transform
+#pragma unroll
+            for (int j = 0; j < kLinRegs; ++j) {
+                v[kLinReg[j]].x = __builtin_fmaf(-lin_k[j], sum.x, v[kLinReg[j]].x);
+                v[kLinReg[j]].y = __builtin_fmaf(-lin_k[j], sum.y, v[kLinReg[j]].y);
+            }
+        }
         // |X|^2 * scale  (scipy _spectral_py.py:2126-2128); sqrt(scale) is folded into the window table
         float P[16];
 #pragma unroll

@@ -486,6 +486,57 @@ def test_pipelined_calls_match_serial():
         piped.fetch_records()
 
 
+@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann"), (2048, "boxcar"), (4096, "hamming")])
+def test_detrend_by_linearity_equals_subtract_first(nperseg, window):
+    """Hamming / hann / boxcar windows: the constant detrend is applied to the transform (mean * FFT(window) off bins
+    0 and +-1) instead of to the samples.  Against the subtract-first kernels (RT_FLAG_NO_LIN_DETREND) on input with a
+    DC offset 46 dB above the noise: bins 0 and +-1 within 5e-2 dB of the oracle in both forms wherever they are not deep in the round-off floor
+    of the offset itself, every other bin within 1e-4 relative, records identical."""
+    _need_gpu()
+    fs, n = 2048000, 64 * 4096  # 128 ms
+    n_seg = n // nperseg
+    w = oracle.window_coefficients(window, nperseg)
+    rng = np.random.default_rng(nperseg + 1)
+    iq = np.stack([synth.make_stream(synth.StreamSpec(n, fs, synth.random_pulses(rng, n, fs, w, 3, dur_ms=(3, 9)), dc=complex(2e-3, -1e-3)), 200 + s) for s in range(2)])
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_min_duration_ms=2)
+    specs, recs = [], []
+    for first in (False, True):
+        b = _batch_for(kw, 2, n, "sparse", subtract_first=first)
+        d_iq = _native.DeviceBuffer(0, iq.nbytes)
+        d_iq.upload(iq)
+        d_out = _native.DeviceBuffer(0, 2 * n_seg * nperseg * 4)
+        b.native.spectrogram_device(d_iq.ptr, n, n, d_out.ptr)
+        specs.append(d_out.download(np.float32, 2 * n_seg * nperseg).reshape(2, n_seg, nperseg))
+        b.enqueue(iq)
+        recs.append(b.fetch_records())
+    lin, sub = specs
+    others = np.ones(nperseg, bool)
+    others[[0, 1, nperseg - 1]] = False
+    # the other bins see the offset's float32 round-off in a different place (w*x instead of w*(x - m)): a few 1e-6 of a
+    # cell, plus an absolute floor far below the noise level (cells in deep nulls)
+    a_, b_ = lin[:, :, others].astype(np.float64), sub[:, :, others].astype(np.float64)
+    med = np.median(b_, axis=2, keepdims=True)
+    smax = b_.max(axis=2, keepdims=True)  # under a strong tone a few ulp of its amplitude leak into every bin, in either form
+    err = np.abs(a_ - b_) / (b_ + 25.0 * med + 5e-3 * np.sqrt(b_ * smax))
+    assert err.max() < SPEC_REL_TOL, err.max()  # the same bound as against the oracle (test_spectrogram_matches_oracle)
+    for s in range(2):
+        _, _, want = oracle.stft_power(iq[s], fs, window, nperseg)
+        floor = np.median(want)  # noise level per cell
+        for k in (0, 1, nperseg - 1):
+            a, b_, o = lin[s, :, k].astype(np.float64), sub[s, :, k].astype(np.float64), want[k].astype(np.float64)
+            # cells of these bins that carry noise-level power or more: both forms agree with the reference's order of operations
+            sel = o > 0.05 * floor
+            # (float32: the offset's transform is ~sqrt(nperseg) * 200 times the noise amplitude in these bins, and one ulp
+            # of it -- in the segment mean of the subtract-first form as in the product sum * W[k] -- is 1e-3 .. 1e-2 dB)
+            assert np.all(np.abs(10 * np.log10(a[sel] / o[sel])) < 5e-2), (nperseg, s, k, float(np.abs(10 * np.log10(a[sel] / o[sel])).max()))
+            assert np.all(np.abs(10 * np.log10(b_[sel] / o[sel])) < 5e-2), (nperseg, s, k, float(np.abs(10 * np.log10(b_[sel] / o[sel])).max()))
+            # below that (the detrended DC bin of a boxcar window is exactly zero in exact arithmetic) they stay at the floor
+            assert np.all(a[~sel] < 0.1 * floor) and np.all(b_[~sel] < 0.1 * floor)
+    assert [(int(r["stream"]), int(r["fi"]), int(r["start"]), int(r["end"]), int(r["shadowed"])) for r in recs[0]] == \
+           [(int(r["stream"]), int(r["fi"]), int(r["start"]), int(r["end"]), int(r["shadowed"])) for r in recs[1]]
+    assert len(recs[0]) > 0
+
+
 # ---------------------------------------------------------------------------
 # capacity handling and degenerate inputs
 # ---------------------------------------------------------------------------
