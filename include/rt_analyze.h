@@ -53,11 +53,18 @@ typedef enum rt_status {
 
 /* how the batch is analysed */
 typedef enum rt_mode {
-    RT_MODE_AUTO = 0,   /* fused sparse path; re-runs a buffer dense when its candidate
-                           lists overflow and then stays dense for the next 16 buffers
-                           (32, 64 ... 1024 while the sparse probes keep overflowing) */
+    RT_MODE_AUTO = 0,   /* fused sparse path; a buffer whose candidate lists overflow is re-run one
+                           level up (pre-filter where available, then dense) and the handle stays
+                           on that level for the next 16 buffers (32, 64 ... 1024 while the probes of
+                           the level below keep overflowing) */
     RT_MODE_DENSE = 1,  /* materialise the power spectrogram (any input)        */
-    RT_MODE_SPARSE = 2  /* fused sparse path only; overflow -> RT_E_HOT_OVERFLOW */
+    RT_MODE_SPARSE = 2, /* fused sparse path only; overflow -> RT_E_HOT_OVERFLOW */
+    RT_MODE_PREFILTER = 3 /* sparse path behind the run-length pre-filter (two scan passes: per chunk of
+                             segments and bin "every cell passes the absolute threshold", then candidate
+                             cells only from such chunks and their neighbours): for inputs whose noise
+                             crosses the threshold.  Needs signal_min_duration >= 2 * segs_per_chunk hops
+                             (else RT_E_UNSUPPORTED); overflow -> RT_E_HOT_OVERFLOW.  RT_MODE_AUTO goes
+                             through it between the sparse and the dense path where it is available. */
 } rt_mode;
 
 /*
@@ -229,7 +236,7 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
 /* Per-call figures of the last rt_process (valid after rt_fetch). */
 typedef struct rt_call_info {
     int32_t n_seg;            /* T of the call                                           */
-    int32_t mode_used;        /* RT_MODE_DENSE or RT_MODE_SPARSE                          */
+    int32_t mode_used;        /* RT_MODE_DENSE, RT_MODE_SPARSE or RT_MODE_PREFILTER       */
     int32_t fell_back;        /* 1 if the sparse path overflowed and dense re-ran        */
     int32_t reserved;
     int64_t n_hot;            /* candidate cells emitted by the sparse scan              */

@@ -63,6 +63,7 @@ struct Slot {
     uint32_t *d_hot_seen = nullptr;
     int32_t *h_hot_total = nullptr;   // pinned, [S]
     float *d_psum = nullptr;
+    uint16_t *d_full = nullptr;       // [S][max_chunks][LG] chunk bits of the run-length pre-filter (null: not available)
     rt_record *d_raw = nullptr;
     int32_t *d_raw_count = nullptr;
     unsigned long long *d_counters = nullptr;  // 4 words (atomics: device memory)
@@ -105,8 +106,14 @@ struct rt_handle {
     bool lin = false;      // constant detrend by linearity (cosine-sum window of order <= 1; rt_kernels.h: LIN)
     float lin_c[3] = {0.f, 0.f, 0.f};
 
-    int dense_sticky = 0;  // AUTO mode: calls left to run dense directly after a sparse overflow
-    int sticky_len = 16;   // ... how many that is: doubles (up to 1024) while the sparse probes keep overflowing
+    // AUTO mode: three ways to analyse a buffer, cheapest first -- RT_MODE_SPARSE (candidates emitted by the scan itself),
+    // RT_MODE_PREFILTER (two scan passes, rt_kernels.h; only where prefilter_ok), RT_MODE_DENSE.  A call whose candidate
+    // lists overflow is re-run one level up when it is fetched; the handle then stays on that level for `dense_sticky`
+    // calls before it probes the level below again (a failed probe costs a wasted scan: the interval doubles, 16 .. 1024).
+    bool prefilter_ok = false;
+    int auto_level = RT_MODE_SPARSE;
+    int dense_sticky = 0;  // calls left on auto_level before the next probe
+    int sticky_len = 16;
     uint64_t n_calls = 0;  // calls enqueued so far
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
@@ -167,11 +174,22 @@ void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
         launch_stft_lin<MODE, U8, false>(h, p, blocks);
 }
 
+// cells a run must have to pass the duration gate unless it runs through t = 0 (see rt_create)
+long long min_run_cells(const rt_handle *h) {
+    const double hop = seg_time(1, h->N, h->cfg.sample_rate) - seg_time(0, h->N, h->cfg.sample_rate);
+    const double cells = h->cfg.min_duration_s * (1.0 - 1e-9) / hop;
+    return (long long)std::ceil(std::min(cells, 1.0e9)) - 1;
+}
+
 int choose_chunk(const rt_handle *h, int n_seg) {
     if (h->cfg.segs_per_chunk > 0) return h->cfg.segs_per_chunk;
     // enough workgroups to fill 256 CUs several times over, halo overhead <= 1/L
     int L = 32;
-    while (L > 4) {
+    // ... but where the run-length pre-filter is possible with chunks of 32 (minimum duration >= 64 hops) the chunks
+    // stay that long for small batches too: its selectivity is p^L (a small batch is launch-bound anyway)
+    // (whatever the mode: the chunk length sets the order of the row sums' partial sums, and the modes return the same bits)
+    const bool keep_long = 2ll * L - 1 <= min_run_cells(h) && n_seg >= 2 * L;
+    while (L > 4 && !keep_long) {
         const int64_t chunks = (n_seg + L - 1) / L;
         const int64_t blocks = (int64_t)h->cfg.n_streams * ((chunks + h->GPW - 1) / h->GPW);
         if (blocks >= 2048) break;
@@ -210,6 +228,7 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.hot_count = sl.d_hot_count;
     p.hot_cap = h->hot_cap;
     p.tbits = key_tbits(n_seg);
+    p.full = sl.d_full;
     return p;
 }
 
@@ -271,8 +290,25 @@ int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
     return RT_OK;
 }
 
-// enqueue scan + detect + readback for the call described by sl.call
-int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool *launched = nullptr) {
+// the level above / below `mode` in AUTO's order SPARSE < PREFILTER < DENSE
+int level_up(const rt_handle *h, int mode) {
+    if (mode == RT_MODE_SPARSE && h->prefilter_ok) return RT_MODE_PREFILTER;
+    return RT_MODE_DENSE;
+}
+int level_down(const rt_handle *h, int mode) {
+    if (mode == RT_MODE_DENSE && h->prefilter_ok) return RT_MODE_PREFILTER;
+    return RT_MODE_SPARSE;
+}
+
+template <int MODE>
+void launch_scan(rt_handle *h, const StftParams &sp, int blocks, bool u8) {
+    if (u8) launch_stft<MODE, true>(h, sp, blocks); else launch_stft<MODE>(h, sp, blocks);
+}
+
+// enqueue scan + detect + readback for the call described by sl.call, analysed the way `mode` says.
+// `second_pass_only`: RT_MODE_PREFILTER for a call whose RT_MODE_SPARSE attempt has just overflowed -- that scan
+// wrote the chunk bits, row sums and tail columns already, only the selective pass and the detection are repeated.
+int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr, bool second_pass_only = false) {
     const CallCtx &c = sl.call;
     if (launched) *launched = false;
     StftParams sp = make_stft_params(h, sl, c.iq, c.stream_stride, c.n_seg, c.tail_write);
@@ -282,6 +318,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool *launched = nullpt
     }
     const int blocks = h->cfg.n_streams * sp.blocks_per_stream;
     const int S = h->cfg.n_streams;
+    const bool dense = (mode == RT_MODE_DENSE);
     // hot_count / raw_count and the four counter words are left zero by their last readers
     // (detect_bucket<true>, finalize_records / detect_dense: close_call)
     if (dense) {
@@ -289,12 +326,19 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool *launched = nullpt
         if (rc != RT_OK) return rc;
         sp.spec = h->d_spec;
     }
-    RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
+    if (mode == RT_MODE_PREFILTER && !sl.d_full) {
+        h->err = "internal: pre-filter without its scratch";
+        return RT_E_INVALID;
+    }
+    if (!second_pass_only) RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
     if (launched) *launched = true;
     if (dense) {
-        if (c.u8) launch_stft<1, true>(h, sp, blocks); else launch_stft<1>(h, sp, blocks);
+        launch_scan<1>(h, sp, blocks, c.u8);
+    } else if (mode == RT_MODE_PREFILTER) {
+        if (!second_pass_only) launch_scan<4>(h, sp, blocks, c.u8);
+        launch_scan<5>(h, sp, blocks, c.u8);
     } else {
-        if (c.u8) launch_stft<0, true>(h, sp, blocks); else launch_stft<0>(h, sp, blocks);
+        launch_scan<0>(h, sp, blocks, c.u8);
     }
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
@@ -305,6 +349,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, bool dense, bool *launched = nullpt
     a.prev_cols = h->K;
     a.chunks = sp.blocks_per_stream;
     a.spec = h->d_spec;
+    a.filtered = (mode == RT_MODE_PREFILTER) ? 1 : 0;
     if (dense) {
         hipLaunchKernelGGL(detect_dense, dim3(S), dim3(kDetBlock), h->lds_dense, sd, a);
     } else {
@@ -425,6 +470,7 @@ void rt_destroy(rt_handle *h) {
         (void)hipFree(sl.d_hot_seen);
         (void)hipHostFree(sl.h_hot_total);
         (void)hipFree(sl.d_psum);
+        (void)hipFree(sl.d_full);
         (void)hipFree(sl.d_raw);
         (void)hipFree(sl.d_raw_count);
         (void)hipFree(sl.d_counters);
@@ -452,7 +498,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     for (int r : {1, 2, 4, 8, 16})
         if (cfg->nperseg == 256 * r) R3 = r;
     if (!R3) return fail_create(RT_E_UNSUPPORTED, "nperseg must be one of 256, 512, 1024, 2048, 4096");
-    if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_SPARSE) return fail_create(RT_E_INVALID, "bad mode");
+    if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_PREFILTER) return fail_create(RT_E_INVALID, "bad mode");
     if (cfg->lanes > 1 && cfg->n_streams > 1) {
         // stream groups on their own handles and HIP streams: the detection kernels, launch gaps and last
         // workgroup round of one group overlap the scan of another
@@ -507,6 +553,17 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->L = choose_chunk(h, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
     const int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
+    {
+        // Run-length pre-filter: a run shorter than r_min cells (and not through t = 0) fails the duration gate whatever
+        // else holds -- (len + 1) * hop < signal_min_duration (analyze.py:427-430; rt_core.h: gate_run), with a margin of
+        // 1e-9 for the rounding of the float64 expressions.  A run of >= 2 L - 1 cells covers an aligned chunk of L.
+        const long long r_min = min_run_cells(h);
+        h->prefilter_ok = h->L >= 4 && 2ll * h->L - 1 <= r_min && h->max_seg >= 2 * h->L;
+        if (cfg->mode == RT_MODE_PREFILTER && !h->prefilter_ok) {
+            delete h;
+            return fail_create(RT_E_UNSUPPORTED, "RT_MODE_PREFILTER needs signal_min_duration >= 2 * segs_per_chunk STFT hops");
+        }
+    }
     if (((long long)h->N << key_tbits(std::max(h->max_seg, 2))) > 0x100000000ll) {
         delete h;
         return fail_create(RT_E_UNSUPPORTED, "max_samples too large for 32-bit cell keys");
@@ -616,6 +673,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->pool_cap = std::min<int64_t>((int64_t)S * h->rec_cap, kMaxPoolRecords);
     for (auto &sl : h->slot) {
         RT_CREATE_HIP(hipMalloc(&sl.d_psum, std::max<size_t>(psum_bytes, 4)));
+        if (h->prefilter_ok && cfg->mode != RT_MODE_DENSE)
+            RT_CREATE_HIP(hipMalloc(&sl.d_full, (size_t)S * h->max_chunks * LG * sizeof(uint16_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot, (size_t)S * kBuckets * h->hot_cap * sizeof(uint2)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_count, (size_t)S * kBuckets * sizeof(uint32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_seen, (size_t)S * kBuckets * sizeof(uint32_t)));
@@ -772,12 +831,15 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         h->any_reset_pending = false;
         c.no_last = true;
     }
-    c.mode_used = (h->cfg.mode == RT_MODE_DENSE) ? RT_MODE_DENSE : RT_MODE_SPARSE;
-    if (h->cfg.mode == RT_MODE_AUTO && h->dense_sticky > 0) {
-        // the input recently overflowed the candidate lists: do not pay for a sparse attempt
-        // plus a dense re-run on every buffer; probe the sparse path again after a while
-        c.mode_used = RT_MODE_DENSE;
-        --h->dense_sticky;
+    c.mode_used = h->cfg.mode;
+    if (h->cfg.mode == RT_MODE_AUTO) {
+        // the level the input last needed, for `dense_sticky` more calls; then a probe of the level below
+        if (h->dense_sticky > 0) {
+            c.mode_used = h->auto_level;
+            --h->dense_sticky;
+        } else {
+            c.mode_used = level_down(h, h->auto_level);
+        }
     }
     if (T == 0) {
         // empty spectrogram: no signals; `_spectrogram_last` becomes an empty map
@@ -792,7 +854,7 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
     } else {
         bool launched = false;
-        rc = enqueue_analysis(h, sl, c.mode_used == RT_MODE_DENSE, &launched);
+        rc = enqueue_analysis(h, sl, c.mode_used, &launched);
         if (rc != RT_OK) {
             // nothing stays enqueued for a failed call.  Before the first launch the slot's scratch is untouched:
             // the call it held (possibly still unfetched) is put back; afterwards its results are gone with it.
@@ -954,30 +1016,42 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     h->info = rt_call_info{};
     h->info.n_seg = c.n_seg;
     h->info.n_hot = 0;
-    if (c.mode_used == RT_MODE_SPARSE && !c.is_extract && c.n_seg > 0)
-        for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
-    if ((flags & kFlagHotOverflow) && !c.is_extract) {
-        if (h->cfg.mode == RT_MODE_SPARSE) {
-            h->err = "candidate-cell capacity exceeded (hot_capacity) in sparse mode";
+    while ((flags & kFlagHotOverflow) && !c.is_extract && c.mode_used != RT_MODE_DENSE) {
+        if (h->cfg.mode != RT_MODE_AUTO) {
+            h->err = "candidate-cell capacity exceeded (hot_capacity)";
             if (peek) return kCallFailed;  // the laned rt_fetch drops this call in every lane together
             c.pending = false;
             return RT_E_HOT_OVERFLOW;
         }
-        // dense re-run of the same buffer with the same look-back state.  Everything of this handle runs in
+        // Re-run of the same buffer with the same look-back state, one level up.  Everything of this handle runs in
         // order on its own stream, so the re-run queues up behind whatever is in flight there (a later call
-        // read the tail columns this call's sparse scan already wrote -- the re-run writes the same values);
+        // read the tail columns this call's first scan already wrote -- the re-run writes the same values);
         // other lanes' streams are left alone.
+        const int from = c.mode_used;
+        c.mode_used = level_up(h, from);
+        // stay on that level for a while; every further failed probe doubles the while (a probe costs a wasted scan;
+        // a call that climbs two levels counts once)
+        h->auto_level = c.mode_used;
+        if (!c.fell_back) {
+            h->dense_sticky = h->sticky_len;
+            h->sticky_len = std::min(h->sticky_len * 2, 1024);
+        }
         c.fell_back = true;
-        c.mode_used = RT_MODE_DENSE;
-        // stay dense for a while; every further failed probe doubles the while (a probe costs a wasted scan)
-        h->dense_sticky = h->sticky_len;
-        h->sticky_len = std::min(h->sticky_len * 2, 1024);
-        int rc = enqueue_analysis(h, sl, true);
+        int rc = enqueue_analysis(h, sl, c.mode_used, nullptr, from == RT_MODE_SPARSE && c.mode_used == RT_MODE_PREFILTER);
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventSynchronize(sl.ev_done));
         flags = sl.h_counters[2];
     }
-    if (c.mode_used == RT_MODE_SPARSE && !c.is_extract && !c.fell_back && c.n_seg > 0) h->sticky_len = 16;  // a sparse call went through
+    if (c.mode_used != RT_MODE_DENSE && !c.is_extract && c.n_seg > 0)
+        for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
+    auto rank = [](int mode) { return mode == RT_MODE_SPARSE ? 0 : mode == RT_MODE_PREFILTER ? 1 : 2; };
+    if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && rank(c.mode_used) < rank(h->auto_level)) {
+        // a probe of a lower level went through: the handle moves there (and from the pre-filter level it will
+        // probe the plain sparse path after the usual interval)
+        h->auto_level = c.mode_used;
+        h->sticky_len = 16;
+        h->dense_sticky = (c.mode_used == RT_MODE_SPARSE) ? 0 : 16;
+    }
     if (flags & kFlagInconsistent) {
         h->err = "internal: candidate list lacks the cell preceding a run";
         if (peek) return kCallFailedInternal;

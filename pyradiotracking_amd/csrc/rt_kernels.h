@@ -5,7 +5,8 @@
 //                         tail and either sparse candidate emission (MODE 0),
 //                         a dense spectrogram (MODE 1) or the spectrogram only
 //                         (MODE 2, debug; MODE 3 = loads only, for PMC traffic
-//                         calibration).  Replaces scipy.signal.spectrogram
+//                         calibration; MODE 4 / 5 = the two passes of the
+//                         run-length pre-filter, see below).  Replaces scipy.signal.spectrogram
 //                         as called at radiotracking/analyze.py:234-241.
 //   detect_sparse         per stream: finish row means, sort candidates,
 //                         plateau extraction + statistics + shadow filter.
@@ -63,7 +64,22 @@ struct StftParams {
     uint32_t *hot_count;     // MODE 0: [S][kBuckets]
     int32_t hot_cap;         // cells per (stream, bucket)
     int32_t tbits;           // bits reserved for t in a key (2^tbits >= T)
+    uint16_t *full;          // [S][chunks][LG] per lane: bit r = "every cell of this chunk in the lane's bin r passes the
+                             // absolute threshold" (chunk 0: or the cell at t = 0 does).  Written by MODE 0 / 4, read by MODE 5.
 };
+
+// Run-length pre-filter (inputs whose noise crosses the absolute threshold, so that MODE 0 overflows its candidate
+// lists).  A run can only become a signal if it is at least `stride - 1` cells long (rt_core.h: gate_run, the duration
+// gate) or reaches back into the previous buffer (then it contains t = 0).  With chunks of L <= stride / 2 segments a
+// run of that length covers at least one aligned chunk completely.  So:
+//   pass A (MODE 4, or MODE 0 itself before it overflowed): per (stream, chunk, bin) one bit "all L cells >= thr"
+//          (chunk 0: "... or the cell at t = 0 is") next to everything a scan writes (row sums, look-back tail);
+//   pass B (MODE 5): only the chunks with a set bit in themselves or a neighbour are transformed again, and only the
+//          flagged bins emit candidate cells.  Every chunk a qualifying run touches is flagged or next to a flagged
+//          one, so the detect kernels see those runs complete; what they see of other runs is too short to pass the
+//          duration gate (DetectArgs::filtered: a run without its preceding cell is dropped, not an error).
+// In noise with P(cell >= thr) = p a chunk bit is set with probability p^L: at L = 32 pass B touches nothing but the
+// neighbourhoods of real signals until the threshold sits ~7 dB under the noise floor.
 
 constexpr int kBuckets = 16;  // candidate lists per stream: bucket = bin & 15 (a bin never spans buckets).
                               // 64 was measured: detect -6 %, but the scan +2 % (N=256) .. +8 % (N=1024)
@@ -376,21 +392,46 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
     }
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
     // candidate staging: 128 cells per wave, flushed with one returned atomic per bucket
-    __shared__ uint2 stage[MODE == 0 ? (kBlock / 64) * kStageCap : 1];
-    uint2 *stg = stage + (MODE == 0 ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
+    __shared__ uint2 stage[(MODE == 0 || MODE == 5) ? (kBlock / 64) * kStageCap : 1];
+    uint2 *stg = stage + ((MODE == 0 || MODE == 5) ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
     constexpr int kStageLimit = kStageCap;
     int stg_n = 0;                                                    // wave-uniform fill level
     bool gave_up = false;  // wave-uniform: a candidate list of this stream has overflowed, the call will be re-run dense
 
     const raw_t *stream_iq = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride;
-    const int i_first = (MODE == 0 || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (sparse only)
+    constexpr bool EMIT = (MODE == 0 || MODE == 5);   // candidate cells go to the bucket lists
+    constexpr bool FLAGS = (MODE == 0 || MODE == 4);  // chunk bits of the run-length pre-filter are written
+    constexpr bool SUMS = (MODE != 2 && MODE != 5);   // row sums and look-back tail (MODE 5 repeats chunks of a scan that wrote them)
+    const int i_first = (EMIT || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (emitting modes only)
+
+    uint32_t allhot = 0xFFFFu, first_hot = 0u;  // FLAGS: the chunk's bits so far / the hot bits of segment 0
+    uint32_t need = 0xFFFFu;                      // MODE 5: the lane's bins that may emit
+    bool group_need = true;                       // MODE 5: this lane group transforms its chunk
+    if constexpr (MODE == 5) {
+        need = 0u;
+        if (chunk_ok) {
+            const uint16_t *f = p.full + ((int64_t)s * p.chunks + chunk) * LG + lt;
+            need = f[0];
+            if (chunk > 0) need |= f[-LG];
+            if (chunk + 1 < p.chunks) need |= f[LG];
+        }
+        if constexpr (LG > 64) {
+            // the step loop has workgroup barriers: the whole workgroup (1 or 2 chunks) goes or stays
+            if (!__syncthreads_or(need != 0u)) return;
+        } else {
+            const unsigned long long any = __builtin_amdgcn_ballot_w64(need != 0u);
+            if (any == 0ull) return;  // nothing below needs this wave (no workgroup barrier follows in MODE 5)
+            // the wave runs, but the lane groups whose chunk is not needed request no memory and emit nothing
+            if constexpr (LG < 64) group_need = ((any >> ((threadIdx.x & 63) & ~(LG - 1))) & ((1ull << LG) - 1ull)) != 0ull;
+        }
+    }
 
     // software pipeline: the 16 loads of the next segment are issued before the
     // current one is transformed, so their HBM latency hides under ~700 VALU ops.
     // Loads are unconditional (segment index clamped into the stream): lanes of
     // idle groups / past-the-end steps read valid memory and discard it.
     const int seg_hi = T - 1;
-    raw_t nxt[16];
+    raw_t nxt[16] = {};
     // LG >= 64: a lane group is one or more whole waves, so the segment index is wave-uniform and the loads go
     // through a buffer descriptor per segment (a past-the-end segment gets an empty one: its lanes read zeros,
     // which idle groups discard).  Smaller groups share a wave with other chunks: flat loads, indices clamped.
@@ -407,7 +448,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
 #endif
 #pragma unroll
             for (int m = 0; m < 16; ++m) nxt[m] = buf_load_iq(r, lt * (int)sizeof(raw_t), LG * m * (int)sizeof(raw_t), raw_t{});
-        } else {
+        } else if (MODE != 5 || group_need) {
             const int sc = seg_req < seg_hi ? seg_req : seg_hi;
 #ifdef RT_EXP_ALIAS  // diagnostic build (tools/variant.sh alias -DRT_EXP_ALIAS=63): every load hits the same 64 segments of
                      // stream 0 (L2-resident) -- the scan kernel without HBM, i.e. its arithmetic + LDS floor; a mask of
@@ -585,16 +626,18 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
 #pragma unroll
         for (int r = 0; r < 16; ++r) P[r] = __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y);
 
-        if (active && !halo) {
+        if constexpr (SUMS) {
+            if (active && !halo) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += P[r];
+                for (int r = 0; r < 16; ++r) acc[r] += P[r];
+            }
         }
         if constexpr (RT_ABLATE == 8) continue;  // + power and row sums only
         {
             // spectrogram row (dense modes) and look-back tail column (last K segments)
             const int col = seg - (T - p.tail_cols);
             const bool to_spec = (MODE == 1 || MODE == 2) && active && !halo;
-            const bool to_tail = (MODE != 2) && active && !halo && col >= 0;
+            const bool to_tail = SUMS && active && !halo && col >= 0;
             float *spec_dst = p.spec + ((int64_t)s * T + seg) * N;
             float *tail_dst = p.tail + ((int64_t)s * p.tail_cols + col) * N;
             if constexpr (R3 == 1) {
@@ -640,7 +683,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
         }
 
         if constexpr (RT_ABLATE == 7) continue;  // + power, row sums, tail columns (no candidate test)
-        if constexpr (MODE == 0) {
+        if constexpr (EMIT || FLAGS) {
             // candidates are rare: one max over the lane's 16 cells and a single compare in the
             // common path, the per-cell tests only where that fires.  (A NaN cell means the whole
             // segment is NaN -- the mean is -- so the max is NaN and `!(m < thr)` holds, as for the
@@ -655,9 +698,17 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
                 for (int r = 0; r < 16; ++r)
                     if (!(P[r] < thr)) hot |= (1u << r);
             }
+            if constexpr (FLAGS) {
+                // pre-filter bits: every cell of the chunk so far at or above the threshold; the run through t = 0
+                // (it may continue a run of the previous buffer) counts whatever its length
+                if (active && !halo) {
+                    allhot &= hot;
+                    if (seg == 0) first_hot = hot;
+                }
+            }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
-            const uint32_t emit = (active && !halo) ? (hot | next_hot) : 0u;
-            if (!gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare
+            const uint32_t emit = (EMIT && active && !halo) ? ((hot | next_hot) & need) : 0u;
+            if (EMIT && !gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare
                 // Candidates are staged per wave in LDS and flushed with ONE returned atomic per
                 // flush: an atomic per cell would stall on vmcnt(0) and drain the prefetch.
                 int need = 0;  // cells this wave emits in this step (scalar arithmetic on ballots)
@@ -705,14 +756,17 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
         }
     }
 
-    if constexpr (MODE == 0) {
+    if constexpr (EMIT) {
         if (stg_n) flush_stage(p, s, stg, stg_n);
+    }
+    if constexpr (FLAGS) {
+        if (p.full && chunk_ok) p.full[((int64_t)s * p.chunks + chunk) * LG + lt] = (uint16_t)((allhot | first_hot) & 0xFFFFu);
     }
     if constexpr (MODE == 3) {
         if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
         return;
     }
-    if constexpr (MODE != 2) {
+    if constexpr (SUMS) {
         // deterministic workgroup reduction of the lane groups' row sums: one
         // partial row per workgroup (fixed summation order, no float atomics)
         __syncthreads();
@@ -773,6 +827,9 @@ struct DetectArgs {
     const float *cal_s;        // [S] its calibration_db (orders maxima in the shadow filter)
     const int32_t *no_last;    // [S] (host-visible) non-zero: this stream has no previous buffer in this call
                                //     (a restarted SDR's fresh analyzer, analyze.py:128)
+    int32_t filtered;          // the candidate lists come from the run-length pre-filter (stft_scan MODE 5): a run whose
+                               //     preceding cell is missing lies across the edge of the emitted chunks, is too short
+                               //     to pass the duration gate and is dropped (without the filter that is an internal error)
 };
 
 // the detect parameters as stream `s` sees them (s is workgroup- or wave-uniform: scalar loads)
@@ -1310,7 +1367,7 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
             e = t + 1;
             if (b > 0 && (first == 0 || keys[first - 1] != key0 - 1)) {
                 // the cell before a run must have been emitted by the scan (T11)
-                atomicOr(&a.counters[2], kFlagInconsistent);
+                if (!a.filtered) atomicOr(&a.counters[2], kFlagInconsistent);
             } else {
                 av = avg[fi / kBuckets];
                 PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};

@@ -690,6 +690,77 @@ def test_dense_input_everything_above_threshold():
     assert len(want_keys) > 100 and len(missing) <= max(2, len(want_keys) // 200), (len(want_keys), len(got_keys), sorted(missing)[:10])
 
 
+def _noisy_batch(n_streams, blen, fs, nperseg, seed, noise_sigma=1e-5, peak_dbw=(-140.0, -126.0), n_buffers=2):
+    """streams whose noise floor (2 sigma^2 / fs = -160 dBW at sigma 1e-5 and 2.048 MS/s) lies around the thresholds used
+    below, with 15 ms pulses 20..34 dB over it (their hamming side lobes, -43 dB, stay under the thresholds), some across the
+    buffer boundary"""
+    w = oracle.window_coefficients("hamming", nperseg)
+    out = []
+    for s in range(n_streams):
+        rng = np.random.default_rng([seed, s])
+        pulses = synth.random_pulses(rng, n_buffers * blen, fs, w, 5 * n_buffers, peak_dbw=peak_dbw)
+        pulses.append(synth.Pulse(blen - int(0.005 * fs) - 11 * s, int(0.015 * fs), (0.05 + 0.04 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))
+        pulses.append(synth.Pulse(0, int(0.011 * fs), (-0.3 + 0.03 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))  # a run that starts at t = 0
+        out.append(synth.make_stream(synth.StreamSpec(n_buffers * blen, fs, pulses, noise_sigma=noise_sigma), seed=900 + s).reshape(n_buffers, blen))
+    return np.stack(out)  # [S, n_buffers, B]
+
+
+@pytest.mark.parametrize("threshold_dbw", [-158.0, -160.0, -163.0])
+def test_run_length_prefilter_equals_dense(threshold_dbw):
+    """Noise floor 2 dB under, at, and 3 dB over the absolute threshold (20 % .. 61 % of all cells pass it): the plain sparse path overflows
+    its candidate lists, RT_MODE_PREFILTER (two scan passes, only chunks of 32 segments in which a bin passes throughout --
+    and their neighbours -- emit cells) must return exactly the records of the dense path, look-back and the run that
+    starts at t = 0 included; AUTO gets there by itself and stays there without further fall-backs."""
+    _need_gpu()
+    fs, nperseg, blen, n_streams = 2048000, 256, 256 * 1500, 6
+    iq = _noisy_batch(n_streams, blen, fs, nperseg, seed=int(-threshold_dbw))
+    kw = dict(sample_rate=fs, signal_threshold_dbw=threshold_dbw)
+    dense = _batch_for(kw, n_streams, blen, "dense")
+    pre = _batch_for(kw, n_streams, blen, "prefilter")
+    auto = _batch_for(kw, n_streams, blen, "auto")
+    lanes = _batch_for(kw, n_streams, blen, "auto", lanes=2)
+    n_neg = n_zero = 0
+    for k in range(2):
+        chunk = np.ascontiguousarray(iq[:, k])
+        for b in (dense, pre, auto, lanes):
+            b.enqueue(chunk)
+        want = dense.fetch_records()
+        got = pre.fetch_records()
+        assert pre.native.call_info().mode_used == _native.RT_MODE_PREFILTER
+        assert len(want) > n_streams and got.tobytes() == want.tobytes(), (threshold_dbw, k, len(got), len(want))
+        for b in (auto, lanes):
+            got_a = b.fetch_records()
+            info = b.native.call_info()
+            assert got_a.tobytes() == want.tobytes()
+            # first buffer: the sparse attempt overflows and is finished by the selective pass; then the handle stays there
+            assert info.mode_used == _native.RT_MODE_PREFILTER and info.fell_back == (1 if k == 0 else 0), (k, info.mode_used, info.fell_back)
+        n_neg += int((want["start"] < 0).sum())
+        n_zero += int((want["start"] == 0).sum())
+    assert n_neg > 0 and n_zero > 0  # runs across the boundary and runs from t = 0 of the first buffer were among them
+    # the same streams as the RTL-SDR wire format (quantised): uint8 through the same two passes
+    raw = synth.quantize_u8(iq[:, 0], gain=2000.0)
+    kw8 = dict(sample_rate=fs, signal_threshold_dbw=threshold_dbw + 66.0)  # the gain of 2000 is 66 dB
+    d8, p8 = _batch_for(kw8, n_streams, blen, "dense"), _batch_for(kw8, n_streams, blen, "prefilter")
+    d8.enqueue_bytes(raw); p8.enqueue_bytes(raw)
+    w8 = d8.fetch_records()
+    assert len(w8) > n_streams and p8.fetch_records().tobytes() == w8.tobytes()
+
+
+def test_prefilter_needs_long_enough_minimum_duration():
+    """chunks of L segments need signal_min_duration >= 2 L hops (L >= 4); otherwise the mode is refused and AUTO goes
+    from the sparse path straight to the dense one"""
+    _need_gpu()
+    fs, nperseg, blen = 300000, 256, 256 * 600  # the reference's default geometry, but 2 ms = 2.3 hops
+    kw = dict(sample_rate=fs, signal_min_duration_ms=2)
+    with pytest.raises(_native.NativeError) as e:
+        _batch_for(kw, 1, blen, "prefilter")
+    assert e.value.code == _native.RT_E_UNSUPPORTED
+    iq = synth.make_stream(synth.StreamSpec(blen, fs, []), 5)
+    b = _batch_for(dict(signal_threshold_dbw=-150.0, **kw), 1, blen, "auto", hot_capacity=256)
+    b.enqueue(iq.reshape(1, -1)); b.fetch_records()
+    assert b.native.call_info().mode_used == _native.RT_MODE_DENSE and b.native.call_info().fell_back == 1
+
+
 def test_degenerate_lengths():
     _need_gpu()
     an = SignalAnalyzer("0", sdr_callback_length=4096)
