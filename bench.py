@@ -68,6 +68,10 @@ def parse():
                          "(interleaved uint8, converted inside the scan kernel; SURVEY 8(f) rank 1)")
     ap.add_argument("--threshold-dbw", type=float, default=None,
                     help="signal_threshold_dbw (default: the reference's -90, or -80 with --input u8)")
+    ap.add_argument("--noise-dbw", type=float, default=None,
+                    help="noise floor of the synthetic streams as a PSD per bin (default: sigma 1e-5 per component = -160 dBW at "
+                         "2.048 MS/s, far under the threshold); e.g. -89 puts it 1 dB OVER the reference's -90 dBW threshold -- the "
+                         "regime of a real RTL-SDR, analysed through the run-length pre-filter")
     ap.add_argument("--trains", action="store_true", default=None,
                     help="BASELINE config 5 style input: 8-16 tags per stream, pulse trains 10-38 ms, period 0.1-1 s")
     ap.add_argument("--settle", type=int, default=30,
@@ -189,7 +193,10 @@ def main():
         iq = synth.quantize_u8_device(iq_c)
         del iq_c
     else:
-        iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=wl["trains"], first_stream=lo)
+        extra = {}
+        if args.noise_dbw is not None:
+            extra["noise_sigma"] = float(np.sqrt(10.0 ** (args.noise_dbw / 10.0) * fs / 2.0))  # PSD per bin = 2 sigma^2 / fs
+        iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=wl["trains"], first_stream=lo, **extra)
     if args.threshold_dbw is not None:
         kw["signal_threshold_dbw"] = args.threshold_dbw
     stream = torch.cuda.current_stream()
@@ -265,7 +272,7 @@ def main():
     bytes_per_launch = samples_per_step_rank * bytes_per_sample // lanes
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
-    default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw) == ("config2", 256, 0, "auto", "c64", None)
+    default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw, args.noise_dbw) == ("config2", 256, 0, "auto", "c64", None, None)
     traffic, traffic_note = pmc_traffic(default_workload, lanes)
 
     # parity + CPU baseline (untimed).  N = 1: the oracle on the host cores over a bounded sample (the baseline) and the
@@ -324,6 +331,8 @@ def main():
             "lanes_per_gpu": args.lanes,
             "settle_steps": args.settle,
             "population_seed": seed,
+            "noise_floor_dbw": args.noise_dbw,
+            "threshold_dbw": kw.get("signal_threshold_dbw", -90.0),
         },
         "roofline": {
             "bound": "hbm",

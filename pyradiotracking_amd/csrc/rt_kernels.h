@@ -666,14 +666,21 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
                     need = to_tail;
                 }
                 if (need) {
-                    float *row = reinterpret_cast<float *>(gx);  // N floats of the group's LG * 36
+                    float *row = reinterpret_cast<float *>(gx);  // N floats (plus the skew) of the group's LG * 36
+                    // element i of the row sits at i + kSkew * (i / 32): the stores below go to bins 16 apart per lane
+                    // (8-way conflicted at nperseg 4096 without the skew; tools/lds_banks.py rules), the loads to 32
+                    // consecutive elements (conflict-free with any skew)
+                    constexpr int kSkew = (R3 == 16) ? 2 : (R3 == 8) ? 4 : (R3 == 4) ? 1 : 0;
                     group_sync<LG>();  // every wave of the group is done with its exchange rows
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) row[bin_of<R3>(lt, r)] = P[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int bin = bin_of<R3>(lt, r);
+                        row[bin + kSkew * (bin >> 5)] = P[r];
+                    }
                     group_sync<LG>();
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const float q = row[j * LG + lt];
+                        const float q = row[j * LG + lt + kSkew * ((j * LG + lt) >> 5)];
                         if (to_spec) spec_dst[j * LG + lt] = q;
                         if (to_tail) tail_dst[j * LG + lt] = q;
                     }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun; outputs under gpurun_out/prof_<tag>/):
-#   1. rocprofv3 --kernel-trace --stats of the default bench.py run  -> kernel_stats.csv, bench.json
+#   1. rocprofv3 --kernel-trace --stats of the default bench.py run (two lanes; without the one-lane pass after the timed
+#      region, so that every stft_scan row of the csv is a 128-stream launch)  -> kernel_stats.csv, bench.json
 #   2. two --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/profile_traffic.py -> pmc_summary.txt
 # The program itself follows `--` (no shell wrappers under the profiler).
 tag=${1:-round}
@@ -8,7 +9,7 @@ out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --isolated-steps 0 > $out/bench.json 2> $out/bench.err
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 tools/profile_traffic.py > $out/traffic_fetch.json 2> $out/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 tools/profile_traffic.py > $out/traffic_write.json 2> $out/pmc_write.err
