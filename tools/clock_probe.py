@@ -77,9 +77,19 @@ def main():
     if samples:
         cards = sorted({c for smp in samples for c in smp})
         mean = {c: sum(smp.get(c, 0.0) for smp in samples) / len(samples) for c in cards}
-        busy = max(cards, key=lambda c: mean[c])
+        # this process's GPU by its PCI address (the box shows every GPU of its host in sysfs)
+        mine, how = None, "busiest"
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for c in cards:
+                if os.path.basename(os.path.realpath(f"/sys/class/drm/{c}/device")) == addr:
+                    mine, how = c, f"PCI {addr}"
+        except Exception:
+            pass
+        busy = mine or max(cards, key=lambda c: mean[c])
         vals = [smp[busy] for smp in samples if busy in smp]
-        clk = f"sclk of {busy} (busiest of {len(cards)}): mean {mean[busy]:.0f} min {min(vals):.0f} max {max(vals):.0f} MHz ({len(vals)} samples)"
+        clk = f"sclk of {busy} ({how}; {len(cards)} cards visible): mean {mean[busy]:.0f} min {min(vals):.0f} max {max(vals):.0f} MHz ({len(vals)} samples)"
     print(f"{lib:28s} {args.what:5s} kernel {ms/n:.4f} ms over {n} launches   {clk}")
 
 
