@@ -102,9 +102,10 @@ typedef struct rt_config {
 
 #define RT_FLAG_TIMING 1u /* record HIP events around the kernels of each call */
 #define RT_FLAG_NO_LIN_DETREND 2u /* always subtract the segment mean before windowing (scipy's order of operations);
-                                     default: for hamming / hann / boxcar windows the constant detrend is applied to
-                                     the transform instead (three bins), which is cheaper and equal within float32
-                                     round-off -- other windows use the subtract-first form anyway */
+                                     default: for hamming / hann / boxcar windows and complex64 input the constant
+                                     detrend is applied to the transform instead (three bins), which is cheaper and
+                                     equal within float32 round-off -- other windows and uint8 input (where a saturated
+                                     segment cancels exactly in the reference) use the subtract-first form anyway */
 
 /*
  * One extracted plateau, before it becomes a Signal (analyze.py:442-449).

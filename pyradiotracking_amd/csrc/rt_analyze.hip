@@ -166,10 +166,13 @@ void launch_stft_lin(rt_handle *h, const StftParams &p, int blocks) {
 }
 
 // MODE 3 (load stream only) has no detrend: one instantiation
+// uint8 input keeps the subtract-first form: quantised samples make exact cancellations real (a saturated segment is
+// constant, x - mean is exactly zero and so is every cell of it in the reference -> std = NaN over a plateau that holds
+// one; the linearity form leaves a residue 140 dB under the offset there -- found by the round-2 soak)
 template <int MODE, bool U8 = false>
 void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
-    if (h->lin && MODE != 3)
-        launch_stft_lin<MODE, U8, (MODE != 3)>(h, p, blocks);
+    if (h->lin && MODE != 3 && !U8)
+        launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, p, blocks);
     else
         launch_stft_lin<MODE, U8, false>(h, p, blocks);
 }

@@ -43,7 +43,11 @@ while time.time() < t_end:
     thr = float(rng.choice([-90.0, -85.0, -100.0]))
     snr = float(rng.choice([5.0, 0.0, 8.0]))
     cal = [float(c) for c in rng.uniform(-6, 6, n_streams)] if rng.random() < 0.5 else 0.0
-    mode = str(rng.choice(["sparse", "dense", "auto"]))
+    mode = str(rng.choice(["sparse", "dense", "auto", "auto", "prefilter"]))  # prefilter: refused where the minimum duration is too short
+    subtract_first = bool(rng.random() < 0.3)  # SciPy's order of the constant detrend instead of the linearity form
+    # round 2: a quarter of the cases with the noise floor around the absolute threshold (8 dB under .. 2 dB over): the
+    # sparse path overflows, AUTO climbs to the run-length pre-filter or the dense path; decisions then sit on the noise
+    noisy = bool(rng.random() < 0.25)
     lanes = int(rng.choice([1, 1, 2, 3]))
     pipelined = bool(rng.random() < 0.4)   # enqueue buffer k + 1 before fetching buffer k
     vary_len = bool(rng.random() < 0.3)    # shorter buffers than sdr_callback_length
@@ -65,7 +69,8 @@ while time.time() < t_end:
             pulses.append(synth.Pulse(max(0, k * blen - ln // 2), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.1))
             pulses.append(synth.Pulse(max(0, k * blen - ln - int(rng.integers(0, 3)) * nperseg), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.3))
         dc = complex(2e-3, -1e-3) if rng.random() < 0.3 else 0j
-        iq.append(synth.make_stream(synth.StreamSpec(total, fs, pulses, dc=dc), 1000 * case + s))
+        sigma = synth.NOISE_SIGMA if not noisy else float(np.sqrt(10.0 ** ((thr + rng.uniform(-8.0, 2.0)) / 10.0) * fs / 2.0))
+        iq.append(synth.make_stream(synth.StreamSpec(total, fs, pulses, dc=dc, noise_sigma=sigma), 1000 * case + s))
     iq = np.stack(iq)
     poison = os.environ.get("SOAK_POISON") == "1" and not u8 and rng.random() < 0.5
     if poison:
@@ -82,7 +87,7 @@ while time.time() < t_end:
               signal_threshold_dbw=thr, snr_threshold_db=snr)
     try:
         b = BatchSignalAnalyzer([str(i) for i in range(n_streams)], sdr_callback_length=blen, mode=mode, lanes=lanes, calibration_db=cal,
-                                record_capacity=2048, segs_per_chunk=chunking, **kw)
+                                record_capacity=2048, segs_per_chunk=chunking, subtract_first=subtract_first, **kw)
     except Exception as e:  # configuration refused: report, go on
         print(f"case {case}: create failed: {e}")
         continue
@@ -222,6 +227,6 @@ while time.time() < t_end:
     n_records += nrec
     n_bad += bad
     print(f"case {case}: N={nperseg} fs={fs} {window} T={n_seg} S={n_streams} bufs={n_buf} min/max={min_ms:.2f}/{max_ms:.1f} ms thr={thr} snr={snr} "
-          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''}{' poisoned' if poison else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
+          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''}{' poisoned' if poison else ''}{' noisy' if noisy else ''}{' subtract-first' if subtract_first else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
 print(f"SOAK: {n_cases} cases, {n_records} oracle records, {n_bad} mismatching stream-buffers "
       f"({n_unexplained} not explained by a float32 round-off margin, {n_field} with a field beyond 0.1 dB)")

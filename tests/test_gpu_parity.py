@@ -420,7 +420,7 @@ def test_uint8_wire_format_ingestion(nperseg, window):
         raw_all.append(synth.quantize_u8(x))
     raw_all = np.stack(raw_all)  # [S, 2*n_buf*blen]
     b8 = _batch_for(kw, n_streams, blen, "sparse")
-    bc = _batch_for(kw, n_streams, blen, "sparse")
+    bc = _batch_for(kw, n_streams, blen, "sparse", subtract_first=True)  # uint8 input always detrends in SciPy's order
     oas = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(n_streams)]
     oas128 = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(n_streams)]
     total = 0
