@@ -238,8 +238,9 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
 typedef struct rt_call_info {
     int32_t n_seg;            /* T of the call                                           */
     int32_t mode_used;        /* RT_MODE_DENSE, RT_MODE_SPARSE or RT_MODE_PREFILTER       */
-    int32_t fell_back;        /* 1 if the sparse path overflowed and dense re-ran        */
-    int32_t reserved;
+    int32_t fell_back;        /* 1 if candidate lists overflowed and (part of) the call was re-run */
+    int32_t n_dense_streams;  /* RT_MODE_AUTO: streams re-run dense on their own because only they overflowed
+                                 (a few noisy SDRs in a batch; mode_used then still names the batch's path) */
     int64_t n_hot;            /* candidate cells emitted by the sparse scan              */
     int64_t n_records;        /* records produced                                        */
     float ms_stft;            /* RT_FLAG_TIMING: STFT/scan kernel, HIP events, ms        */

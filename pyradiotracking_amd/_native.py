@@ -61,7 +61,7 @@ class RtCallInfo(C.Structure):
         ("n_seg", C.c_int32),
         ("mode_used", C.c_int32),
         ("fell_back", C.c_int32),
-        ("reserved", C.c_int32),
+        ("n_dense_streams", C.c_int32),
         ("n_hot", C.c_int64),
         ("n_records", C.c_int64),
         ("ms_stft", C.c_float),

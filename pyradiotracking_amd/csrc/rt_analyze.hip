@@ -38,6 +38,7 @@ thread_local std::string g_create_error;
 constexpr int kSlots = 2;
 constexpr int kTails = 3;
 constexpr int64_t kMaxPoolRecords = 4 << 20;  // pinned record pool per slot: at most 4 Mi records (160 MiB)
+constexpr int kMaxPartial = 32;  // AUTO: up to this many overflowing streams of a batch are re-run dense on their own
 
 struct CallCtx {
     bool pending = false;   // enqueued, not fetched yet
@@ -53,6 +54,7 @@ struct CallCtx {
     bool is_extract = false;
     bool u8 = false;        // IQ is interleaved uint8 (RTL-SDR wire format)
     bool no_last = false;   // the slot's h_no_last flags apply (some stream was reset, rt_reset_stream)
+    int n_dense_streams = 0;  // streams of this call that were re-run dense on their own (AUTO, partial fall-back)
     // handle state before this call (restored when the call is rolled back: a later lane failed to enqueue)
     int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0;
 };
@@ -73,6 +75,9 @@ struct Slot {
     int32_t *h_rec_offset = nullptr, *h_rec_count = nullptr;  // [S]
     rt_record *h_records = nullptr;                            // [pool_cap]
     int32_t *h_no_last = nullptr;                              // pinned, [S]: streams without a previous buffer in this call
+    int32_t *h_overflow = nullptr;                             // pinned, [S]: set by detect_bucket for a stream whose candidate lists overflowed
+    int32_t *h_list = nullptr;                                 // pinned, [kMaxPartial]: the streams of a partial dense re-run (read by the kernels)
+    unsigned long long *h_total = nullptr;                     // pinned: records allocated so far, uploaded before a partial re-run
     hipEvent_t ev_begin = nullptr, ev_scan = nullptr, ev_done = nullptr;
     CallCtx call;
 };
@@ -95,6 +100,7 @@ struct rt_handle {
     cf *d_tw1 = nullptr, *d_tw2 = nullptr;
     float *d_tail[kTails] = {nullptr, nullptr, nullptr};
     float *d_spec = nullptr;                   // lazily allocated dense spectrogram (shared)
+    float *d_spec_part = nullptr;              // ... and one for min(S, kMaxPartial) streams (partial dense re-run)
     void *d_iq_stage[kSlots] = {nullptr, nullptr};  // for rt_process_host: one per call slot (a call's IQ must stay
     size_t iq_stage_bytes[kSlots] = {0, 0};         // in place until it is fetched -- AUTO mode may re-run it dense)
     int64_t pool_cap = 0;
@@ -272,6 +278,7 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.thr_s = h->d_thr_s;
     a.cal_s = h->d_cal_s;
     a.no_last = sl.call.no_last ? sl.h_no_last : nullptr;
+    a.stream_overflow = sl.h_overflow;
     return a;
 }
 
@@ -365,6 +372,42 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     RT_HIP(h, hipGetLastError());
     // no readback: the call's last workgroup wrote the counter words to pinned host memory
     RT_HIP(h, hipEventRecord(sl.ev_done, sd));
+    return RT_OK;
+}
+
+// AUTO: a few streams of the batch overflowed their candidate lists (one noisy SDR among hundreds): only they are
+// analysed again, on the dense path, while the records of the others stand.  The scan and detect_dense take the
+// list of streams; the records go behind the ones already in the pool (the counter word is put back first), the
+// streams' offset / count entries are simply overwritten.
+int enqueue_partial_dense(rt_handle *h, Slot &sl, int n_list, unsigned long long records_so_far) {
+    const CallCtx &c = sl.call;
+    const int n_part = std::min(h->cfg.n_streams, kMaxPartial);
+    if (!h->d_spec_part) {
+        const size_t bytes = (size_t)n_part * (size_t)h->max_seg * (size_t)h->N * sizeof(float);
+        hipError_t e = hipMalloc(&h->d_spec_part, bytes ? bytes : 4);
+        if (e != hipSuccess) {
+            h->d_spec_part = nullptr;
+            h->err = "dense spectrogram scratch for the partial re-run (" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e);
+            return RT_E_NOMEM;
+        }
+    }
+    StftParams sp = make_stft_params(h, sl, c.iq, c.stream_stride, c.n_seg, c.tail_write);
+    sp.n_streams = n_list;
+    sp.stream_list = sl.h_list;  // pinned host memory, device-visible: a few dozen scalar loads per workgroup
+    sp.spec = h->d_spec_part;
+    *sl.h_total = records_so_far;
+    RT_HIP(h, hipMemcpyAsync(sl.d_counters, sl.h_total, sizeof(unsigned long long), hipMemcpyHostToDevice, h->s_scan));
+    launch_scan<1>(h, sp, n_list * sp.blocks_per_stream, c.u8);
+    RT_HIP(h, hipGetLastError());
+    DetectArgs a = make_detect_args(h, sl, c.n_seg, h->N, c.n_seg_last);
+    a.prev = h->d_tail[c.tail_read];
+    a.prev_cols = h->K;
+    a.chunks = sp.blocks_per_stream;
+    a.spec = h->d_spec_part;
+    a.stream_list = sl.h_list;
+    hipLaunchKernelGGL(detect_dense, dim3(n_list), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
+    RT_HIP(h, hipGetLastError());
+    RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
     return RT_OK;
 }
 
@@ -464,6 +507,7 @@ void rt_destroy(rt_handle *h) {
     (void)hipFree(h->d_tw2);
     for (auto &t : h->d_tail) (void)hipFree(t);
     (void)hipFree(h->d_spec);
+    (void)hipFree(h->d_spec_part);
     for (auto &st : h->d_iq_stage) (void)hipFree(st);
     (void)hipFree(h->d_thr_s);
     (void)hipFree(h->d_cal_s);
@@ -482,6 +526,9 @@ void rt_destroy(rt_handle *h) {
         (void)hipHostFree(sl.h_rec_count);
         (void)hipHostFree(sl.h_records);
         (void)hipHostFree(sl.h_no_last);
+        (void)hipHostFree(sl.h_overflow);
+        (void)hipHostFree(sl.h_list);
+        (void)hipHostFree(sl.h_total);
         if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
         if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
@@ -696,6 +743,10 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipHostMalloc(&sl.h_records, (size_t)h->pool_cap * sizeof(rt_record)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_no_last, (size_t)S * sizeof(int32_t)));
         std::memset(sl.h_no_last, 0, (size_t)S * sizeof(int32_t));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_overflow, (size_t)S * sizeof(int32_t)));
+        std::memset(sl.h_overflow, 0, (size_t)S * sizeof(int32_t));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_list, (size_t)kMaxPartial * sizeof(int32_t)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_total, sizeof(unsigned long long)));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_begin));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_scan));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_done));
@@ -1020,11 +1071,33 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     h->info.n_seg = c.n_seg;
     h->info.n_hot = 0;
     while ((flags & kFlagHotOverflow) && !c.is_extract && c.mode_used != RT_MODE_DENSE) {
+        // which streams overflowed?  (the flags are consumed here, whatever happens next)
+        int n_bad = 0;
+        for (int s = 0; s < h->cfg.n_streams; ++s)
+            if (sl.h_overflow[s]) {
+                if (n_bad < kMaxPartial) sl.h_list[n_bad] = s;
+                ++n_bad;
+                sl.h_overflow[s] = 0;
+            }
         if (h->cfg.mode != RT_MODE_AUTO) {
             h->err = "candidate-cell capacity exceeded (hot_capacity)";
             if (peek) return kCallFailed;  // the laned rt_fetch drops this call in every lane together
             c.pending = false;
             return RT_E_HOT_OVERFLOW;
+        }
+        {
+            // a few of many: only they go dense, the handle stays on its level
+            if (n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams) {
+                const unsigned long long other = flags & ~kFlagHotOverflow;
+                int rc = enqueue_partial_dense(h, sl, n_bad, sl.h_counters[0]);
+                if (rc != RT_OK) return rc;
+                RT_HIP(h, hipEventSynchronize(sl.ev_done));
+                flags = other | sl.h_counters[2];
+                sl.h_counters[2] = flags;  // (the laned rt_fetch looks at this call twice: sizing, then delivery)
+                c.fell_back = true;
+                c.n_dense_streams = n_bad;
+                break;
+            }
         }
         // Re-run of the same buffer with the same look-back state, one level up.  Everything of this handle runs in
         // order on its own stream, so the re-run queues up behind whatever is in flight there (a later call
@@ -1068,6 +1141,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     }
     h->info.mode_used = c.mode_used;
     h->info.fell_back = c.fell_back ? 1 : 0;
+    h->info.n_dense_streams = c.n_dense_streams;
 
     const int S = h->cfg.n_streams;
     size_t total = 0;
@@ -1149,6 +1223,7 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
         h->info.n_seg = ki.n_seg;
         h->info.mode_used = i == 0 ? ki.mode_used : (ki.mode_used < h->info.mode_used ? ki.mode_used : h->info.mode_used);
         h->info.fell_back |= ki.fell_back;
+        h->info.n_dense_streams += ki.n_dense_streams;
         h->info.n_hot += ki.n_hot;
         h->info.n_records += ki.n_records;
         h->info.ms_stft += ki.ms_stft;      // sums over the lanes' launches (they overlap in time)

@@ -64,6 +64,9 @@ struct StftParams {
     uint32_t *hot_count;     // MODE 0: [S][kBuckets]
     int32_t hot_cap;         // cells per (stream, bucket)
     int32_t tbits;           // bits reserved for t in a key (2^tbits >= T)
+    const int32_t *stream_list;  // null, or the n_streams streams this launch analyses (AUTO's dense re-run of the few streams
+                             // whose candidate lists overflowed): the grid's stream index is a position in this list, per-stream
+                             // arrays are indexed by the stream it names, the dense spectrogram by the position
     uint16_t *full;          // [S][chunks][LG] per lane: bit r = "every cell of this chunk in the lane's bin r passes the
                              // absolute threshold" (chunk 0: or the cell at t = 0 does).  Written by MODE 0 / 4, read by MODE 5.
 };
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
     // Workgroups are dispatched in index order.  The ones holding a stream's last segments also write the
     // look-back tail columns and run longer; they go first so that their extra time is hidden behind the
     // rest of the launch instead of stretching its end.
-    const int s = blockIdx.x % p.n_streams;
+    const int s_pos = blockIdx.x % p.n_streams;
+    const int s = p.stream_list ? p.stream_list[s_pos] : s_pos;
     const int cb = p.blocks_per_stream - 1 - blockIdx.x / p.n_streams;
     const int chunk = cb * GPW + g;
     const bool chunk_ok = chunk < p.chunks;
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
             const int col = seg - (T - p.tail_cols);
             const bool to_spec = (MODE == 1 || MODE == 2) && active && !halo;
             const bool to_tail = SUMS && active && !halo && col >= 0;
-            float *spec_dst = p.spec + ((int64_t)s * T + seg) * N;
+            float *spec_dst = p.spec + ((int64_t)s_pos * T + seg) * N;
             float *tail_dst = p.tail + ((int64_t)s * p.tail_cols + col) * N;
             if constexpr (R3 == 1) {
                 // bin = lane + 16 r: every store instruction already writes 64-byte runs
@@ -834,6 +838,8 @@ struct DetectArgs {
     const float *cal_s;        // [S] its calibration_db (orders maxima in the shadow filter)
     const int32_t *no_last;    // [S] (host-visible) non-zero: this stream has no previous buffer in this call
                                //     (a restarted SDR's fresh analyzer, analyze.py:128)
+    const int32_t *stream_list;  // detect_dense: null, or the streams of this launch (spectrogram indexed by position, see StftParams)
+    int32_t *stream_overflow;  // [S] (host-visible) set for a stream one of whose candidate lists overflowed
     int32_t filtered;          // the candidate lists come from the run-length pre-filter (stft_scan MODE 5): a run whose
                                //     preceding cell is missing lies across the edge of the emitted chunks, is too short
                                //     to pass the duration gate and is dropped (without the filter that is an internal error)
@@ -1215,7 +1221,10 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     }
     if (n_raw == 0) return;
     if (n_raw > (uint32_t)a.hot_cap) {
-        if (!LARGE && lane == 0) atomicOr(&a.counters[2], kFlagHotOverflow);
+        if (!LARGE && lane == 0) {
+            atomicOr(&a.counters[2], kFlagHotOverflow);
+            if (a.stream_overflow) a.stream_overflow[s] = 1;
+        }
         return;
     }
     if (LARGE != (n_raw > (uint32_t)kSmallBucket)) return;
@@ -1535,7 +1544,8 @@ __device__ __forceinline__ bool scan_dense_row_blocked(const DetectParams &p, co
 // run-based form.  Phase 2/3 as in detect_sparse.
 __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int s = blockIdx.x;
+    const int s_pos = blockIdx.x;
+    const int s = a.stream_list ? a.stream_list[s_pos] : s_pos;
     const int tid = threadIdx.x;
     const int F = a.n_bins;
     const int T = a.dp.n_seg;
@@ -1545,7 +1555,7 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     __syncthreads();
 
     const DetectParams dp = stream_params(a, s);
-    const float *sp = a.spec + (int64_t)s * T * F;
+    const float *sp = a.spec + (int64_t)s_pos * T * F;
     // work items = (bin, time range): with few bins the time axis is split so that all 1024
     // threads scan (runs are owned by the range they start in)
     int Q = 1;

@@ -48,6 +48,8 @@ while time.time() < t_end:
     # round 2: a quarter of the cases with the noise floor around the absolute threshold (8 dB under .. 2 dB over): the
     # sparse path overflows, AUTO climbs to the run-length pre-filter or the dense path; decisions then sit on the noise
     noisy = bool(rng.random() < 0.25)
+    # ... and in another fifth only one or two of the streams: AUTO re-runs just those dense (n_dense_streams)
+    noisy_some = set() if noisy or n_streams < 5 or rng.random() > 0.2 else set(int(x) for x in rng.choice(n_streams, size=int(rng.integers(1, 3)), replace=False))
     lanes = int(rng.choice([1, 1, 2, 3]))
     pipelined = bool(rng.random() < 0.4)   # enqueue buffer k + 1 before fetching buffer k
     vary_len = bool(rng.random() < 0.3)    # shorter buffers than sdr_callback_length
@@ -69,7 +71,7 @@ while time.time() < t_end:
             pulses.append(synth.Pulse(max(0, k * blen - ln // 2), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.1))
             pulses.append(synth.Pulse(max(0, k * blen - ln - int(rng.integers(0, 3)) * nperseg), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.3))
         dc = complex(2e-3, -1e-3) if rng.random() < 0.3 else 0j
-        sigma = synth.NOISE_SIGMA if not noisy else float(np.sqrt(10.0 ** ((thr + rng.uniform(-8.0, 2.0)) / 10.0) * fs / 2.0))
+        sigma = synth.NOISE_SIGMA if not (noisy or s in noisy_some) else float(np.sqrt(10.0 ** ((thr + rng.uniform(-8.0, 2.0)) / 10.0) * fs / 2.0))
         iq.append(synth.make_stream(synth.StreamSpec(total, fs, pulses, dc=dc, noise_sigma=sigma), 1000 * case + s))
     iq = np.stack(iq)
     poison = os.environ.get("SOAK_POISON") == "1" and not u8 and rng.random() < 0.5
@@ -227,6 +229,6 @@ while time.time() < t_end:
     n_records += nrec
     n_bad += bad
     print(f"case {case}: N={nperseg} fs={fs} {window} T={n_seg} S={n_streams} bufs={n_buf} min/max={min_ms:.2f}/{max_ms:.1f} ms thr={thr} snr={snr} "
-          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''}{' poisoned' if poison else ''}{' noisy' if noisy else ''}{' subtract-first' if subtract_first else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
+          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''}{' poisoned' if poison else ''}{' noisy' if noisy else ''}{' noisy-streams=' + str(sorted(noisy_some)) if noisy_some else ''}{' subtract-first' if subtract_first else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
 print(f"SOAK: {n_cases} cases, {n_records} oracle records, {n_bad} mismatching stream-buffers "
       f"({n_unexplained} not explained by a float32 round-off margin, {n_field} with a field beyond 0.1 dB)")

@@ -746,6 +746,49 @@ def test_run_length_prefilter_equals_dense(threshold_dbw):
     assert len(w8) > n_streams and p8.fetch_records().tobytes() == w8.tobytes()
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_a_few_noisy_streams_go_dense_on_their_own(lanes):
+    """One or two SDRs of a batch with their noise floor over the threshold: their candidate lists overflow, the others'
+    do not.  AUTO re-runs only those streams on the dense path (rt_call_info.n_dense_streams), keeps the batch on the
+    sparse path, and returns what the dense path returns for every stream -- over consecutive buffers, pipelined."""
+    _need_gpu()
+    fs, nperseg, blen, n_streams = 300000, 256, 256 * 700, 12  # 8 ms = 9.4 hops: no pre-filter at this geometry
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(44)
+    noisy = {3, 10}
+    iq = []
+    for s in range(n_streams):
+        pulses = synth.random_pulses(rng, 3 * blen, fs, w, 9, peak_dbw=(-80.0, -62.0))
+        pulses.append(synth.Pulse(blen - int(0.006 * fs), int(0.015 * fs), (0.1 + 0.02 * s) * fs, synth.amp_for_peak_dbw(-66.0, w, fs)))
+        sigma = float(np.sqrt(10 ** (-88.0 / 10) * fs / 2)) if s in noisy else synth.NOISE_SIGMA  # floor 2 dB over the threshold
+        iq.append(synth.make_stream(synth.StreamSpec(3 * blen, fs, pulses, noise_sigma=sigma), seed=700 + s).reshape(3, blen))
+    iq = np.stack(iq)
+    kw = dict(sample_rate=fs)
+    dense = _batch_for(kw, n_streams, blen, "dense", record_capacity=2048)
+    auto = _batch_for(kw, n_streams, blen, "auto", lanes=lanes, record_capacity=2048)
+    want = []
+    for k in range(3):
+        dense.enqueue(np.ascontiguousarray(iq[:, k]))
+        want.append(dense.fetch_records())
+    # two calls in flight
+    auto.enqueue(np.ascontiguousarray(iq[:, 0]))
+    for k in range(3):
+        if k + 1 < 3:
+            auto.enqueue(np.ascontiguousarray(iq[:, k + 1]))
+        got = auto.fetch_records()
+        info = auto.native.call_info()
+        assert got.tobytes() == want[k].tobytes(), (lanes, k, len(got), len(want[k]))
+        assert info.mode_used == _native.RT_MODE_SPARSE and info.fell_back == 1 and info.n_dense_streams == len(noisy), (k, info.mode_used, info.n_dense_streams)
+    assert sum(int((w_["stream"] == 3).sum()) for w_ in want) > 0 and sum(int((w_["stream"] == 0).sum()) for w_ in want) > 0
+    # too many noisy streams for that (more than a quarter of the batch): the whole batch climbs, as before
+    many = iq[:, 0].copy()
+    many[:6] = iq[3, 0]
+    b = _batch_for(kw, n_streams, blen, "auto", record_capacity=2048)
+    b.enqueue(np.ascontiguousarray(many)); b.fetch_records()
+    info = b.native.call_info()
+    assert info.mode_used == _native.RT_MODE_DENSE and info.fell_back == 1 and info.n_dense_streams == 0
+
+
 def test_prefilter_needs_long_enough_minimum_duration():
     """chunks of L segments need signal_min_duration >= 2 L hops (L >= 4); otherwise the mode is refused and AUTO goes
     from the sparse path straight to the dense one"""
