@@ -72,6 +72,9 @@ def parse():
                     help="noise floor of the synthetic streams as a PSD per bin (default: sigma 1e-5 per component = -160 dBW at "
                          "2.048 MS/s, far under the threshold); e.g. -89 puts it 1 dB OVER the reference's -90 dBW threshold -- the "
                          "regime of a real RTL-SDR, analysed through the run-length pre-filter")
+    ap.add_argument("--noisy-streams", type=int, default=0,
+                    help="with --noise-dbw: only the first K streams of every rank get that noise floor (a few noisy SDRs in a "
+                         "batch: AUTO re-runs just those on the dense path)")
     ap.add_argument("--trains", action="store_true", default=None,
                     help="BASELINE config 5 style input: 8-16 tags per stream, pulse trains 10-38 ms, period 0.1-1 s")
     ap.add_argument("--settle", type=int, default=30,
@@ -194,9 +197,17 @@ def main():
         del iq_c
     else:
         extra = {}
+        sigma = None
         if args.noise_dbw is not None:
-            extra["noise_sigma"] = float(np.sqrt(10.0 ** (args.noise_dbw / 10.0) * fs / 2.0))  # PSD per bin = 2 sigma^2 / fs
+            sigma = float(np.sqrt(10.0 ** (args.noise_dbw / 10.0) * fs / 2.0))  # PSD per bin = 2 sigma^2 / fs
+            if not args.noisy_streams:
+                extra["noise_sigma"] = sigma
         iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=wl["trains"], first_stream=lo, **extra)
+        if sigma is not None and args.noisy_streams:
+            k = min(S, args.noisy_streams)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(seed + 7)
+            torch.view_as_real(iq)[:k].add_(torch.empty((k, blen, 2), dtype=torch.float32, device=dev).normal_(0.0, sigma, generator=gen))
     if args.threshold_dbw is not None:
         kw["signal_threshold_dbw"] = args.threshold_dbw
     stream = torch.cuda.current_stream()
@@ -273,6 +284,7 @@ def main():
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
     default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw, args.noise_dbw) == ("config2", 256, 0, "auto", "c64", None, None)
+    n_dense_streams = int(info.n_dense_streams)
     traffic, traffic_note = pmc_traffic(default_workload, lanes)
 
     # parity + CPU baseline (untimed).  N = 1: the oracle on the host cores over a bounded sample (the baseline) and the
@@ -332,6 +344,8 @@ def main():
             "settle_steps": args.settle,
             "population_seed": seed,
             "noise_floor_dbw": args.noise_dbw,
+            "noisy_streams_per_gpu": args.noisy_streams or (S if args.noise_dbw is not None else 0),
+            "streams_rerun_dense_rank0": n_dense_streams,
             "threshold_dbw": kw.get("signal_threshold_dbw", -90.0),
         },
         "roofline": {

@@ -76,6 +76,7 @@ struct Slot {
     rt_record *h_records = nullptr;                            // [pool_cap]
     int32_t *h_no_last = nullptr;                              // pinned, [S]: streams without a previous buffer in this call
     int32_t *h_overflow = nullptr;                             // pinned, [S]: set by detect_bucket for a stream whose candidate lists overflowed
+    int32_t *h_incons = nullptr;                               // pinned, [S]: ... and for one in which a run lacked its preceding cell
     int32_t *h_list = nullptr;                                 // pinned, [kMaxPartial]: the streams of a partial dense re-run (read by the kernels)
     unsigned long long *h_total = nullptr;                     // pinned: records allocated so far, uploaded before a partial re-run
     hipEvent_t ev_begin = nullptr, ev_scan = nullptr, ev_done = nullptr;
@@ -279,6 +280,7 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.cal_s = h->d_cal_s;
     a.no_last = sl.call.no_last ? sl.h_no_last : nullptr;
     a.stream_overflow = sl.h_overflow;
+    a.stream_incons = sl.h_incons;
     return a;
 }
 
@@ -527,6 +529,7 @@ void rt_destroy(rt_handle *h) {
         (void)hipHostFree(sl.h_records);
         (void)hipHostFree(sl.h_no_last);
         (void)hipHostFree(sl.h_overflow);
+        (void)hipHostFree(sl.h_incons);
         (void)hipHostFree(sl.h_list);
         (void)hipHostFree(sl.h_total);
         if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
@@ -745,6 +748,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         std::memset(sl.h_no_last, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_overflow, (size_t)S * sizeof(int32_t)));
         std::memset(sl.h_overflow, 0, (size_t)S * sizeof(int32_t));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_incons, (size_t)S * sizeof(int32_t)));
+        std::memset(sl.h_incons, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_list, (size_t)kMaxPartial * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_total, sizeof(unsigned long long)));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_begin));
@@ -1071,14 +1076,20 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     h->info.n_seg = c.n_seg;
     h->info.n_hot = 0;
     while ((flags & kFlagHotOverflow) && !c.is_extract && c.mode_used != RT_MODE_DENSE) {
-        // which streams overflowed?  (the flags are consumed here, whatever happens next)
+        // which streams overflowed?  (the flags are consumed here, whatever happens next)  The scan stops emitting for a
+        // stream once one of its lists has overflowed, so a "run without its preceding cell" in such a stream is not an
+        // internal error; in any other stream it is.
         int n_bad = 0;
-        for (int s = 0; s < h->cfg.n_streams; ++s)
+        bool incons_elsewhere = false;
+        for (int s = 0; s < h->cfg.n_streams; ++s) {
+            if (sl.h_incons[s] && !sl.h_overflow[s]) incons_elsewhere = true;
+            sl.h_incons[s] = 0;
             if (sl.h_overflow[s]) {
                 if (n_bad < kMaxPartial) sl.h_list[n_bad] = s;
                 ++n_bad;
                 sl.h_overflow[s] = 0;
             }
+        }
         if (h->cfg.mode != RT_MODE_AUTO) {
             h->err = "candidate-cell capacity exceeded (hot_capacity)";
             if (peek) return kCallFailed;  // the laned rt_fetch drops this call in every lane together
@@ -1087,8 +1098,10 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         }
         {
             // a few of many: only they go dense, the handle stays on its level
-            if (n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams) {
-                const unsigned long long other = flags & ~kFlagHotOverflow;
+            // (where the pre-filter level is still ahead, the whole batch goes there first: its second pass costs less
+            // than the fixed ~1 ms of a dense re-run of a few streams -- one workgroup per stream in detect_dense)
+            if (n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams && level_up(h, c.mode_used) == RT_MODE_DENSE) {
+                const unsigned long long other = flags & ~(kFlagHotOverflow | (incons_elsewhere ? 0ull : kFlagInconsistent));
                 int rc = enqueue_partial_dense(h, sl, n_bad, sl.h_counters[0]);
                 if (rc != RT_OK) return rc;
                 RT_HIP(h, hipEventSynchronize(sl.ev_done));
@@ -1129,6 +1142,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         h->dense_sticky = (c.mode_used == RT_MODE_SPARSE) ? 0 : 16;
     }
     if (flags & kFlagInconsistent) {
+        std::memset(sl.h_incons, 0, (size_t)h->cfg.n_streams * sizeof(int32_t));
         h->err = "internal: candidate list lacks the cell preceding a run";
         if (peek) return kCallFailedInternal;
         c.pending = false;

@@ -840,6 +840,8 @@ struct DetectArgs {
                                //     (a restarted SDR's fresh analyzer, analyze.py:128)
     const int32_t *stream_list;  // detect_dense: null, or the streams of this launch (spectrogram indexed by position, see StftParams)
     int32_t *stream_overflow;  // [S] (host-visible) set for a stream one of whose candidate lists overflowed
+    int32_t *stream_incons;    // [S] (host-visible) set for a stream in which a run lacked its preceding cell: an internal error,
+                               //     unless the stream overflowed (the scan stops emitting for such a stream, its other lists are torn)
     int32_t filtered;          // the candidate lists come from the run-length pre-filter (stft_scan MODE 5): a run whose
                                //     preceding cell is missing lies across the edge of the emitted chunks, is too short
                                //     to pass the duration gate and is dropped (without the filter that is an internal error)
@@ -1383,7 +1385,10 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
             e = t + 1;
             if (b > 0 && (first == 0 || keys[first - 1] != key0 - 1)) {
                 // the cell before a run must have been emitted by the scan (T11)
-                if (!a.filtered) atomicOr(&a.counters[2], kFlagInconsistent);
+                if (!a.filtered) {
+                    atomicOr(&a.counters[2], kFlagInconsistent);
+                    if (a.stream_incons) a.stream_incons[s] = 1;
+                }
             } else {
                 av = avg[fi / kBuckets];
                 PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};

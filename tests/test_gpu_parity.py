@@ -778,7 +778,9 @@ def test_a_few_noisy_streams_go_dense_on_their_own(lanes):
         got = auto.fetch_records()
         info = auto.native.call_info()
         assert got.tobytes() == want[k].tobytes(), (lanes, k, len(got), len(want[k]))
-        assert info.mode_used == _native.RT_MODE_SPARSE and info.fell_back == 1 and info.n_dense_streams == len(noisy), (k, info.mode_used, info.n_dense_streams)
+        # (at this geometry the pre-filter exists with chunks of 4 segments only: the batch tries it first, the two noisy
+        # streams overflow it as well, and then they alone go dense)
+        assert info.mode_used in (_native.RT_MODE_SPARSE, _native.RT_MODE_PREFILTER) and info.fell_back == 1 and info.n_dense_streams == len(noisy), (k, info.mode_used, info.n_dense_streams)
     assert sum(int((w_["stream"] == 3).sum()) for w_ in want) > 0 and sum(int((w_["stream"] == 0).sum()) for w_ in want) > 0
     # too many noisy streams for that (more than a quarter of the batch): the whole batch climbs, as before
     many = iq[:, 0].copy()
