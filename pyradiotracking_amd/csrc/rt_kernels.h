@@ -304,7 +304,7 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
 // group-wide sum) becomes "subtract sum * W[k]/N from three output bins" (six fused multiply-adds, after pass 3).
 // The host picks LIN when the window qualifies (rt_create); other windows keep the subtract-first form.
 template <int R3, int MODE, bool U8 = false, bool LIN = false>
-__global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/SIMD where the allocation would drift above 168 VGPRs
+__global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: at most 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
     constexpr bool SUMS = (MODE != 2 && MODE != 5);   // row sums and look-back tail (MODE 5 repeats chunks of a scan that wrote them)
     const int i_first = (EMIT || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (emitting modes only)
 
-    uint32_t allhot = 0xFFFFu, first_hot = 0u;  // FLAGS: the chunk's bits so far / the hot bits of segment 0
+    uint32_t allhot = 0xFFFFu;  // FLAGS: the chunk's bits so far
     uint32_t need = 0xFFFFu;                      // MODE 5: the lane's bins that may emit
     bool group_need = true;                       // MODE 5: this lane group transforms its chunk
     if constexpr (MODE == 5) {
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
                 // (it may continue a run of the previous buffer) counts whatever its length
                 if (active && !halo) {
                     allhot &= hot;
-                    if (seg == 0) first_hot = hot;
+                    if (seg == 0) allhot |= hot;  // (segment 0 is the last step of chunk 0: nothing is and-ed in after it)
                 }
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(kBlock, (R3 == 1 || R3 >= 8) ? 3 : 1)  // 3 waves/S
         if (stg_n) flush_stage(p, s, stg, stg_n);
     }
     if constexpr (FLAGS) {
-        if (p.full && chunk_ok) p.full[((int64_t)s * p.chunks + chunk) * LG + lt] = (uint16_t)((allhot | first_hot) & 0xFFFFu);
+        if (p.full && chunk_ok) p.full[((int64_t)s * p.chunks + chunk) * LG + lt] = (uint16_t)(allhot & 0xFFFFu);
     }
     if constexpr (MODE == 3) {
         if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
