@@ -676,9 +676,11 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
                     // consecutive elements (conflict-free with any skew)
                     constexpr int kSkew = (R3 == 16) ? 2 : (R3 == 8) ? 4 : (R3 == 4) ? 1 : 0;
                     group_sync<LG>();  // every wave of the group is done with its exchange rows
+                    int lt_w = lt;  // opaque, so that the sixteen lane-constant row offsets are not hoisted out of the step loop
+                    asm volatile("" : "+v"(lt_w));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int bin = bin_of<R3>(lt, r);
+                        const int bin = bin_of<R3>(lt_w, r);
                         row[bin + kSkew * (bin >> 5)] = P[r];
                     }
                     group_sync<LG>();
@@ -719,9 +721,14 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
             const uint32_t emit = (EMIT && active && !halo) ? ((hot | next_hot) & need) : 0u;
-            if (EMIT && !gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare
+            if (EMIT && RT_ABLATE != 9 && !gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare (RT_ABLATE 9: test without emission)
                 // Candidates are staged per wave in LDS and flushed with ONE returned atomic per
                 // flush: an atomic per cell would stall on vmcnt(0) and drain the prefetch.
+                // (the lane index is made opaque here: otherwise hipcc hoists the sixteen lane-constant key bases
+                // bin_of(lt, r) << tbits out of the step loop, where they cost registers the hot path is short of --
+                // the mere presence of this rare block made the kernel 4 % slower at nperseg 256 and 8 % at 1024)
+                int lt_e = lt;
+                asm volatile("" : "+v"(lt_e));
                 int need = 0;  // cells this wave emits in this step (scalar arithmetic on ballots)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) need += __builtin_popcountll(__builtin_amdgcn_ballot_w64((emit >> r) & 1u));
@@ -736,7 +743,7 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
                         const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
                         if (mine) {
                             const int off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                            const uint32_t key = ((uint32_t)bin_of<R3>(lt, r) << p.tbits) | (uint32_t)seg;
+                            const uint32_t key = ((uint32_t)bin_of<R3>(lt_e, r) << p.tbits) | (uint32_t)seg;
                             stg[stg_n + off] = make_uint2(key, __float_as_uint(P[r]));
                         }
                         stg_n += __builtin_popcountll(m);
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
 #pragma unroll
                     for (int r = 0; r < 16 && !gave_up; ++r) {
                         if (emit & (1u << r)) {
-                            const int bin = bin_of<R3>(lt, r);
+                            const int bin = bin_of<R3>(lt_e, r);
                             const int bkt = bin & (kBuckets - 1);
                             const uint32_t slot = atomicAdd(&p.hot_count[s * kBuckets + bkt], 1u);
                             if (slot < (uint32_t)p.hot_cap) {
