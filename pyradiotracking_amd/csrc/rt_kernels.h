@@ -707,9 +707,10 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
             mx = __builtin_fmaxf(mx, P[15]);
             uint32_t hot = 0;
             if (active && !(mx < thr)) {
+                // bit r = !(P[r] < thr), built by shifting (v_lshl_or_b32): `hot |= 1u << r` made hipcc keep the nine
+                // literals 128 .. 32768 in VGPRs across the whole step loop (a select cannot take a literal on gfx9)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (!(P[r] < thr)) hot |= (1u << r);
+                for (int r = 15; r >= 0; --r) hot = (hot << 1) | ((P[r] < thr) ? 0u : 1u);
             }
             if constexpr (FLAGS) {
                 // pre-filter bits: every cell of the chunk so far at or above the threshold; the run through t = 0
