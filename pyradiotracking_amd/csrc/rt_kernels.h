@@ -304,7 +304,13 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
 // group-wide sum) becomes "subtract sum * W[k]/N from three output bins" (six fused multiply-adds, after pass 3).
 // The host picks LIN when the window qualifies (rt_create); other windows keep the subtract-first form.
 template <int R3, int MODE, bool U8 = false, bool LIN = false>
-__global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: at most 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
+// Experiment switch (default off): -DRT_WG4_MAX_R3=1 runs nperseg 256 at four workgroups per CU (its kernels need
+// <= 124 VGPRs and, with 32 staged cells per wave, exactly 40 960 B of LDS).  Measured in round 2: one lane 0.792 ->
+// 0.826 ms, two lanes 0.766 -> 0.788 ms per step (uint8 input +3 %): more waves do not help the complex64 scan.
+#ifndef RT_WG4_MAX_R3
+#define RT_WG4_MAX_R3 0
+#endif
+__global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
@@ -312,8 +318,22 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
     constexpr int GPW = kBlock / LG;  // lane groups per workgroup
     constexpr int G = 16 / R3;
 
-    __shared__ __attribute__((aligned(16))) cf xch[kBlock * kRowF2];
-    __shared__ cf red[kBlock / 64];
+    // One LDS block carved by hand: at nperseg 256 the pieces add up to exactly 40 960 B, a quarter of a CU's LDS
+    // (separate __shared__ arrays cannot have size zero, and their placeholders cost the fourth workgroup).
+    constexpr bool W_IN_LDS = (R3 <= 8);  // N = 4096: the window comes from L2 as well (3 workgroups per CU)
+    constexpr bool T1_IN_LDS = (R3 <= 4);
+    constexpr bool T1_FACTORED = !T1_IN_LDS;
+    constexpr int kStage = (R3 <= RT_WG4_MAX_R3) ? 32 : kStageCap;  // candidate cells staged per wave before a flush
+    constexpr size_t kXchB = sizeof(cf) * kBlock * kRowF2;
+    constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (kBlock / 64) : 0;
+    constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
+    constexpr size_t kT1fB = T1_FACTORED ? sizeof(float4) * 2 * LG : 0;
+    constexpr size_t kT1B = T1_IN_LDS ? sizeof(float4) * 8 * LG : 0;
+    constexpr size_t kT2B = (R3 > 1) ? sizeof(float4) * 8 * R3 : 0;
+    constexpr size_t kStageB = (MODE == 0 || MODE == 5) ? sizeof(uint2) * (kBlock / 64) * kStage : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB];
+    cf *const xch = reinterpret_cast<cf *>(lds_block);
+    cf *const red = reinterpret_cast<cf *>(lds_block + kXchB);
 
     const int tid = threadIdx.x;
     const int g = tid / LG;
@@ -336,17 +356,14 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
     // read them (16-byte pieces, consecutive lanes -> consecutive pieces), and
     // read just in time: keeping them in VGPRs would cost 62 registers per lane
     // and a wave per SIMD of occupancy.
-    constexpr bool W_IN_LDS = (R3 <= 8);  // N = 4096: the window comes from L2 as well (3 workgroups per CU)
-    __shared__ __attribute__((aligned(16))) float4 w_lds[W_IN_LDS ? 4 * LG : 1];    // [m/4][lane]: w[lane + LG*(4*(m/4) + 0..3)]
-    constexpr bool T1_IN_LDS = (R3 <= 4);
+    float4 *const w_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB);    // [m/4][lane]: w[lane + LG*(4*(m/4) + 0..3)]
     // N >= 2048: the full table (128 B per lane) does not fit LDS next to the exchange rows at 3 workgroups
     // per CU, and read from L2 it doubles the step's L1 fill traffic (measured +0.2 .. +0.34 ms per launch).
     // Only W^(a), W^(2a), W^(4a), W^(8a) are staged (32 B per lane); the other eleven factors are products
     // of two to four of them (W^(a k) with k in binary), 44 more VALU operations per step.
-    constexpr bool T1_FACTORED = !T1_IN_LDS;
-    __shared__ __attribute__((aligned(16))) float4 t1f_lds[T1_FACTORED ? 2 * LG : 1];  // [0][lane] = (W^a, W^2a), [1][lane] = (W^4a, W^8a)
-    __shared__ __attribute__((aligned(16))) float4 t1_lds[T1_IN_LDS ? 8 * LG : 1];   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
-    __shared__ __attribute__((aligned(16))) float4 t2_lds[R3 > 1 ? 8 * R3 : 1];  // [q/2][b]
+    float4 *const t1f_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB);  // [0][lane] = (W^a, W^2a), [1][lane] = (W^4a, W^8a)
+    float4 *const t1_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB + kT1fB);   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
+    float4 *const t2_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B);  // [q/2][b]
     if constexpr (W_IN_LDS) {
         for (int idx = tid; idx < 4 * LG; idx += kBlock) {
             const int mm = idx / LG, l = idx % LG;
@@ -396,9 +413,9 @@ __global__ __launch_bounds__(kBlock, 3)  // 3 workgroups per CU = 3 waves/SIMD: 
     }
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
     // candidate staging: 128 cells per wave, flushed with one returned atomic per bucket
-    __shared__ uint2 stage[(MODE == 0 || MODE == 5) ? (kBlock / 64) * kStageCap : 1];
-    uint2 *stg = stage + ((MODE == 0 || MODE == 5) ? (tid >> 6) * kStageCap : 0);  // this wave's staging area
-    constexpr int kStageLimit = kStageCap;
+    uint2 *const stage = reinterpret_cast<uint2 *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B);
+    uint2 *stg = stage + ((MODE == 0 || MODE == 5) ? (tid >> 6) * kStage : 0);  // this wave's staging area
+    constexpr int kStageLimit = kStage;
     int stg_n = 0;                                                    // wave-uniform fill level
     bool gave_up = false;  // wave-uniform: a candidate list of this stream has overflowed, the call will be re-run dense
 
