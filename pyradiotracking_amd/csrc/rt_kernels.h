@@ -310,7 +310,7 @@ template <int R3, int MODE, bool U8 = false, bool LIN = false>
 #ifndef RT_WG4_MAX_R3
 #define RT_WG4_MAX_R3 0
 #endif
-__global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
+__global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
@@ -323,7 +323,8 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3) ? 4 : 3)  // workgrou
     constexpr bool W_IN_LDS = (R3 <= 8);  // N = 4096: the window comes from L2 as well (3 workgroups per CU)
     constexpr bool T1_IN_LDS = (R3 <= 4);
     constexpr bool T1_FACTORED = !T1_IN_LDS;
-    constexpr int kStage = (R3 <= RT_WG4_MAX_R3) ? 32 : kStageCap;  // candidate cells staged per wave before a flush
+    // (uint8 input at nperseg 256 does run at four workgroups per CU: 106 VGPRs, +3 %)
+    constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 32 : kStageCap;  // candidate cells staged per wave before a flush
     constexpr size_t kXchB = sizeof(cf) * kBlock * kRowF2;
     constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (kBlock / 64) : 0;
     constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
