@@ -63,9 +63,10 @@ struct Slot {
     uint2 *d_hot = nullptr;
     uint32_t *d_hot_count = nullptr;
     uint32_t *d_hot_seen = nullptr;
+    int32_t *d_items = nullptr;       // [S][max_blocks][GPW] chunks of pass B's workgroups, then [S] their number per stream (with d_full)
     int32_t *h_hot_total = nullptr;   // pinned, [S]
     float *d_psum = nullptr;
-    uint16_t *d_full = nullptr;       // [S][max_chunks][LG] chunk bits of the run-length pre-filter (null: not available)
+    uint16_t *d_full = nullptr;       // [S][max_chunks][LG] chunk bits of the run-length pre-filter, then [S][L][LG] bits of chunk 0 by segment (null: not available)
     rt_record *d_raw = nullptr;
     int32_t *d_raw_count = nullptr;
     unsigned long long *d_counters = nullptr;  // 4 words (atomics: device memory)
@@ -93,6 +94,7 @@ struct rt_handle {
     int L = 32;            // segments per chunk
     int max_seg = 0;       // T for max_samples
     int max_chunks = 0;
+    int max_blocks = 0;  // workgroups per stream at max_chunks
     hipStream_t s_scan = nullptr;
     bool own_scan_stream = false;
     std::string err;
@@ -239,6 +241,9 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.hot_cap = h->hot_cap;
     p.tbits = key_tbits(n_seg);
     p.full = sl.d_full;
+    p.first = sl.d_full ? sl.d_full + (size_t)h->cfg.n_streams * h->max_chunks * h->LG : nullptr;
+    p.item_chunks = sl.d_items;
+    p.item_count = sl.d_items ? sl.d_items + (size_t)h->cfg.n_streams * h->max_blocks * h->GPW : nullptr;
     return p;
 }
 
@@ -348,6 +353,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         launch_scan<1>(h, sp, blocks, c.u8);
     } else if (mode == RT_MODE_PREFILTER) {
         if (!second_pass_only) launch_scan<4>(h, sp, blocks, c.u8);
+        hipLaunchKernelGGL(plan_pass_b, dim3(S), dim3(256), sizeof(uint32_t) * ((sp.chunks + 31) / 32), h->s_scan, sp.full, sp.first,
+                           sp.item_chunks, sp.item_count, h->LG, sp.segs_per_chunk, c.n_seg, sp.chunks, sp.blocks_per_stream, h->GPW);
         launch_scan<5>(h, sp, blocks, c.u8);
     } else {
         launch_scan<0>(h, sp, blocks, c.u8);
@@ -517,6 +524,7 @@ void rt_destroy(rt_handle *h) {
         (void)hipFree(sl.d_hot);
         (void)hipFree(sl.d_hot_count);
         (void)hipFree(sl.d_hot_seen);
+        (void)hipFree(sl.d_items);
         (void)hipHostFree(sl.h_hot_total);
         (void)hipFree(sl.d_psum);
         (void)hipFree(sl.d_full);
@@ -606,12 +614,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->L = choose_chunk(h, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
     const int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
+    h->max_blocks = max_blocks_per_stream;
     {
         // Run-length pre-filter: a run shorter than r_min cells (and not through t = 0) fails the duration gate whatever
         // else holds -- (len + 1) * hop < signal_min_duration (analyze.py:427-430; rt_core.h: gate_run), with a margin of
         // 1e-9 for the rounding of the float64 expressions.  A run of >= 2 L - 1 cells covers an aligned chunk of L.
         const long long r_min = min_run_cells(h);
-        h->prefilter_ok = h->L >= 4 && 2ll * h->L - 1 <= r_min && h->max_seg >= 2 * h->L;
+        h->prefilter_ok = h->L >= 4 && 2ll * h->L - 1 <= r_min && h->max_seg >= 2 * h->L &&
+                          h->max_chunks <= (1 << 18);  // (plan_pass_b keeps a bit per chunk in LDS)
         if (cfg->mode == RT_MODE_PREFILTER && !h->prefilter_ok) {
             delete h;
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_PREFILTER needs signal_min_duration >= 2 * segs_per_chunk STFT hops");
@@ -727,7 +737,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     for (auto &sl : h->slot) {
         RT_CREATE_HIP(hipMalloc(&sl.d_psum, std::max<size_t>(psum_bytes, 4)));
         if (h->prefilter_ok && cfg->mode != RT_MODE_DENSE)
-            RT_CREATE_HIP(hipMalloc(&sl.d_full, (size_t)S * h->max_chunks * LG * sizeof(uint16_t)));
+            RT_CREATE_HIP(hipMalloc(&sl.d_full, (size_t)S * (h->max_chunks + h->L) * LG * sizeof(uint16_t)));  // + the bits of chunk 0 by segment
+        if (sl.d_full) RT_CREATE_HIP(hipMalloc(&sl.d_items, ((size_t)S * h->max_blocks * h->GPW + S) * sizeof(int32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot, (size_t)S * kBuckets * h->hot_cap * sizeof(uint2)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_count, (size_t)S * kBuckets * sizeof(uint32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_seen, (size_t)S * kBuckets * sizeof(uint32_t)));

@@ -68,15 +68,22 @@ struct StftParams {
                              // whose candidate lists overflowed): the grid's stream index is a position in this list, per-stream
                              // arrays are indexed by the stream it names, the dense spectrogram by the position
     uint16_t *full;          // [S][chunks][LG] per lane: bit r = "every cell of this chunk in the lane's bin r passes the
-                             // absolute threshold" (chunk 0: or the cell at t = 0 does).  Written by MODE 0 / 4, read by MODE 5.
+                             // absolute threshold".  Written by MODE 0 / 4, read by MODE 5.
+    uint16_t *first;         // [S][segs_per_chunk][LG] per lane: MODE 0 / 4 write bit r = "the cell (t, lane's bin r) passes it" for
+                             // the segments t of chunk 0; plan_pass_b turns that into "every cell 0 .. t does"; read by MODE 5
+    int32_t *item_chunks;    // [S][blocks_per_stream][lane groups per workgroup] MODE 5: the chunks a workgroup transforms (plan_pass_b;
+                             // `chunks` = none), item_count[s] workgroups per stream
+    int32_t *item_count;     // [S]
 };
 
 // Run-length pre-filter (inputs whose noise crosses the absolute threshold, so that MODE 0 overflows its candidate
 // lists).  A run can only become a signal if it is at least `stride - 1` cells long (rt_core.h: gate_run, the duration
 // gate) or reaches back into the previous buffer (then it contains t = 0).  With chunks of L <= stride / 2 segments a
 // run of that length covers at least one aligned chunk completely.  So:
-//   pass A (MODE 4, or MODE 0 itself before it overflowed): per (stream, chunk, bin) one bit "all L cells >= thr"
-//          (chunk 0: "... or the cell at t = 0 is") next to everything a scan writes (row sums, look-back tail);
+//   pass A (MODE 4, or MODE 0 itself before it overflowed): per (stream, chunk, bin) one bit "all L cells >= thr",
+//          and the threshold bits of chunk 0 cell by cell (a run through t = 0 either ends inside chunk 0 or makes
+//          chunk 0 all hot; prefix_first and-s them up from t = 0, which leaves exactly the cells of such runs),
+//          next to everything a scan writes (row sums, look-back tail);
 //   pass B (MODE 5): only the chunks with a set bit in themselves or a neighbour are transformed again, and only the
 //          flagged bins emit candidate cells.  Every chunk a qualifying run touches is flagged or next to a flagged
 //          one, so the detect kernels see those runs complete; what they see of other runs is too short to pass the
@@ -345,7 +352,13 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     const int s_pos = blockIdx.x % p.n_streams;
     const int s = p.stream_list ? p.stream_list[s_pos] : s_pos;
     const int cb = p.blocks_per_stream - 1 - blockIdx.x / p.n_streams;
-    const int chunk = cb * GPW + g;
+    int chunk = cb * GPW + g;
+    if constexpr (MODE == 5) {
+        // pass B of the run-length pre-filter: the stream's workgroups take the chunks plan_pass_b packed for them
+        const int item = blockIdx.x / p.n_streams;
+        if (item >= p.item_count[s]) return;
+        chunk = p.item_chunks[((int64_t)s * p.blocks_per_stream + item) * GPW + g];
+    }
     const bool chunk_ok = chunk < p.chunks;
     const int c0 = chunk * p.segs_per_chunk;
     const int T = p.n_seg;
@@ -427,21 +440,25 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     const int i_first = (EMIT || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (emitting modes only)
 
     uint32_t allhot = 0xFFFFu;  // FLAGS: the chunk's bits so far
-    uint32_t need = 0xFFFFu;                      // MODE 5: the lane's bins that may emit
+    uint32_t need = 0xFFFFu;                      // MODE 5: the lane's bins that may emit in every segment of the chunk
+    uint32_t first_nxt = 0u;                      // MODE 5, chunk 0: the bins whose run through t = 0 reaches the requested segment
     bool group_need = true;                       // MODE 5: this lane group transforms its chunk
     if constexpr (MODE == 5) {
         need = 0u;
+        uint32_t need_run = 0u;
         if (chunk_ok) {
             const uint16_t *f = p.full + ((int64_t)s * p.chunks + chunk) * LG + lt;
             need = f[0];
             if (chunk > 0) need |= f[-LG];
             if (chunk + 1 < p.chunks) need |= f[LG];
+            need_run = need;
+            if (chunk == 0) need_run |= p.first[(int64_t)s * p.segs_per_chunk * LG + lt];  // any run through t = 0
         }
         if constexpr (LG > 64) {
             // the step loop has workgroup barriers: the whole workgroup (1 or 2 chunks) goes or stays
-            if (!__syncthreads_or(need != 0u)) return;
+            if (!__syncthreads_or(need_run != 0u)) return;
         } else {
-            const unsigned long long any = __builtin_amdgcn_ballot_w64(need != 0u);
+            const unsigned long long any = __builtin_amdgcn_ballot_w64(need_run != 0u);
             if (any == 0ull) return;  // nothing below needs this wave (no workgroup barrier follows in MODE 5)
             // the wave runs, but the lane groups whose chunk is not needed request no memory and emit nothing
             if constexpr (LG < 64) group_need = ((any >> ((threadIdx.x & 63) & ~(LG - 1))) & ((1ull << LG) - 1ull)) != 0ull;
@@ -460,6 +477,10 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     constexpr bool BUF_LOADS = (LG >= 64);
     const int chunk_u = BUF_LOADS ? __builtin_amdgcn_readfirstlane(chunk) : 0;
     auto request_segment = [&](int seg_req) {
+        if constexpr (MODE == 5) {
+            first_nxt = 0u;
+            if (chunk == 0 && chunk_ok && seg_req < L) first_nxt = p.first[((int64_t)s * L + seg_req) * LG + lt];
+        }
         if constexpr (BUF_LOADS) {
             const int sg = __builtin_amdgcn_readfirstlane(chunk_u * L + (seg_req - c0));  // == seg_req, in SGPRs
 #ifdef RT_EXP_ALIAS
@@ -493,6 +514,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
         cf v[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = to_cf(nxt[m]);
+        const uint32_t need_seg = need | first_nxt;  // (first_nxt was requested for this step's segment)
         // N = 4096: the window comes from L2.  Vector-memory operations return in order, so these loads must be
         // issued BEFORE the next segment's: waiting for them afterwards (`s_waitcnt vmcnt(0)`) would wait for the
         // whole prefetch, i.e. expose an HBM round trip in every step (it did: 1.01 ms per launch).
@@ -735,11 +757,15 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                 // (it may continue a run of the previous buffer) counts whatever its length
                 if (active && !halo) {
                     allhot &= hot;
-                    if (seg == 0) allhot |= hot;  // (segment 0 is the last step of chunk 0: nothing is and-ed in after it)
+                    if (chunk == 0 && p.full) {  // (lane index opaque: the address stays out of the loop's registers)
+                        int lt_f = lt;
+                        asm volatile("" : "+v"(lt_f));
+                        p.first[((int64_t)s * L + seg) * LG + lt_f] = (uint16_t)hot;
+                    }
                 }
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
-            const uint32_t emit = (EMIT && active && !halo) ? ((hot | next_hot) & need) : 0u;
+            const uint32_t emit = (EMIT && active && !halo) ? ((hot | next_hot) & need_seg) : 0u;
             if (EMIT && RT_ABLATE != 9 && !gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare (RT_ABLATE 9: test without emission)
                 // Candidates are staged per wave in LDS and flushed with ONE returned atomic per
                 // flush: an atomic per cell would stall on vmcnt(0) and drain the prefetch.
@@ -821,6 +847,61 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             dst[bin] = sum;
         }
     }
+}
+
+// Run-length pre-filter, between pass A and pass B, one workgroup per stream:
+//   * the threshold bits of chunk 0 become "every cell from t = 0 up to this one passes" -- the cells of the runs
+//     that may continue a run of the previous buffer, which count whatever their length (idempotent);
+//   * the chunks pass B has to transform again (a set bit in the chunk itself or a neighbour, chunk 0 also for a hot
+//     cell at t = 0) are packed `gpw` to a workgroup: in the noise-floor regime a fifth of the chunks is needed, spread
+//     so that most workgroups of a one-to-one launch would keep one wave busy and three idle.
+// Dynamic LDS: one bit per chunk.
+__global__ __launch_bounds__(256) void plan_pass_b(const uint16_t *full, uint16_t *first, int32_t *item_chunks, int32_t *item_count,
+                                                   int lg, int segs_per_chunk, int n_seg, int chunks, int blocks_per_stream, int gpw) {
+    extern __shared__ uint32_t plan_lds[];
+    uint32_t *const any_w = plan_lds;  // [(chunks + 31) / 32]
+    __shared__ uint32_t first_any, wave_cnt[4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int words = (chunks + 31) / 32;
+    for (int i = tid; i < words; i += 256) any_w[i] = 0u;
+    if (tid == 0) first_any = 0u;
+    __syncthreads();
+    if (tid < lg) {
+        uint16_t *f = first + (int64_t)s * segs_per_chunk * lg + tid;
+        if (f[0]) atomicOr(&first_any, 1u);
+        uint16_t m = 0xFFFFu;
+        const int n = segs_per_chunk < n_seg ? segs_per_chunk : n_seg;
+        for (int t = 0; t < n; ++t) {
+            m &= f[(int64_t)t * lg];
+            f[(int64_t)t * lg] = m;
+        }
+    }
+    const uint16_t *fs = full + (int64_t)s * chunks * lg;
+    for (int64_t i = tid; i < (int64_t)chunks * lg; i += 256) {
+        if (fs[i]) {
+            const int c = (int)(i / lg);
+            atomicOr(&any_w[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    auto bit = [&](int c) -> bool { return c >= 0 && c < chunks && ((any_w[c >> 5] >> (c & 31)) & 1u); };
+    int32_t *items = item_chunks + (int64_t)s * blocks_per_stream * gpw;
+    int base = 0;  // workgroup-uniform: needed chunks below this tile
+    for (int c0 = 0; c0 < chunks; c0 += 256) {
+        const int c = c0 + tid;
+        const bool needed = c < chunks && (bit(c - 1) || bit(c) || bit(c + 1) || (c == 0 && first_any));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(needed);
+        if ((tid & 63) == 0) wave_cnt[tid >> 6] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < (tid >> 6); ++w) off += (int)wave_cnt[w];
+        if (needed) items[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = c;
+        base += (int)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+        __syncthreads();
+    }
+    const int n_items = (base + gpw - 1) / gpw;
+    for (int i = base + tid; i < n_items * gpw; i += 256) items[i] = chunks;  // the last workgroup's idle lane groups
+    if (tid == 0) item_count[s] = n_items;
 }
 
 // ---------------------------------------------------------------------------

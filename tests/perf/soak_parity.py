@@ -48,6 +48,12 @@ while time.time() < t_end:
     # round 2: a quarter of the cases with the noise floor around the absolute threshold (8 dB under .. 2 dB over): the
     # sparse path overflows, AUTO climbs to the run-length pre-filter or the dense path; decisions then sit on the noise
     noisy = bool(rng.random() < 0.25)
+    if BIG and noisy:
+        # the oracle walks every run of a noisy spectrogram in Python: minutes per stream at the BIG sizes
+        n_streams = min(n_streams, 16)
+        if n_seg > 2000 * 256 // nperseg:
+            n_seg = 2000 * 256 // nperseg
+            blen = n_seg * nperseg + blen % nperseg
     # ... and in another fifth only one or two of the streams: AUTO re-runs just those dense (n_dense_streams)
     noisy_some = set() if noisy or n_streams < 5 or rng.random() > 0.2 else set(int(x) for x in rng.choice(n_streams, size=int(rng.integers(1, 3)), replace=False))
     lanes = int(rng.choice([1, 1, 2, 3]))

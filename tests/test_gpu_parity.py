@@ -701,6 +701,8 @@ def _noisy_batch(n_streams, blen, fs, nperseg, seed, noise_sigma=1e-5, peak_dbw=
         pulses = synth.random_pulses(rng, n_buffers * blen, fs, w, 5 * n_buffers, peak_dbw=peak_dbw)
         pulses.append(synth.Pulse(blen - int(0.005 * fs) - 11 * s, int(0.015 * fs), (0.05 + 0.04 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))
         pulses.append(synth.Pulse(0, int(0.011 * fs), (-0.3 + 0.03 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))  # a run that starts at t = 0
+        # ... and one that reaches only 4 .. 20 segments into the next buffer: its run through t = 0 ends inside the first chunk
+        pulses.append(synth.Pulse(blen - int(0.015 * fs) + (4 + 3 * s) * nperseg, int(0.015 * fs), (0.31 + 0.02 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))
         out.append(synth.make_stream(synth.StreamSpec(n_buffers * blen, fs, pulses, noise_sigma=noise_sigma), seed=900 + s).reshape(n_buffers, blen))
     return np.stack(out)  # [S, n_buffers, B]
 
@@ -719,7 +721,7 @@ def test_run_length_prefilter_equals_dense(threshold_dbw):
     pre = _batch_for(kw, n_streams, blen, "prefilter")
     auto = _batch_for(kw, n_streams, blen, "auto")
     lanes = _batch_for(kw, n_streams, blen, "auto", lanes=2)
-    n_neg = n_zero = 0
+    n_neg = n_zero = n_short = 0
     for k in range(2):
         chunk = np.ascontiguousarray(iq[:, k])
         for b in (dense, pre, auto, lanes):
@@ -736,7 +738,10 @@ def test_run_length_prefilter_equals_dense(threshold_dbw):
             assert info.mode_used == _native.RT_MODE_PREFILTER and info.fell_back == (1 if k == 0 else 0), (k, info.mode_used, info.fell_back)
         n_neg += int((want["start"] < 0).sum())
         n_zero += int((want["start"] == 0).sum())
-    assert n_neg > 0 and n_zero > 0  # runs across the boundary and runs from t = 0 of the first buffer were among them
+        n_short += int(((want["start"] < 0) & (want["end"] < 32)).sum())
+    # runs across the boundary, runs from t = 0 of the first buffer, and runs across it that end inside the second
+    # buffer's first chunk (only the cells up to their end are emitted there) were among them
+    assert n_neg > 0 and n_zero > 0 and n_short >= n_streams // 2, (n_neg, n_zero, n_short)
     # the same streams as the RTL-SDR wire format (quantised): uint8 through the same two passes
     raw = synth.quantize_u8(iq[:, 0], gain=2000.0)
     kw8 = dict(sample_rate=fs, signal_threshold_dbw=threshold_dbw + 66.0)  # the gain of 2000 is 66 dB
