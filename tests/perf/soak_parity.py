@@ -51,6 +51,8 @@ while time.time() < t_end:
     if BIG and noisy:
         # the oracle walks every run of a noisy spectrogram in Python: minutes per stream at the BIG sizes
         n_streams = min(n_streams, 16)
+        if isinstance(cal, list):
+            cal = cal[:n_streams]
         if n_seg > 2000 * 256 // nperseg:
             n_seg = 2000 * 256 // nperseg
             blen = n_seg * nperseg + blen % nperseg
