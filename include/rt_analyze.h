@@ -151,7 +151,9 @@ int rt_reset_stream(rt_handle *h, int32_t stream);
  * `calibration_db` are HOST arrays of n_streams float32 (linear threshold; calibration in dB, used as in
  * rt_config to order maxima in the shadow filter); either may be NULL = keep rt_config's value for every
  * stream.  Applies to calls enqueued afterwards; refused (RT_E_INVALID) while unfetched calls are pending, since
- * AUTO mode may still re-run those with the thresholds they were enqueued with.  [SURVEY 8(f) rank 4]
+ * AUTO mode may still re-run those with the thresholds they were enqueued with.  A stream whose threshold CHANGES
+ * starts its next buffer without look-back, as after rt_reset_stream: in the reference a threshold is fixed
+ * when the SignalAnalyzer is built (analyze.py:115), so a new one means a new analyzer.  [SURVEY 8(f) rank 4]
  */
 int rt_set_stream_params(rt_handle *h, const float *threshold, const float *calibration_db);
 

@@ -93,6 +93,7 @@ struct rt_handle {
     int stride = 1;        // probe stride
     int L = 32;            // segments per chunk
     int max_seg = 0;       // T for max_samples
+    std::vector<float> h_thr_s;  // host copy of the per-stream thresholds (empty: rt_config's for every stream)
     int max_chunks = 0;
     int max_blocks = 0;  // workgroups per stream at max_chunks
     hipStream_t s_scan = nullptr;
@@ -831,6 +832,18 @@ int rt_set_stream_params(rt_handle *h, const float *threshold, const float *cali
         RT_HIP(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
         return RT_OK;
     };
+    // A stream whose threshold changes starts without look-back: the reference fixes the threshold when a SignalAnalyzer is
+    // built (analyze.py:115), a new one needs a new analyzer (_spectrogram_last = None) -- and the sparse scans keep only
+    // those tail cells a walk with the threshold of their own call can reach (rt_kernels.h: sparse tail).
+    for (int s = 0; s < h->cfg.n_streams; ++s) {
+        const float was = h->h_thr_s.empty() ? h->cfg.threshold : h->h_thr_s[(size_t)s];
+        const float is = threshold ? threshold[s] : h->cfg.threshold;
+        if (!(was == is)) {
+            h->reset_pending[(size_t)s] = 1;
+            h->any_reset_pending = true;
+        }
+    }
+    if (threshold) h->h_thr_s.assign(threshold, threshold + h->cfg.n_streams); else h->h_thr_s.clear();
     int rc = put(h->d_thr_s, threshold);
     if (rc != RT_OK) return rc;
     return put(h->d_cal_s, calibration_db);

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     // (uint8 input at nperseg 256 does run at four workgroups per CU: 106 VGPRs, +3 %)
     constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 32 : kStageCap;  // candidate cells staged per wave before a flush
     constexpr size_t kXchB = sizeof(cf) * kBlock * kRowF2;
-    constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (kBlock / 64) : 0;
+    constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (kBlock / 64) + 16 : 0;  // + the three tail_any words
     constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
     constexpr size_t kT1fB = T1_FACTORED ? sizeof(float4) * 2 * LG : 0;
     constexpr size_t kT1B = T1_IN_LDS ? sizeof(float4) * 8 * LG : 0;
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB];
     cf *const xch = reinterpret_cast<cf *>(lds_block);
     cf *const red = reinterpret_cast<cf *>(lds_block + kXchB);
+    uint32_t *const tail_any = reinterpret_cast<uint32_t *>(lds_block + kXchB + sizeof(cf) * (kBlock / 64));  // LG > 64, see the tail columns below
 
     const int tid = threadIdx.x;
     const int g = tid / LG;
@@ -405,6 +406,9 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             const cf x = p.tw2[b * 16 + 2 * kk], y = p.tw2[b * 16 + 2 * kk + 1];
             t2_lds[idx] = make_float4(x.x, x.y, y.x, y.y);
         }
+    }
+    if constexpr (LG > 64) {
+        if (tid < 3) tail_any[tid] = (tid == 1) ? 1u : 0u;  // the first step (i = 1) writes its whole column
     }
     __syncthreads();
 
@@ -684,6 +688,14 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             const bool to_tail = SUMS && active && !halo && col >= 0;
             float *spec_dst = p.spec + ((int64_t)s_pos * T + seg) * N;
             float *tail_dst = p.tail + ((int64_t)s * p.tail_cols + col) * N;
+            // Sparse tail (the scans that keep threshold bits, MODE 0 / 4): the next buffer's look-back walks down from
+            // the last segment while the cells pass the absolute threshold and stops ON the first that does not
+            // (rt_core.h: walk_start; cell_above implies >= thr), so it can only reach a cell whose later cells are all
+            // hot.  A cell is written iff the later cells OF ITS CHUNK are -- `allhot` before this step's update, all
+            // ones at the chunk's last segment: a superset (a walk that crosses into a chunk enters at its last
+            // segment), one column per chunk instead of 32 on sparse input.  Cells not written keep stale values
+            // that no walk reaches.  The dense scan (MODE 1) writes every cell.
+            const uint32_t tail_mask = FLAGS ? allhot : 0xFFFFu;
             if constexpr (R3 == 1) {
                 // bin = lane + 16 r: every store instruction already writes 64-byte runs
                 if (to_spec) {
@@ -691,8 +703,17 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                     for (int r = 0; r < 16; ++r) spec_dst[bin_of<R3>(lt, r)] = P[r];
                 }
                 if (to_tail) {
+                    if (!FLAGS || __builtin_amdgcn_ballot_w64(tail_mask != 0xFFFFu) == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) tail_dst[bin_of<R3>(lt, r)] = P[r];
+                        for (int r = 0; r < 16; ++r) tail_dst[bin_of<R3>(lt, r)] = P[r];
+                    } else if (__builtin_amdgcn_ballot_w64(tail_mask != 0u) != 0) {
+                        int lt_t = lt;  // (opaque: the sixteen addresses are rebuilt here, not kept across the loop)
+                        asm volatile("" : "+v"(lt_t));
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if ((tail_mask >> r) & 1u) tail_dst[bin_of<R3>(lt_t, r)] = P[r];
+                        }
+                    }
                 }
             } else {
                 // Larger N: a lane's 16 bins are N/16 (or more) apart and neighbouring lanes' bins 64..512 B
@@ -706,8 +727,15 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                 } else if constexpr (LG > 64) {
                     const int seg_last = (cb * GPW + GPW - 1) * L + L - i;
                     need = !halo && seg_last >= T - p.tail_cols;
+                    if constexpr (FLAGS) {
+                        // whole rows, for the workgroup: some lane's tail_mask is not empty (word i mod 3 was set
+                        // at the end of the step before, behind this step's barriers; the word read in the step
+                        // before is cleared for the step after)
+                        need = need && tail_any[i % 3] != 0u;
+                        if (tid == 0) tail_any[(i + 2) % 3] = 0u;
+                    }
                 } else {
-                    need = to_tail;
+                    need = to_tail && (!FLAGS || __builtin_amdgcn_ballot_w64(tail_mask != 0u) != 0);  // whole rows, for the wave
                 }
                 if (need) {
                     float *row = reinterpret_cast<float *>(gx);  // N floats (plus the skew) of the group's LG * 36
@@ -762,6 +790,9 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                         asm volatile("" : "+v"(lt_f));
                         p.first[((int64_t)s * L + seg) * LG + lt_f] = (uint16_t)hot;
                     }
+                }
+                if constexpr (LG > 64 && SUMS) {
+                    if (allhot != 0u && chunk_ok) tail_any[(i + 1) % 3] = 1u;  // the next step may have tail cells to write
                 }
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)

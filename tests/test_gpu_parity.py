@@ -327,6 +327,62 @@ def test_batch_of_streams_matches_oracle(nperseg, window, fs, mode):
     assert total > 20
 
 
+@pytest.mark.parametrize("nperseg,fs,mode", [(256, 2048000, "sparse"), (256, 2048000, "prefilter"), (512, 2048000, "sparse"), (1024, 2400000, "sparse"),
+                                             (2048, 2048000, "sparse"), (4096, 3200000, "sparse"), (1024, 2400000, "dense")])
+def test_look_back_over_several_chunks(nperseg, fs, mode):
+    """The sparse scans write only those look-back tail cells a walk from the next buffer can reach (per chunk of 32
+    segments: the last column, and a cell whose later cells of the chunk all pass the threshold).  Runs that reach
+    3 chunks back from the end of a buffer, runs interrupted by one cold cell right before / right after a chunk
+    boundary, and short ones, all continued in the next buffer: records equal the oracle's, walk by walk."""
+    _need_gpu()
+    n_streams, n_buf, t_b = 8, 3, 160  # chunk boundaries 32, 64, 96 ... segments before the end
+    blen = t_b * nperseg
+    hop_ms = nperseg / fs * 1e3
+    w = oracle.window_coefficients("hamming", nperseg)
+    amp = synth.amp_for_peak_dbw(-68.0, w, fs)
+    iq = []
+    for s in range(n_streams):
+        pulses = []
+        for k in (1, 2):  # across the end of buffer k - 1
+            end = k * blen  # (a multiple of nperseg: the pulses cover whole segments)
+
+            def span(a_seg, b_seg, f):  # tone on segments [a_seg, b_seg) counted from the end of the buffer (negative = before)
+                pulses.append(synth.Pulse(end + a_seg * nperseg, (b_seg - a_seg) * nperseg, f * fs, amp))
+
+            span(-(100 + s), 10 + s, 0.05 + 0.01 * s)                      # a long run: three chunk boundaries back
+            cut = -(32 * (1 + s % 3)) - (s % 2)                             # a cold cell right at / right before a chunk boundary
+            span(-70 - s, cut, -0.10 - 0.01 * s)
+            span(cut + 2, 8, -0.10 - 0.01 * s)
+            span(-3, 12 + s, 0.30 + 0.01 * s)                               # a short one
+        iq.append(synth.make_stream(synth.StreamSpec(n_buf * blen, fs, pulses), 800 + s).reshape(n_buf, blen))
+    iq = np.stack(iq)  # [S, n_buf, blen]
+    # (the tones fill most of their rows: the SNR gate against the row mean is opened wide)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window="hamming", signal_max_duration_ms=400 * hop_ms, snr_threshold_db=-20.0)
+    if mode != "prefilter":
+        kw["signal_min_duration_ms"] = 4 * hop_ms
+    b = _batch_for(kw, n_streams, blen, mode)
+    oas = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(n_streams)]
+    starts = []
+    for k in range(n_buf):
+        chunk = np.ascontiguousarray(iq[:, k])
+        b.enqueue(chunk)
+        rec = b.fetch_records()
+        for s in range(n_streams):
+            want_all, want_kept = oas[s].process(chunk[s], gu.TS0)
+            mine = rec[rec["stream"] == s]
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want_all], f"buffer {k} stream {s}"
+            kept_ids = {id(x) for x in want_kept}
+            assert [bool(r["shadowed"]) for r in mine] == [id(x) not in kept_ids for x in want_all]
+            sigs = b._decoder.signals(mine, [str(s)] * n_streams, [gu.TS0] * n_streams)
+            for g, x in zip(sigs, want_all):
+                for name in ("max", "avg", "noise", "snr", "std"):
+                    assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB, (name, getattr(g, name), getattr(x, name))
+            starts += [int(r["start"]) for r in mine]
+    assert min(starts) <= -100, sorted(starts)[:40]
+    if mode != "prefilter":  # (its minimum duration of 64 hops rejects the shorter runs on both sides)
+        assert sum(1 for x in starts if -100 < x < -20) >= n_streams and sum(1 for x in starts if -4 <= x < 0) >= n_streams, sorted(starts)[:40]
+
+
 def test_strided_device_batch_and_reset():
     """IQ rows with padding between streams (stream_stride > n_samples); reset()
     drops the look-back exactly like `_spectrogram_last = None`."""
@@ -1181,6 +1237,42 @@ def test_lanes_give_the_same_records():
     assert outs[0].tobytes() == outs[1].tobytes()
     with pytest.raises(ValueError):
         _batch_for(kw, 4, blen, "sparse", lanes=2, hip_stream=torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_a_changed_threshold_starts_the_stream_without_look_back(lanes):
+    """rt_set_stream_params: the reference fixes the threshold when the SignalAnalyzer is built (analyze.py:115), so a
+    new threshold is a new analyzer with ``_spectrogram_last = None``; the streams whose value did not change keep
+    their look-back."""
+    _need_gpu()
+    fs, nperseg, n_streams = 2048000, 256, 6
+    blen = nperseg * 300
+    w = oracle.window_coefficients("hamming", nperseg)
+    amp = synth.amp_for_peak_dbw(-70.0, w, fs)
+    iq = []
+    for s in range(n_streams):
+        pulses = [synth.Pulse(blen - int(0.006 * fs), int(0.015 * fs), (0.1 + 0.05 * s) * fs, amp, 0.25)]
+        iq.append(synth.make_stream(synth.StreamSpec(2 * blen, fs, pulses), 300 + s).reshape(2, blen))
+    iq = np.stack(iq)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg)
+    b = _batch_for(kw, n_streams, blen, "sparse", lanes=lanes)
+    b.enqueue(np.ascontiguousarray(iq[:, 0]))
+    assert len(b.fetch_records()) == 0  # the pulses lap into the next buffer
+    base = np.float32(10.0 ** (-90.0 / 10.0))
+    thr = np.full(n_streams, base, np.float32)
+    changed = [1, 4]
+    thr[changed] = base * np.float32(0.5)
+    b.native.set_stream_params(thr, None)
+    b.enqueue(np.ascontiguousarray(iq[:, 1]))
+    rec = b.fetch_records()
+    for s in range(n_streams):
+        mine = rec[rec["stream"] == s]
+        oa = oracle.OracleAnalyzer(device=str(s), signal_threshold_dbw=-90.0 + (10.0 * np.log10(0.5) if s in changed else 0.0), **kw)
+        if s not in changed:
+            oa.process(iq[s, 0], gu.TS0)
+        want, _ = oa.process(iq[s, 1], gu.TS0)
+        assert len(want) >= 1 and [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want], s
+        assert all(int(r["start"]) == 0 for r in mine) if s in changed else all(int(r["start"]) < 0 for r in mine)
 
 
 @pytest.mark.parametrize("mode,lanes", [("sparse", 1), ("dense", 1), ("sparse", 2)])
