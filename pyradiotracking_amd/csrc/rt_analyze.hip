@@ -111,7 +111,7 @@ struct rt_handle {
     Slot slot[kSlots];
 
     int hot_cap = 8192, rec_cap = 1024, cand_cap = 32;
-    size_t lds_large = 0, lds_small = 0, lds_final = 0, lds_dense = 0;
+    size_t lds_large = 0, lds_small = 0, lds_dense = 0;
 
     bool lin = false;      // constant detrend by linearity (cosine-sum window of order <= 1; rt_kernels.h: LIN)
     float lin_c[3] = {0.f, 0.f, 0.f};
@@ -377,7 +377,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
         // always launched: it is also the pass that re-zeroes the per-bucket counters
         hipLaunchKernelGGL(detect_bucket<true>, dim3(waves), dim3(256), h->lds_large, sd, a);
-        hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), h->lds_final, sd, a);
+        hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), 0, sd, a);
     }
     RT_HIP(h, hipGetLastError());
     // no readback: the call's last workgroup wrote the counter words to pinned host memory
@@ -639,7 +639,6 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                      ? cfg->hot_capacity
                      : std::min(8192, std::max(kSmallBucket, next_pow2(std::max(h->max_seg, 1)) * std::max(1, h->N / 1024)));
     h->lds_dense = rec_lds_bytes(h->rec_cap);
-    h->lds_final = rec_lds_bytes(h->rec_cap);
     {
         // plateaus a wave stages per bucket: a bucket holds N/16 bins; 32 keeps four waves' LDS
         // under 40 KiB (all 16 bucket waves of a CU resident at once) for nperseg 256/512
@@ -773,8 +772,6 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
-    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_records),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_final));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dense));
 #undef RT_CREATE_HIP

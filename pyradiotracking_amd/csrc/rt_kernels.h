@@ -1567,37 +1567,95 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
 }
 
 // One workgroup per stream: order the stream's records by (fi, start), shadow verdicts, publish.
+// (rt::rank_and_shadow against tiles of 256 records in 16 KiB of static LDS: with room for `rec_cap` records -- 64 KiB at
+// the default -- two workgroups fit a CU, and a batch of thousands of streams with a dozen records each spent most of this
+// kernel waiting for a slot.)  ONE atomic per workgroup on the call's counter word: records allocated in the low 40 bits,
+// workgroups arrived above them (two atomics on one address cost thousands of streams ~11 ns each, one after the other).
+// The workgroup that arrives last closes the call (close_call's job in detect_dense): the others have made their only
+// update of the counters by then; the pool overflow is told from the total.
+constexpr int kFinalTile = 256;
+constexpr int kTicketShift = 40;
 __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ rt_record t_rec[kFinalTile];
+    __shared__ long long t_ts[kFinalTile], t_dur[kFinalTile];
+    __shared__ long long sh_base;
     const int s = blockIdx.x;
+    const int tid = threadIdx.x;
     int n = a.raw_count[s];
+    if (n > a.rec_cap) n = a.rec_cap;  // overflow already flagged by the producer
+    if (n < 0) n = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         if (n) a.raw_count[s] = 0;  // ready for the slot's next call
         uint32_t tot = 0;
         for (int b = 0; b < kBuckets; ++b) tot += a.hot_seen[s * kBuckets + b];
         a.hot_total[s] = (int32_t)tot;
-    }
-    if (n <= 0) {
-        if (threadIdx.x == 0) {
-            a.rec_offset[s] = 0;
-            a.rec_count[s] = 0;
-            close_call(a);
+        const unsigned long long v = atomicAdd(&a.counters[0], (unsigned long long)n | (1ull << kTicketShift));
+        const unsigned long long mask = (1ull << kTicketShift) - 1ull;
+        long long base = (long long)(v & mask);
+        if (base + n > a.pool_cap) base = -1;
+        sh_base = base;
+        a.rec_offset[s] = base < 0 ? 0 : (int)base;
+        a.rec_count[s] = base < 0 ? 0 : n;
+        if ((v >> kTicketShift) + 1ull == (unsigned long long)gridDim.x) {
+            // every workgroup has added its records: publish the counter words, leave them zero for the slot's next call
+            const unsigned long long total = __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask;
+            unsigned long long flags = __hip_atomic_load(&a.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (total > (unsigned long long)a.pool_cap) flags |= kFlagRecOverflow;
+            a.host_counters[0] = total;
+            a.host_counters[1] = __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.host_counters[2] = flags;
+            a.host_counters[3] = (unsigned long long)gridDim.x;
+            for (int i = 0; i < 4; ++i) __hip_atomic_store(&a.counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        return;
-    }
-    if (n > a.rec_cap) n = a.rec_cap;  // overflow already flagged by the producer
-    unsigned char *ptr = smem;
-    RecLds l = carve_rec_lds(ptr, a.rec_cap);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const rt_record r = a.raw[(int64_t)s * a.rec_cap + i];
-        l.rec[i] = r;
-        l.ts_us[i] = timedelta_us(start_time(a.dp, r.start));
-        l.dur_us[i] = timedelta_us(run_duration(a.dp, r.start, r.end));
     }
     __syncthreads();
-    publish_records(a, l, s, n);
-    if (threadIdx.x == 0) close_call(a);  // thread 0 made this workgroup's counter updates
+    const long long base = sh_base;
+    if (n == 0 || base < 0) return;
+    const float cal_db = a.cal_s ? a.cal_s[s] : a.dp.cal_db;
+    const rt_record *raw = a.raw + (int64_t)s * a.rec_cap;
+    for (int i0 = 0; i0 < n; i0 += kFinalTile) {  // the records this pass ranks (one per thread)
+        const int i = i0 + tid;
+        rt_record mine{};
+        long long ts_i = 0, dur_i = 0;
+        float mx_i = 0.f;
+        if (i < n) {
+            mine = raw[i];
+            ts_i = timedelta_us(start_time(a.dp, mine.start));
+            dur_i = timedelta_us(run_duration(a.dp, mine.start, mine.end));
+            mx_i = db10(mine.max_p) - cal_db;
+        }
+        int rank = 0, shadow = 0;
+        for (int j0 = 0; j0 < n; j0 += kFinalTile) {  // ... against every record, a tile at a time
+            __syncthreads();
+            if (j0 == i0) {
+                t_rec[tid] = mine;
+                t_rec[tid].reserved = __float_as_int(mx_i);
+                t_ts[tid] = ts_i;
+                t_dur[tid] = dur_i;
+            } else if (j0 + tid < n) {
+                rt_record r = raw[j0 + tid];
+                r.reserved = __float_as_int(db10(r.max_p) - cal_db);
+                t_rec[tid] = r;
+                t_ts[tid] = timedelta_us(start_time(a.dp, r.start));
+                t_dur[tid] = timedelta_us(run_duration(a.dp, r.start, r.end));
+            }
+            __syncthreads();
+            const int nj = (n - j0 < kFinalTile) ? (n - j0) : kFinalTile;
+            if (i < n) {
+                for (int j = 0; j < nj; ++j) {
+                    const rt_record &rj = t_rec[j];
+                    if (rj.fi < mine.fi || (rj.fi == mine.fi && rj.start < mine.start)) ++rank;
+                    if (shadowed_by(ts_i, dur_i, mx_i, t_ts[j], t_dur[j], __int_as_float(rj.reserved))) shadow = 1;
+                }
+            }
+        }
+        if (i < n) {
+            mine.shadowed = shadow;
+            mine.reserved = 0;
+            a.records[base + rank] = mine;
+        }
+    }
 }
 
 // Device form of rt::scan_dense_row (same decisions): the row is read in blocks of 16 time

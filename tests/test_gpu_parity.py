@@ -1239,6 +1239,42 @@ def test_lanes_give_the_same_records():
         _batch_for(kw, 4, blen, "sparse", lanes=2, hip_stream=torch.cuda.current_stream().cuda_stream)
 
 
+def test_many_records_per_stream_are_ranked_and_shadowed_in_tiles():
+    """finalize_records ranks and shadow-tests a stream's records against tiles of 256 in LDS: streams with 0, a few, about
+    300 and about 900 records (one to four tiles, overlapping pulses: shadow verdicts across tiles) equal the dense path
+    byte for byte (its publish step holds all records in LDS at once) and the oracle."""
+    _need_gpu()
+    fs, nperseg = 2048000, 256
+    blen = nperseg * 4000
+    w = oracle.window_coefficients("hamming", nperseg)
+    n_pulses = [0, 3, 100, 300]
+    iq = []
+    for s, n_p in enumerate(n_pulses):
+        rng = np.random.default_rng([31, s])
+        pulses = [synth.Pulse(int(rng.integers(0, blen - 4000)), int(0.0015 * fs), float(rng.uniform(-0.45, 0.45) * fs),
+                              synth.amp_for_peak_dbw(float(rng.uniform(-80.0, -60.0)), w, fs), float(rng.uniform(0, 1))) for _ in range(n_p)]
+        iq.append(synth.make_stream(synth.StreamSpec(blen, fs, pulses), seed=40 + s))
+    iq = np.stack(iq)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, signal_min_duration_ms=1.0)
+    got = {}
+    for mode in ("sparse", "dense"):
+        b = _batch_for(kw, len(n_pulses), blen, mode, record_capacity=2048)
+        b.enqueue(iq)
+        got[mode] = b.fetch_records()
+        b.close()
+    rec = got["sparse"]
+    assert rec.tobytes() == got["dense"].tobytes()
+    counts = np.bincount(rec["stream"], minlength=len(n_pulses))
+    assert counts[0] == 0 and 0 < counts[1] <= 16 and 256 < counts[2] <= 512 and counts[3] > 768, counts
+    assert 0 < int(rec["shadowed"].sum()) < len(rec)
+    for s in (1, 2, 3):
+        want, kept = oracle.OracleAnalyzer(device=str(s), **kw).process(iq[s], gu.TS0)
+        mine = rec[rec["stream"] == s]
+        assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want], s
+        kept_ids = {id(x) for x in kept}
+        assert [bool(r["shadowed"]) for r in mine] == [id(x) not in kept_ids for x in want], s
+
+
 @pytest.mark.parametrize("lanes", [1, 2])
 def test_a_changed_threshold_starts_the_stream_without_look_back(lanes):
     """rt_set_stream_params: the reference fixes the threshold when the SignalAnalyzer is built (analyze.py:115), so a
