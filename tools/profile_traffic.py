@@ -38,7 +38,9 @@ def main():
     for s in range(8):
         rng = np.random.default_rng([1000, s])
         k = int(rng.integers(4, 9))
-        pulses = synth.random_pulses(rng, blen, fs, win, k, keep_clear_tail=2 * nperseg)
+        peak = os.environ.get("RT_PROF_PEAK_DBW")  # "lo,hi": pulse peak powers (default: synth's -80 .. -60 dBW)
+        extra = dict(peak_dbw=tuple(float(x) for x in peak.split(","))) if peak else {}
+        pulses = synth.random_pulses(rng, blen, fs, win, k, keep_clear_tail=2 * nperseg, **extra)
         base.append(synth.make_stream(synth.StreamSpec(blen, fs, pulses), 1000 + s))
     dev = _native.DeviceBuffer(0, S * blen * 8)
     for s in range(S):
