@@ -441,7 +441,17 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     constexpr bool EMIT = (MODE == 0 || MODE == 5);   // candidate cells go to the bucket lists
     constexpr bool FLAGS = (MODE == 0 || MODE == 4);  // chunk bits of the run-length pre-filter are written
     constexpr bool SUMS = (MODE != 2 && MODE != 5);   // row sums and look-back tail (MODE 5 repeats chunks of a scan that wrote them)
-    const int i_first = (EMIT || MODE == 3) ? 0 : 1;  // step 0 is the halo segment c0+L (emitting modes only)
+    // Steps 1 .. L walk the chunk down from its latest segment.  A cell is a candidate cell if it passes the threshold or
+    // directly precedes one that does (T11); for the chunk's lowest segment c0 that concerns a cell of the neighbour
+    // below, whose owner cannot know.  So where (and only where) a lowest cell is hot, the wave (workgroup, for lane
+    // groups of several waves) takes step L + 1 on segment c0 - 1 and emits the cells there that precede a hot one and
+    // are not hot themselves (those the owner emits): ~10 % of the chunks on sparse input, where a halo segment read
+    // and transformed by every chunk cost 1/33 of all loads and arithmetic.
+    // nperseg 4096 keeps that halo segment (BELOW = false: step 0 on segment c0 + L, whose only product is next_hot):
+    // there the extra workgroup barrier and registers of the conditional step cost more than the halo (+2.5 %).
+    constexpr bool BELOW = (R3 < 16);
+    const int i_first = (!BELOW && EMIT) ? 0 : 1;
+    int n_steps = L;
 
     uint32_t allhot = 0xFFFFu;  // FLAGS: the chunk's bits so far
     uint32_t need = 0xFFFFu;                      // MODE 5: the lane's bins that may emit in every segment of the chunk
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     auto request_segment = [&](int seg_req) {
         if constexpr (MODE == 5) {
             first_nxt = 0u;
-            if (chunk == 0 && chunk_ok && seg_req < L) first_nxt = p.first[((int64_t)s * L + seg_req) * LG + lt];
+            if (chunk == 0 && chunk_ok && seg_req >= 0 && seg_req < L) first_nxt = p.first[((int64_t)s * L + seg_req) * LG + lt];
         }
         if constexpr (BUF_LOADS) {
             const int sg = __builtin_amdgcn_readfirstlane(chunk_u * L + (seg_req - c0));  // == seg_req, in SGPRs
@@ -491,12 +501,14 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             const raw_t *base = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(sg & RT_EXP_ALIAS) * N;
             const rsrc_t r = make_rsrc(base, (uint32_t)(N * sizeof(raw_t)));
 #else
-            const rsrc_t r = make_rsrc(stream_iq + (int64_t)sg * N, sg < T ? (uint32_t)(N * sizeof(raw_t)) : 0u);
+            // (sg < 0: the step below the chunk of a workgroup whose other lane group holds chunk 0)
+            const rsrc_t r = make_rsrc(stream_iq + (int64_t)(sg < 0 ? 0 : sg) * N, (sg >= 0 && sg < T) ? (uint32_t)(N * sizeof(raw_t)) : 0u);
 #endif
 #pragma unroll
             for (int m = 0; m < 16; ++m) nxt[m] = buf_load_iq(r, lt * (int)sizeof(raw_t), LG * m * (int)sizeof(raw_t), raw_t{});
         } else if (MODE != 5 || group_need) {
-            const int sc = seg_req < seg_hi ? seg_req : seg_hi;
+            int sc = seg_req < seg_hi ? seg_req : seg_hi;
+            sc = sc < 0 ? 0 : sc;  // (step L + 1 of a wave that also holds chunk 0)
 #ifdef RT_EXP_ALIAS  // diagnostic build (tools/variant.sh alias -DRT_EXP_ALIAS=63): every load hits the same 64 segments of
                      // stream 0 (L2-resident) -- the scan kernel without HBM, i.e. its arithmetic + LDS floor; a mask of
                      // 8191 keeps a whole stream (16 MB at nperseg 256: misses L2, stays in the Infinity Cache)
@@ -510,10 +522,10 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     };
     request_segment(c0 + L - i_first);
 
-    for (int i = i_first; i <= L; ++i) {
+    for (int i = i_first; i <= n_steps; ++i) {
         const int seg = c0 + L - i;
-        const bool halo = (i == 0);
-        const bool active = chunk_ok && seg < T;
+        const bool halo = BELOW ? (i > L) : (i == 0);  // the step below (above) the chunk: no sums, tail, chunk bits
+        const bool active = chunk_ok && seg < T && seg >= 0;
 
         cf v[16];
 #pragma unroll
@@ -529,8 +541,12 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             for (int m = 0; m < 16; ++m) wreg[m] = raw_buffer_load_f1(rw, lt * 4, LG * m * 4, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep the order of the two groups of loads
         }
-        // next step's segment (the last step re-reads its own: harmless, keeps the loop uniform)
-        request_segment((i < L) ? seg - 1 : seg);
+        // next step's segment (the segment below the chunk is requested at the end of step L, once it is known to be needed)
+        if constexpr (BELOW) {
+            if (i < L) request_segment(seg - 1);
+        } else {
+            request_segment((i < L) ? seg - 1 : seg);  // (the last step re-reads its own: harmless, keeps the loop uniform)
+        }
 
         if constexpr (MODE == 3) {
             // traffic calibration: the scan's exact load stream, nothing else
@@ -796,7 +812,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                 }
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
-            const uint32_t emit = (EMIT && active && !halo) ? ((hot | next_hot) & need_seg) : 0u;
+            const uint32_t emit = (EMIT && active) ? ((halo ? (BELOW ? (next_hot & ~hot) : 0u) : (hot | next_hot)) & need_seg) : 0u;
             if (EMIT && RT_ABLATE != 9 && !gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare (RT_ABLATE 9: test without emission)
                 // Candidates are staged per wave in LDS and flushed with ONE returned atomic per
                 // flush: an atomic per cell would stall on vmcnt(0) and drain the prefetch.
@@ -847,6 +863,21 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                 }
             }
             next_hot = hot;
+            if constexpr (EMIT && BELOW) {
+                if (i == L) {
+                    const bool below = chunk_ok && c0 > 0 && (hot & need) != 0u;  // a lowest cell of the chunk is a candidate
+                    bool any_below;
+                    if constexpr (LG > 64) {
+                        any_below = __syncthreads_or(below) != 0;  // the step has workgroup barriers
+                    } else {
+                        any_below = __builtin_amdgcn_ballot_w64(below) != 0;
+                    }
+                    if (any_below) {
+                        n_steps = L + 1;
+                        request_segment(c0 - 1);
+                    }
+                }
+            }
         }
     }
 

@@ -354,6 +354,8 @@ def test_look_back_over_several_chunks(nperseg, fs, mode):
             span(-70 - s, cut, -0.10 - 0.01 * s)
             span(cut + 2, 8, -0.10 - 0.01 * s)
             span(-3, 12 + s, 0.30 + 0.01 * s)                               # a short one
+            span(-96, -88 + s, 0.40 + 0.005 * s)                            # starts on a chunk's lowest segment: the cell before it is the neighbour's
+            span(-128 - 10, -128, -0.40 - 0.005 * s)                        # ends on a chunk's highest segment
         iq.append(synth.make_stream(synth.StreamSpec(n_buf * blen, fs, pulses), 800 + s).reshape(n_buf, blen))
     iq = np.stack(iq)  # [S, n_buf, blen]
     # (the tones fill most of their rows: the SNR gate against the row mean is opened wide)
