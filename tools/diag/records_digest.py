@@ -23,12 +23,12 @@ for nperseg in (256, 512, 1024, 2048, 4096):
             pulses.append(synth.Pulse(blen - int(0.004 * fs), int(0.012 * fs), 1e5 * (s - 3), synth.amp_for_peak_dbw(-70.0, w, fs)))
             iq.append(synth.make_stream(synth.StreamSpec(2 * blen, fs, pulses, dc=complex(1e-3, -2e-3)), seed=50 + s).reshape(2, blen))
         iq = np.stack(iq)
-        raw = synth.quantize_u8(iq.reshape(n_streams, -1), gain=2000.0).reshape(n_streams, 2, -1)
+        raw = synth.quantize_u8(iq.reshape(n_streams, -1), gain=5.0).reshape(n_streams, 2, -1)  # (|x| stays under 1: no clipping)
         for mode in ("sparse", "dense"):
             for u8 in (False, True):
                 kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_min_duration_ms=2.0)
                 if u8:
-                    kw["signal_threshold_dbw"] = -90.0 + 66.0
+                    kw["signal_threshold_dbw"] = -90.0 + 14.0  # the gain of 5 is 14 dB
                 an = BatchSignalAnalyzer([str(i) for i in range(n_streams)], sdr_callback_length=blen, mode=mode, **kw)
                 h = hashlib.sha256()
                 n = 0
