@@ -1241,6 +1241,42 @@ def test_lanes_give_the_same_records():
         _batch_for(kw, 4, blen, "sparse", lanes=2, hip_stream=torch.cuda.current_stream().cuda_stream)
 
 
+def test_buckets_ordered_by_bitmap_equal_the_dense_path():
+    """nperseg 256 with 2 048 segments per buffer (BASELINE config 4, the reference's default geometry): a bucket's key
+    space (16 bins x 2 048 times) fits a bitmap of 32 768 bits, and buckets of more than 64 cells are ordered by it
+    instead of the sorting network (rt_kernels.h: sort_bucket_bitmap).  Streams whose buckets hold about 100 .. 1 000
+    cells (all four register counts of the path) and one with a few cells (the network): records byte-identical to the
+    dense path, which orders nothing."""
+    _need_gpu()
+    fs, nperseg = 2048000, 256
+    blen = nperseg * 2048
+    w = oracle.window_coefficients("hamming", nperseg)
+    n_pulses = [2, 6, 12, 24, 40]  # ~340 cells per pulse over 16 buckets: ~40 .. 850 cells per bucket
+    iq = []
+    for s, n_p in enumerate(n_pulses):
+        rng = np.random.default_rng([47, s])
+        pulses = [synth.Pulse(int(rng.integers(0, blen - int(0.03 * fs))), int(rng.uniform(0.008, 0.02) * fs), float(rng.uniform(-0.45, 0.45) * fs),
+                              synth.amp_for_peak_dbw(float(rng.uniform(-80.0, -60.0)), w, fs), float(rng.uniform(0, 1))) for _ in range(n_p)]
+        iq.append(synth.make_stream(synth.StreamSpec(blen, fs, pulses), seed=60 + s))
+    iq = np.stack(iq)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg)
+    got, cells = {}, 0
+    for mode in ("sparse", "dense"):
+        b = _batch_for(kw, len(n_pulses), blen, mode, record_capacity=2048)
+        b.enqueue(iq)
+        got[mode] = b.fetch_records()
+        if mode == "sparse":
+            cells = b.native.call_info().n_hot
+        b.close()
+    assert got["sparse"].tobytes() == got["dense"].tobytes()
+    counts = np.bincount(got["sparse"]["stream"], minlength=len(n_pulses))
+    assert counts[0] >= 1 and counts[-1] > 5 * counts[1], counts
+    assert cells > 16 * 128 * len(n_pulses)  # far more than 64 cells per bucket on average
+    want, kept = oracle.OracleAnalyzer(device="3", **kw).process(iq[3], gu.TS0)
+    mine = got["sparse"][got["sparse"]["stream"] == 3]
+    assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want]
+
+
 def test_many_records_per_stream_are_ranked_and_shadowed_in_tiles():
     """finalize_records ranks and shadow-tests a stream's records against tiles of 256 in LDS: streams with 0, a few, about
     300 and about 900 records (one to four tiles, overlapping pulses: shadow verdicts across tiles) equal the dense path
