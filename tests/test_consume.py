@@ -249,6 +249,64 @@ def test_cbor_known_answers_of_rfc8949():
     assert wide[0][2:].hex() == "c100" "fb0000000000000000" "d90539fb0000000000000000" + "f6" * 30
 
 
+def _libcbor():
+    import ctypes as C
+    import ctypes.util
+
+    path = ctypes.util.find_library("cbor") or "libcbor.so.0.8"
+    try:
+        lib = C.CDLL(path)
+    except OSError:
+        return None
+
+    class LoadResult(C.Structure):
+        _fields_ = [("error_position", C.c_size_t), ("error_code", C.c_int), ("read", C.c_size_t)]
+
+    lib.cbor_load.restype = C.c_void_p
+    lib.cbor_load.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LoadResult)]
+    lib.cbor_serialize_alloc.restype = C.c_size_t
+    lib.cbor_serialize_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.cbor_decref.argtypes = [C.POINTER(C.c_void_p)]
+    lib.cbor_isa_array.restype = C.c_bool
+    lib.cbor_isa_array.argtypes = [C.c_void_p]
+    lib.cbor_array_size.restype = C.c_size_t
+    lib.cbor_array_size.argtypes = [C.c_void_p]
+    return lib, LoadResult
+
+
+def test_cbor_messages_pass_through_libcbor_unchanged():
+    """A second RFC 8949 implementation (libcbor 0.8, the C library of the image; not cbor2, so the parity with the
+    reference's encoder stays unpinned): every message loads without error, is consumed to its last byte, is one
+    array of the expected length, and libcbor's own serialisation of the loaded item gives the same bytes back."""
+    import ctypes as C
+
+    got = _libcbor()
+    if got is None:
+        pytest.skip("libcbor is not installed")
+    lib, LoadResult = got
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    rows, names = signal_rows()
+    mrows, avgs, present, mnames = matched_rows()
+    batches = [(rtc.format_signals("cbor", rows, names), 9), (rtc.format_matched("cbor", mrows, avgs, present, mnames), 3 + len(mnames))]
+    n = 0
+    for msgs, width in batches:
+        for m in msgs:
+            raw = bytes(m)
+            res = LoadResult()
+            item = lib.cbor_load(raw, len(raw), C.byref(res))
+            assert item and res.error_code == 0 and res.read == len(raw), (res.error_code, res.error_position, raw.hex())
+            assert lib.cbor_isa_array(item) and lib.cbor_array_size(item) == width
+            buf, size = C.c_void_p(), C.c_size_t()
+            length = lib.cbor_serialize_alloc(item, C.byref(buf), C.byref(size))
+            assert length == len(raw) and C.string_at(buf, length) == raw
+            libc.free(buf)
+            ref = C.c_void_p(item)
+            lib.cbor_decref(C.byref(ref))
+            n += 1
+    assert n == len(rows) + len(mrows) and n > 100
+
+
 def test_errors_and_empty_batches():
     from pyradiotracking_amd import _native
 
