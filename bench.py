@@ -17,12 +17,21 @@ population -- and the total number of records, which is printed -- is the same a
 There is no collective on the data path.  The control plane (rendezvous, barrier, the
 max-over-ranks of one double, record counts) runs over gloo at every N.
 
+``--gpus N`` without a launcher (no RANK / WORLD_SIZE in the environment) starts the N
+ranks itself: N fresh child processes of this script, before anything here has touched a
+GPU, one per GPU, rank 0's JSON line relayed; a failing rank fails the run.  Launched by
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` it is a rank.
+
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (stft_scan) at 8
-algorithmic bytes per IQ sample against the 8 TB/s HBM peak, from HIP events recorded on
-the launch stream around every launch of the timed region; `kernel_ms_isolated` is the
-same kernel in a one-lane pass after the timed region (one launch per step, nothing
-beside it).  `cpu_baseline` is the oracle (port of the reference's SciPy/NumPy path) on
-this node's host cores, N = 1 only; `parity` compares sampled streams with it.
+algorithmic bytes per IQ sample against the 8 TB/s HBM peak: `kernel_ms` / `achieved` /
+`frac` are the launch ALONE (one lane: one launch over all streams of the rank per step,
+HIP events on its stream, a pass after the timed region unless the timed region itself
+ran one lane) -- the figure a one-lane rocprofv3 --kernel-trace average reproduces;
+`kernel_ms_concurrent` / `frac_concurrent` are the per-launch figures of the timed region,
+where the lanes' launches run beside each other.  `host_sinks` (outside the timed region,
+one core) puts the host-side consumers next to the record rate the GPU path produced.
+`cpu_baseline` is the oracle (port of the reference's SciPy/NumPy path) on this node's
+host cores, N = 1 only; `parity` compares sampled streams with it.
 """
 import argparse
 import hashlib
@@ -140,11 +149,64 @@ def pmc_traffic(default_workload, lanes):
         return None, "profiles/pmc_traffic.json missing"
     if doc.get("sources_sha256") != sources_sha256():
         return None, "kernel sources changed since profiles/pmc_traffic.json was measured (run tools/profile_round.sh)"
-    return int(doc["bytes_per_launch_256_streams"]) // lanes, "bytes/launch: PMC FETCH_SIZE (calibrated on the kernel's own load stream) + WRITE_SIZE on one 256-stream launch, split over the lanes; " + doc.get("source", "profiles/pmc_traffic.json")
+    return int(doc["bytes_per_launch_256_streams"]) // lanes, "bytes/launch: PMC FETCH_SIZE (calibrated on the kernel's own load stream) + WRITE_SIZE on one 256-stream launch; " + doc.get("source", "profiles/pmc_traffic.json")
+
+
+def spawn_ranks(args):
+    """``--gpus N`` started by hand (no launcher): run the N ranks as N fresh child processes of this script, one per
+    GPU, rendezvous on 127.0.0.1.  This process has not imported torch and never touches a GPU; it relays rank 0's
+    output and exits non-zero if any rank does (the others are then stopped by their exact PIDs)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].stdout.read()
+    rcs = []
+    failed = False
+    for pr in procs:
+        try:
+            rcs.append(pr.wait(timeout=None if not failed else 30))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            rcs.append(pr.wait())
+        if rcs[-1] != 0 and not failed:
+            failed = True
+            for other in procs:
+                if other.poll() is None:
+                    other.terminate()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: rank(s) failed (rank, exit code): {bad}")
+
+
+def device_identity(torch, local_rank):
+    """What tells two ranks' GPUs apart in a SCALE record without any collective library: ordinal, PCI address, name."""
+    props = torch.cuda.get_device_properties(local_rank)
+    pci = None
+    try:
+        pci = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+    except AttributeError:
+        pass
+    uuid = getattr(props, "uuid", None)
+    return {"ordinal": local_rank, "pci_bus_id": pci, "uuid": str(uuid) if uuid is not None else None, "name": props.name}
 
 
 def main():
     args = parse()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        return spawn_ranks(args)  # before torch is imported: this process never initialises a GPU
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -156,10 +218,10 @@ def main():
     share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if world != args.gpus and rank == 0:
+        # a launcher's WORLD_SIZE is what actually runs; the JSON line reports it as n_gpus
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); running {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -274,6 +336,15 @@ def main():
     else:
         n_records_total, n_hot_total = n_records, n_hot
 
+    # which GPU every rank ran on (ordinal, PCI address): a SCALE record shows N distinct devices without any collective library
+    me = device_identity(torch, local_rank)
+    me["rank"] = rank
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+    else:
+        devices = [me]
+
     samples_per_step_rank = S * n_seg * nperseg  # samples actually transformed (T6)
     total_samples = total_streams * n_seg * nperseg * args.steps
     value = total_samples / elapsed / 1e6
@@ -285,7 +356,7 @@ def main():
 
     default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw, args.noise_dbw) == ("config2", 256, 0, "auto", "c64", None, None)
     n_dense_streams = int(info.n_dense_streams)
-    traffic, traffic_note = pmc_traffic(default_workload, lanes)
+    traffic, traffic_note = pmc_traffic(default_workload, 1)  # per launch over all 256 streams, like kernel_ms
 
     # parity + CPU baseline (untimed).  N = 1: the oracle on the host cores over a bounded sample (the baseline) and the
     # records of >= 16 sampled streams against it; N > 1: every rank checks the first and last stream of its shard.
@@ -300,6 +371,7 @@ def main():
             parity["streams_checked"], parity["streams_mismatched"] = int(c[0]), int(c[1])
             parity["note"] = "first and last stream of every rank's shard"
 
+    an_decoder = an.decoder
     # the scan launch alone: one lane, one launch per step, nothing running beside it
     iso_ms = None
     if args.isolated_steps > 0 and not (lanes == 1):
@@ -312,6 +384,42 @@ def main():
         an1.close()
     elif lanes == 1:
         iso_ms = k_ms
+
+    # host sinks, outside the timed region (rank 0, one core): what the reference's path ends in -- Signal objects on the
+    # queue (analyze.py:251, 280) -- and the vectorised record -> CSV route, next to the record rate the timed steps produced
+    sinks = None
+    if rank == 0:
+        sinks = host_sinks(an_decoder, rec, [str(i) for i in range(lo, hi)], n_records_total * args.steps / elapsed)
+
+    conc_frac = achieved / HBM_PEAK_GBS
+    if iso_ms:
+        kernel_ms, kernel_frac = iso_ms, samples_per_step_rank * bytes_per_sample / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        kernel_note = (f"the stft_scan launch ALONE: one launch over all {S} streams of the rank per step, one lane, HIP events on its stream, "
+                       + (f"{args.isolated_steps} steps after the timed region" if lanes > 1 else "the timed region itself")
+                       + "; a one-lane rocprofv3 --kernel-trace average of the same command reproduces it")
+    else:
+        kernel_ms, kernel_frac = k_ms, conc_frac
+        kernel_note = "isolated pass skipped (--isolated-steps 0): the concurrent per-launch figure stands in"
+    roofline = {
+        "bound": "hbm",
+        "kernel": "stft_scan",
+        "achieved": round(kernel_frac * HBM_PEAK_GBS, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(kernel_frac, 4),
+        "traffic": traffic,
+        "traffic_note": traffic_note,
+        "kernel_ms": round(kernel_ms, 4),
+        "kernel_ms_note": kernel_note,
+        "algorithmic_bytes_per_launch": samples_per_step_rank * bytes_per_sample,
+        "launches_per_step_timed_region": lanes,
+        "kernel_ms_concurrent": round(k_ms, 4),
+        "frac_concurrent": round(conc_frac, 4),
+        "concurrent_note": "mean duration of one stft_scan launch over the timed region; with more than one lane each launch covers "
+                           "1/lanes of the streams and runs beside the other lanes' scan and detect kernels, which stretches it",
+        "detect_kernel_ms": round(ms_detect / max(1, args.steps) / lanes, 4),
+        "whole_path_frac": round(value * 1e6 / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
+    }
 
     part = (f"{total_streams} streams sharded over {world} GPU(s) ({S} on rank 0)" if wl["scaling"] == "strong"
             else f"{S} streams/GPU")
@@ -347,27 +455,10 @@ def main():
             "noisy_streams_per_gpu": args.noisy_streams or (S if args.noise_dbw is not None else 0),
             "streams_rerun_dense_rank0": n_dense_streams,
             "threshold_dbw": kw.get("signal_threshold_dbw", -90.0),
+            "devices": devices,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "stft_scan",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "traffic_note": traffic_note,
-            "launches_per_step": lanes,
-            "kernel_ms": round(k_ms, 4),
-            "kernel_ms_note": "mean duration of one stft_scan launch over the timed region (HIP events on its stream); with more than one lane "
-                              "the launches of different lanes run concurrently with each other's scan and detect kernels, which stretches each of them",
-            "kernel_ms_isolated": round(iso_ms, 4) if iso_ms else None,
-            "frac_isolated": round(samples_per_step_rank * bytes_per_sample / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms else None,
-            "isolated_note": f"one launch over all {S} streams of the rank, one lane, {args.isolated_steps} steps after the timed region",
-            "detect_kernel_ms": round(ms_detect / max(1, args.steps) / lanes, 4),
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "whole_path_frac": round(value * 1e6 / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
-        },
+        "roofline": roofline,
+        "host_sinks": sinks,
     }
     if base is not None:
         out["cpu_baseline"] = base
@@ -379,6 +470,47 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def host_sinks(decoder, rec, device_names, records_per_s_produced):
+    """Records/s through the host-side consumers, on one core, outside the timed region: (a) `decoder.signals` -- one
+    `Signal` object per record, what the reference's path ends in (`signal_queue.put(Signal)`, analyze.py:251, 280);
+    (b) `rows_from_analysis` + the native CSV formatter (pyradiotracking_amd/consume.py) -- no Python object per
+    record.  `records_per_s_produced` is what the timed steps delivered as rt_record arrays."""
+    import datetime
+
+    import numpy as np
+
+    from pyradiotracking_amd import consume
+    from pyradiotracking_amd.match import datetime_to_us
+
+    n = len(rec)
+    out = {
+        "timed_region_ends_at": "rt_record arrays in pinned host memory (rt_fetch); the sinks below run after it and are NOT part of `value`",
+        "records_per_s_produced": round(records_per_s_produced, 1),
+        "sample_records": int(n),
+        "cores": 1,
+    }
+    if n == 0:
+        return out
+    ts0 = [datetime.datetime(2024, 1, 1)] * len(device_names)
+    ts0_us = [datetime_to_us(ts0[0])] * len(device_names)
+    kept = rec[rec["shadowed"] == 0]
+
+    def rate(fn, count):
+        reps, t = 0, 0.0
+        while t < 0.5 and reps < 50:
+            t0 = time.perf_counter()
+            fn()
+            t += time.perf_counter() - t0
+            reps += 1
+        return round(count * reps / t, 1)
+
+    out["signal_objects_per_s"] = rate(lambda: decoder.signals(kept, device_names, ts0), len(kept))
+    out["csv_rows_per_s"] = rate(lambda: consume.format_signals("csv", consume.rows_from_analysis(rec, decoder, ts0_us), device_names), len(kept))
+    out["note"] = ("signal_objects_per_s: Signal objects built from the records that pass the shadow filter (the reference's signal_queue.put payload); "
+                   "csv_rows_per_s: the same records to `;`-separated CSV rows through rows_from_analysis + rt_format_signals")
+    return out
 
 
 def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -97,7 +97,11 @@ typedef struct rt_config {
                                    contiguous groups, each analysed on its own HIP stream (hip_stream must be
                                    NULL), so that the detection kernels and launch gaps of one group overlap the
                                    scan of another; same records, rt_fetch still returns them in stream order     */
-    int32_t reserved;
+    int32_t record_pool;        /* records the pinned result pool of a call holds at first (0 = default:
+                                   min(n_streams * record_capacity, 4 Mi)).  A call that needs more grows the pool
+                                   and is analysed again when it is fetched, so nothing is lost up to
+                                   record_capacity records per stream (the reference appends without limit,
+                                   analyze.py:449-450)                                                            */
 } rt_config;
 
 #define RT_FLAG_TIMING 1u /* record HIP events around the kernels of each call */

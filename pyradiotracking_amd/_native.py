@@ -52,7 +52,7 @@ class RtConfig(C.Structure):
         ("flags", C.c_int32),
         ("hip_stream", C.c_void_p),
         ("lanes", C.c_int32),
-        ("reserved", C.c_int32),
+        ("record_pool", C.c_int32),
     ]
 
 
@@ -254,6 +254,7 @@ class NativeAnalyzer:
         hip_stream: Optional[int] = None,
         lanes: int = 1,
         subtract_first: bool = False,
+        record_pool: int = 0,
     ):
         self._lib = load_library()
         self._handle = C.c_void_p()
@@ -280,6 +281,7 @@ class NativeAnalyzer:
         cfg.flags = (RT_FLAG_TIMING if timing else 0) | (RT_FLAG_NO_LIN_DETREND if subtract_first else 0)
         cfg.hip_stream = hip_stream
         cfg.lanes = int(lanes)
+        cfg.record_pool = int(record_pool)
         rc = self._lib.rt_create(C.byref(cfg), C.byref(self._handle))
         if rc != RT_OK:
             self._handle = C.c_void_p()

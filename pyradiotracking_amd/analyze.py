@@ -158,9 +158,14 @@ class BatchSignalAnalyzer:
         hip_stream: Optional[int] = None,
         lanes: int = 1,
         subtract_first: bool = False,
+        record_pool: int = 0,
         **kwargs,
     ):
-        """``subtract_first``: apply SciPy's ``detrend='constant'`` in SciPy's order (segment mean subtracted before
+        """``record_pool`` (``rt_config.record_pool``): records the pinned result pool holds at first (0: up to 4 Mi); a
+        buffer with more signals grows it -- the reference appends without limit (``analyze.py:449-450``), here only
+        ``record_capacity`` per stream bounds a call.
+
+        ``subtract_first``: apply SciPy's ``detrend='constant'`` in SciPy's order (segment mean subtracted before
         the window) even for hamming / hann / boxcar windows, where the kernels by default subtract ``mean * FFT(window)``
         from the three bins it touches instead (equal within float32 round-off, fewer operations).
 
@@ -217,6 +222,7 @@ class BatchSignalAnalyzer:
             hip_stream=hip_stream,
             lanes=max(1, int(lanes)),
             subtract_first=bool(subtract_first),
+            record_pool=int(record_pool),
         )
         if per_stream_cal is not None:
             self.calibration_db = per_stream_cal
@@ -448,6 +454,8 @@ class SignalAnalyzer:
             sdr_callback_length=sdr_callback_length,
             gpu=gpu,
             mode=mode,
+            # capacities of the native handle (no counterpart in the reference, whose lists are unbounded)
+            **{k: kwargs[k] for k in ("record_capacity", "record_pool", "hot_capacity") if k in kwargs},
         )
         self._decoder = self._batch._decoder
 

@@ -37,7 +37,9 @@ thread_local std::string g_create_error;
 
 constexpr int kSlots = 2;
 constexpr int kTails = 3;
-constexpr int64_t kMaxPoolRecords = 4 << 20;  // pinned record pool per slot: at most 4 Mi records (160 MiB)
+constexpr int64_t kInitialPoolRecords = 4 << 20;  // pinned record pool per slot at rt_create unless rt_config.record_pool says otherwise
+                                                  // (4 Mi records = 160 MiB); a call that needs more grows it (grow_pool), up to what
+                                                  // n_streams * record_capacity can ever deliver
 constexpr int kMaxPartial = 32;  // AUTO: up to this many overflowing streams of a batch are re-run dense on their own
 
 struct CallCtx {
@@ -55,6 +57,7 @@ struct CallCtx {
     bool u8 = false;        // IQ is interleaved uint8 (RTL-SDR wire format)
     bool no_last = false;   // the slot's h_no_last flags apply (some stream was reset, rt_reset_stream)
     int n_dense_streams = 0;  // streams of this call that were re-run dense on their own (AUTO, partial fall-back)
+    bool pool_grown = false;  // the record pool was enlarged for this call and the call analysed again (fetch_one)
     // handle state before this call (restored when the call is rolled back: a later lane failed to enqueue)
     int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0;
 };
@@ -75,6 +78,7 @@ struct Slot {
     unsigned long long *h_counters = nullptr;
     int32_t *h_rec_offset = nullptr, *h_rec_count = nullptr;  // [S]
     rt_record *h_records = nullptr;                            // [pool_cap]
+    int64_t pool_cap = 0;                                      // records the slot's pool holds (grows on demand, grow_pool)
     int32_t *h_no_last = nullptr;                              // pinned, [S]: streams without a previous buffer in this call
     int32_t *h_overflow = nullptr;                             // pinned, [S]: set by detect_bucket for a stream whose candidate lists overflowed
     int32_t *h_incons = nullptr;                               // pinned, [S]: ... and for one in which a run lacked its preceding cell
@@ -107,7 +111,8 @@ struct rt_handle {
     float *d_spec_part = nullptr;              // ... and one for min(S, kMaxPartial) streams (partial dense re-run)
     void *d_iq_stage[kSlots] = {nullptr, nullptr};  // for rt_process_host: one per call slot (a call's IQ must stay
     size_t iq_stage_bytes[kSlots] = {0, 0};         // in place until it is fetched -- AUTO mode may re-run it dense)
-    int64_t pool_cap = 0;
+    int64_t pool_want = 0;  // records every slot's pool should hold: the largest size any call has needed so far
+    int64_t pool_max = 0;   // ... and the most any call can deliver: (n_streams + partial re-runs) * record_capacity
     Slot slot[kSlots];
 
     int hot_cap = 8192, rec_cap = 1024, cand_cap = 32;
@@ -188,25 +193,53 @@ void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
 }
 
 // cells a run must have to pass the duration gate unless it runs through t = 0 (see rt_create)
-long long min_run_cells(const rt_handle *h) {
-    const double hop = seg_time(1, h->N, h->cfg.sample_rate) - seg_time(0, h->N, h->cfg.sample_rate);
-    const double cells = h->cfg.min_duration_s * (1.0 - 1e-9) / hop;
+long long min_run_cells(const rt_config &cfg, int N) {
+    const double hop = seg_time(1, N, cfg.sample_rate) - seg_time(0, N, cfg.sample_rate);
+    const double cells = cfg.min_duration_s * (1.0 - 1e-9) / hop;
     return (long long)std::ceil(std::min(cells, 1.0e9)) - 1;
 }
+long long min_run_cells(const rt_handle *h) { return min_run_cells(h->cfg, h->N); }
 
-int choose_chunk(const rt_handle *h, int n_seg) {
-    if (h->cfg.segs_per_chunk > 0) return h->cfg.segs_per_chunk;
+// segments per chunk for a handle of `n_streams` streams (for a laned handle: of all lanes together -- the lanes take the
+// parent's choice, so that a stream's row sums are added in the same order however the batch is split into lanes)
+int choose_chunk(const rt_config &cfg, int R3, int n_streams, int n_seg) {
+    if (cfg.segs_per_chunk > 0) return cfg.segs_per_chunk;
+    const int N = 256 * R3, GPW = kBlock / (16 * R3);
     // enough workgroups to fill 256 CUs several times over, halo overhead <= 1/L
     int L = 32;
     // ... but where the run-length pre-filter is possible with chunks of 32 (minimum duration >= 64 hops) the chunks
     // stay that long for small batches too: its selectivity is p^L (a small batch is launch-bound anyway)
     // (whatever the mode: the chunk length sets the order of the row sums' partial sums, and the modes return the same bits)
-    const bool keep_long = 2ll * L - 1 <= min_run_cells(h) && n_seg >= 2 * L;
+    const bool keep_long = 2ll * L - 1 <= min_run_cells(cfg, N) && n_seg >= 2 * L;
     while (L > 4 && !keep_long) {
         const int64_t chunks = (n_seg + L - 1) / L;
-        const int64_t blocks = (int64_t)h->cfg.n_streams * ((chunks + h->GPW - 1) / h->GPW);
+        const int64_t blocks = (int64_t)n_streams * ((chunks + GPW - 1) / GPW);
         if (blocks >= 2048) break;
         L >>= 1;
+    }
+    if (L == 32 && !keep_long && R3 >= 4) {
+        // nperseg >= 1024, a batch that fills the chip: the chunk length is chosen by what a workgroup costs.  All lane
+        // groups of a workgroup take L steps (a last chunk that is short leaves its group idle), and a workgroup pays
+        // c0 steps on top: tables into LDS, the first segment's HBM round trip with nothing to overlap it, the halo
+        // step (nperseg 4096), the row-sum epilogue.  Measured (profiles/r03_a_chunk_length_sweep.txt, one lane):
+        // nperseg 4096, 781 segments: L = 32 -> 71 (11 chunks, none short) takes 5.8 - 6.7 % less time at 1 024 and at
+        // 4 096 streams, L = 52 (a last chunk of one segment) 1.6 % more; that fits c0 = 3.8.  nperseg 1024, 2 343 segments,
+        // four chunks to a workgroup: L = 28 / 31 (84 / 76 chunks: 21 / 19 full workgroups) take 4 % less than 32 (19
+        // workgroups, three chunk slots idle), 36 and 64 more: c0 = 2.  (No term for the end of the launch: the choice
+        // must not depend on the number of streams, or shards of one population would add their row sums in different orders.)
+        const double c0 = R3 >= 8 ? 3.8 : 2.0;
+        const int lo = 24, hi = R3 >= 8 ? 80 : 40;
+        double best = 0.0;
+        for (int cand = lo; cand <= hi; ++cand) {
+            const int64_t chunks = (n_seg + cand - 1) / cand;
+            const int64_t wgs = (chunks + GPW - 1) / GPW;
+            if ((int64_t)n_streams * wgs < 2048) break;
+            const double cost = (double)wgs * (cand + c0);
+            if (best == 0.0 || cost < best * (1.0 - 1e-9)) {
+                best = cost;
+                L = cand;
+            }
+        }
     }
     return L;
 }
@@ -276,7 +309,7 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.raw_count = sl.d_raw_count;
     a.psum = sl.d_psum;
     a.records = sl.h_records;
-    a.pool_cap = h->pool_cap;
+    a.pool_cap = sl.pool_cap;
     a.rec_cap = h->rec_cap;
     a.rec_offset = sl.h_rec_offset;
     a.rec_count = sl.h_rec_count;
@@ -421,12 +454,41 @@ int enqueue_partial_dense(rt_handle *h, Slot &sl, int n_list, unsigned long long
     return RT_OK;
 }
 
+// A call needed more records than the slot's pinned pool holds: a larger pool (the reference appends without limit,
+// analyze.py:449-450; here the limit is what the streams' record_capacity can deliver).  Only while none of the slot's
+// kernels is in flight.  Failure leaves the old pool in place.
+int grow_pool(rt_handle *h, Slot &sl, int64_t want) {
+    want = std::min(want, h->pool_max);
+    if (want <= sl.pool_cap) return RT_OK;
+    int64_t cap = std::min(h->pool_max, std::max(want + want / 4, 2 * sl.pool_cap));
+    rt_record *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, (size_t)cap * sizeof(rt_record));
+    if (e != hipSuccess && cap > want) {
+        cap = want;
+        e = hipHostMalloc(&p, (size_t)cap * sizeof(rt_record));
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        h->err = "record pool of " + std::to_string(cap) + " records: " + hipGetErrorString(e);
+        return RT_E_NOMEM;
+    }
+    (void)hipHostFree(sl.h_records);
+    sl.h_records = p;
+    sl.pool_cap = cap;
+    h->pool_want = std::max(h->pool_want, cap);
+    return RT_OK;
+}
+
 // claim the slot of the next call; the GPU work of the call that used it last must be over
 // before its scratch is rewritten (its results, if never fetched, are dropped)
 int claim_slot(rt_handle *h, Slot **out, CallCtx *saved) {
     Slot &sl = h->slot[h->n_calls % kSlots];
     // (everything of this handle runs in order on one stream, so the slot's previous GPU work is over
     // before anything enqueued from here on starts: no event wait needed)
+    if (sl.pool_cap < h->pool_want && !sl.call.pending) {
+        // the other slot's pool had to grow: this one follows before its next call needs it (best effort)
+        if (sl.call.seq == 0 || hipEventSynchronize(sl.ev_done) == hipSuccess) (void)grow_pool(h, sl, h->pool_want);
+    }
     *saved = sl.call;  // put back if the new call fails before it has launched anything
     sl.call = CallCtx{};
     sl.call.seq = h->n_calls + 1;
@@ -573,6 +635,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         for (int k = 0; k < lanes; ++k) {
             rt_config kc = *cfg;
             kc.lanes = 1;
+            kc.segs_per_chunk = choose_chunk(*cfg, R3, cfg->n_streams, (int)(cfg->max_samples / cfg->nperseg));  // the whole batch's choice
             kc.n_streams = p->kid_base[(size_t)k + 1] - p->kid_base[(size_t)k];
             rt_handle *kid = nullptr;
             const int rc = rt_create(&kc, &kid);
@@ -612,7 +675,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         if (h->K < 1) h->K = 1;
     }
     h->max_seg = (int)(cfg->max_samples / h->N);
-    h->L = choose_chunk(h, h->max_seg);  // fixed per handle so the scratch bound holds for every call
+    h->L = choose_chunk(*cfg, R3, cfg->n_streams, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
     const int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
     h->max_blocks = max_blocks_per_stream;
@@ -733,8 +796,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     const size_t psum_bytes = (size_t)S * max_blocks_per_stream * N * sizeof(float);
     const size_t tail_bytes = (size_t)S * h->K * N * sizeof(float);
     for (auto &t : h->d_tail) RT_CREATE_HIP(hipMalloc(&t, tail_bytes));
-    h->pool_cap = std::min<int64_t>((int64_t)S * h->rec_cap, kMaxPoolRecords);
+    // (the records of streams re-run dense on their own go behind the ones already in the pool: their first lists stay orphaned)
+    h->pool_max = ((int64_t)S + std::min(S, kMaxPartial)) * h->rec_cap;
+    h->pool_want = std::min<int64_t>(h->pool_max, cfg->record_pool > 0 ? (int64_t)cfg->record_pool : std::min<int64_t>((int64_t)S * h->rec_cap, kInitialPoolRecords));
     for (auto &sl : h->slot) {
+        sl.pool_cap = h->pool_want;
         RT_CREATE_HIP(hipMalloc(&sl.d_psum, std::max<size_t>(psum_bytes, 4)));
         if (h->prefilter_ok && cfg->mode != RT_MODE_DENSE)
             RT_CREATE_HIP(hipMalloc(&sl.d_full, (size_t)S * (h->max_chunks + h->L) * LG * sizeof(uint16_t)));  // + the bits of chunk 0 by segment
@@ -754,7 +820,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipHostMalloc(&sl.h_counters, 4 * sizeof(unsigned long long)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_offset, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_count, (size_t)S * sizeof(int32_t)));
-        RT_CREATE_HIP(hipHostMalloc(&sl.h_records, (size_t)h->pool_cap * sizeof(rt_record)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_records, (size_t)sl.pool_cap * sizeof(rt_record)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_no_last, (size_t)S * sizeof(int32_t)));
         std::memset(sl.h_no_last, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_overflow, (size_t)S * sizeof(int32_t)));
@@ -1096,6 +1162,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     h->info = rt_call_info{};
     h->info.n_seg = c.n_seg;
     h->info.n_hot = 0;
+  for (;;) {  // (a second round only after the record pool had to grow)
     while ((flags & kFlagHotOverflow) && !c.is_extract && c.mode_used != RT_MODE_DENSE) {
         // which streams overflowed?  (the flags are consumed here, whatever happens next)  The scan stops emitting for a
         // stream once one of its lists has overflowed, so a "run without its preceding cell" in such a stream is not an
@@ -1124,13 +1191,17 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             if (n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams && level_up(h, c.mode_used) == RT_MODE_DENSE) {
                 const unsigned long long other = flags & ~(kFlagHotOverflow | (incons_elsewhere ? 0ull : kFlagInconsistent));
                 int rc = enqueue_partial_dense(h, sl, n_bad, sl.h_counters[0]);
-                if (rc != RT_OK) return rc;
-                RT_HIP(h, hipEventSynchronize(sl.ev_done));
-                flags = other | sl.h_counters[2];
-                sl.h_counters[2] = flags;  // (the laned rt_fetch looks at this call twice: sizing, then delivery)
-                c.fell_back = true;
-                c.n_dense_streams = n_bad;
-                break;
+                if (rc == RT_OK) {
+                    RT_HIP(h, hipEventSynchronize(sl.ev_done));
+                    flags = other | sl.h_counters[2];
+                    sl.h_counters[2] = flags;  // (the laned rt_fetch looks at this call twice: sizing, then delivery)
+                    c.fell_back = true;
+                    c.n_dense_streams = n_bad;
+                    break;
+                }
+                // the partial re-run could not be enqueued (its scratch spectrogram did not fit): the whole batch goes one
+                // level up instead, which needs no scratch of its own or reports its own failure
+                if (rc != RT_E_NOMEM) return rc;
             }
         }
         // Re-run of the same buffer with the same look-back state, one level up.  Everything of this handle runs in
@@ -1152,6 +1223,26 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         RT_HIP(h, hipEventSynchronize(sl.ev_done));
         flags = sl.h_counters[2];
     }
+    // The call found more records than the slot's pinned pool holds (word 0 = records wanted): streams beyond its end
+    // got truncated lists.  The pool grows and the call is analysed again on the level it ended on -- same buffer, same
+    // look-back state, like a fall-back re-run -- so the caller loses nothing; later calls find the larger pool.  Not
+    // possible for rt_extract (the caller's spectrogram is not kept) or when the host has no memory left: then the
+    // truncated lists are delivered with RT_E_CAPACITY.
+    if ((flags & kFlagRecOverflow) && !c.is_extract && c.n_seg > 0 && sl.h_counters[0] > (unsigned long long)sl.pool_cap &&
+        sl.pool_cap < h->pool_max && !c.pool_grown) {
+        if (grow_pool(h, sl, (int64_t)std::min<unsigned long long>(sl.h_counters[0], (unsigned long long)h->pool_max)) == RT_OK) {
+            c.pool_grown = true;  // once per call
+            for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
+            c.n_dense_streams = 0;
+            int rc = enqueue_analysis(h, sl, c.mode_used);
+            if (rc != RT_OK) return rc;
+            RT_HIP(h, hipEventSynchronize(sl.ev_done));
+            flags = sl.h_counters[2];
+            continue;
+        }
+    }
+    break;
+  }
     if (c.mode_used != RT_MODE_DENSE && !c.is_extract && c.n_seg > 0)
         for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
     auto rank = [](int mode) { return mode == RT_MODE_SPARSE ? 0 : mode == RT_MODE_PREFILTER ? 1 : 2; };
@@ -1198,7 +1289,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     }
     // (out == NULL / cap == 0 with records available is a size query: the call stays pending)
     if (flags & kFlagRecOverflow) {
-        h->err = "record capacity exceeded (record_capacity); results truncated";
+        h->err = "record capacity exceeded (record_capacity per stream, or the record pool could not grow); results truncated";
         return RT_E_CAPACITY;
     }
     return RT_OK;

@@ -140,7 +140,11 @@ __device__ __forceinline__ void flush_stage(const StftParams &p, int s, const ui
 
 template <int LG>
 __device__ __forceinline__ void group_sync() {
+#ifdef RT_EXP_NOBAR1  // timing-only diagnostic: the exchange without its workgroup barrier (wrong spectra)
+    if constexpr (false) {
+#else
     if constexpr (LG > 64) {
+#endif
         __syncthreads();
     } else {
         // a lane group lives inside one wave: DS operations of a wave execute
@@ -189,7 +193,9 @@ __device__ __forceinline__ cf group_sum(cf v, cf *red /* [kBlock/64] LDS */) {
         const int wave = threadIdx.x >> 6;
         constexpr int WPG = LG / 64;  // waves per group
         if ((threadIdx.x & 63) == 0) red[wave] = v;
+#ifndef RT_EXP_NOBAR0  // timing-only diagnostic: without the barrier (wrong sums, exchange rows unprotected)
         __syncthreads();
+#endif
         const int w0 = (wave / WPG) * WPG;
         cf s{0.f, 0.f};
 #pragma unroll
@@ -536,10 +542,15 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
         // whole prefetch, i.e. expose an HBM round trip in every step (it did: 1.01 ms per launch).
         float wreg[W_IN_LDS ? 1 : 16];
         if constexpr (!W_IN_LDS) {
+#ifdef RT_EXP_NOWIN  // timing-only diagnostic: no window loads (wrong spectra)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) wreg[m] = 0.5f + 0.01f * m;
+#else
             const rsrc_t rw = make_rsrc(p.window, (uint32_t)(N * sizeof(float)));
 #pragma unroll
             for (int m = 0; m < 16; ++m) wreg[m] = raw_buffer_load_f1(rw, lt * 4, LG * m * 4, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep the order of the two groups of loads
+#endif
         }
         // next step's segment (the segment below the chunk is requested at the end of step L, once it is known to be needed)
         if constexpr (BELOW) {
@@ -1160,16 +1171,18 @@ __device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int n) {
     int *lds_base = l.count + 1;
     if (threadIdx.x == 0) {
         long long base = (long long)atomicAdd(&a.counters[0], (unsigned long long)n);
-        if (base + n > a.pool_cap) {
-            atomicOr(&a.counters[2], kFlagRecOverflow);
-            base = -1;
-        }
-        *lds_base = (int)base;
-        a.rec_offset[s] = base < 0 ? 0 : (int)base;
-        a.rec_count[s] = base < 0 ? 0 : n;
+        // a pool too short for this stream: the first records (in emission order) that still fit are delivered, the
+        // call is flagged, and counters[0] tells the host how large a pool the call wants (rt_fetch grows it)
+        long long fit = a.pool_cap - base;
+        fit = fit < 0 ? 0 : (fit > n ? n : fit);
+        if (fit < n) atomicOr(&a.counters[2], kFlagRecOverflow);
+        lds_base[0] = fit > 0 ? (int)base : -1;
+        lds_base[1] = (int)fit;
+        a.rec_offset[s] = fit > 0 ? (int)base : 0;
+        a.rec_count[s] = (int)fit;
     }
     __syncthreads();
-    const int base = *lds_base;
+    const int base = lds_base[0], n_fit = lds_base[1];
     if (base < 0) return;
     const float cal_db = a.cal_s ? a.cal_s[s] : a.dp.cal_db;
     // rt::rank_and_shadow with the dBW figure of every record's maximum computed once (parked in the record's
@@ -1189,7 +1202,7 @@ __device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int n) {
         rt_record out = l.rec[i];
         out.shadowed = shadow;
         out.reserved = 0;
-        a.records[(int64_t)base + rank] = out;
+        if (rank < n_fit) a.records[(int64_t)base + rank] = out;
     }
 }
 
@@ -1693,6 +1706,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     __shared__ rt_record t_rec[kFinalTile];
     __shared__ long long t_ts[kFinalTile], t_dur[kFinalTile];
     __shared__ long long sh_base;
+    __shared__ int sh_fit;
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     int n = a.raw_count[s];
@@ -1706,11 +1720,15 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
         a.hot_total[s] = (int32_t)tot;
         const unsigned long long v = atomicAdd(&a.counters[0], (unsigned long long)n | (1ull << kTicketShift));
         const unsigned long long mask = (1ull << kTicketShift) - 1ull;
-        long long base = (long long)(v & mask);
-        if (base + n > a.pool_cap) base = -1;
-        sh_base = base;
-        a.rec_offset[s] = base < 0 ? 0 : (int)base;
-        a.rec_count[s] = base < 0 ? 0 : n;
+        const long long base = (long long)(v & mask);
+        // a pool too short for this stream: its first records (in emission order) that still fit are delivered; the
+        // call's total below tells the host how large a pool the call wants (rt_fetch grows it and runs the call again)
+        long long fit = a.pool_cap - base;
+        fit = fit < 0 ? 0 : (fit > n ? n : fit);
+        sh_base = fit > 0 ? base : -1;
+        sh_fit = (int)fit;
+        a.rec_offset[s] = fit > 0 ? (int)base : 0;
+        a.rec_count[s] = (int)fit;
         if ((v >> kTicketShift) + 1ull == (unsigned long long)gridDim.x) {
             // every workgroup has added its records: publish the counter words, leave them zero for the slot's next call
             const unsigned long long total = __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask;
@@ -1725,6 +1743,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     }
     __syncthreads();
     const long long base = sh_base;
+    const int n_fit = sh_fit;
     if (n == 0 || base < 0) return;
     const float cal_db = a.cal_s ? a.cal_s[s] : a.dp.cal_db;
     const rt_record *raw = a.raw + (int64_t)s * a.rec_cap;
@@ -1767,7 +1786,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
         if (i < n) {
             mine.shadowed = shadow;
             mine.reserved = 0;
-            a.records[base + rank] = mine;
+            if (rank < n_fit) a.records[base + rank] = mine;
         }
     }
 }

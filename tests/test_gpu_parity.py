@@ -629,6 +629,64 @@ def test_a_truncated_call_is_consumed(mode):
     assert b.fetch_records().tobytes() == want_few.tobytes()
 
 
+@pytest.mark.parametrize("mode,lanes", [("sparse", 1), ("dense", 1), ("sparse", 2)])
+def test_the_record_pool_grows_instead_of_losing_streams(mode, lanes):
+    """The reference appends signals without limit (analyze.py:449-450).  A call that finds more records than the pinned
+    pool holds grows the pool and is analysed again when it is fetched: every stream keeps all its records, order intact,
+    byte-identical to a handle whose pool was large from the start -- also with two calls in flight, and in both slots."""
+    _need_gpu()
+    fs, nperseg, blen, S = 2048000, 256, 1200 * 256, 6
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(21)
+    kw = dict(sample_rate=fs, signal_min_duration_ms=2.0)
+    bufs = [np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 14, dur_ms=(3, 6), keep_clear_tail=1024)), 90 + 10 * k + s)
+                      for s in range(S)]) for k in range(3)]
+    ref = _batch_for(kw, S, blen, mode)
+    want = []
+    for x in bufs:
+        ref.enqueue(x)
+        want.append(ref.fetch_records())
+    counts = np.bincount(want[0]["stream"], minlength=S)
+    assert counts.min() > 8 and len(want[0]) > 64, counts
+    b = _batch_for(kw, S, blen, mode, lanes=lanes, record_pool=16)  # < one stream's records
+    b.enqueue(bufs[0])
+    b.enqueue(bufs[1])  # second slot, enqueued while the first call's pool is still too small
+    got0 = b.fetch_records()
+    got1 = b.fetch_records()
+    b.enqueue(bufs[2])
+    got2 = b.fetch_records()
+    for k, (g, wnt) in enumerate(zip((got0, got1, got2), want)):
+        assert g.tobytes() == wnt.tobytes(), (k, len(g), len(wnt))
+    assert not b.native.last_truncated
+
+
+def test_a_pool_that_cannot_grow_delivers_the_first_records_in_order():
+    """rt_extract analyses a caller-owned spectrogram the library does not keep, so the call cannot be run again with
+    a larger pool: the records that fit the pool are delivered in emission order with RT_E_CAPACITY (never an empty list)."""
+    _need_gpu()
+    fs, nperseg, F, T = 2048000, 256, 256, 400
+    an = SignalAnalyzer("0", sample_rate=fs, fft_nperseg=nperseg, sdr_callback_length=4096, signal_min_duration_ms=1.0)
+    small = SignalAnalyzer("0", sample_rate=fs, fft_nperseg=nperseg, sdr_callback_length=4096, signal_min_duration_ms=1.0, record_pool=10)
+    rng = np.random.default_rng(3)
+    cur = (rng.exponential(1.0, (F, T)) * 1e-12).astype(np.float32)
+    for j in range(40):
+        cur[5 * j + 3, 20 + 7 * j: 20 + 7 * j + 12] = 1e-7 * (1 + j)
+    freqs = np.fft.fftfreq(F, 1 / fs)
+    times = (nperseg / 2 + np.arange(T) * nperseg) / float(fs)
+    full = an.extract_signals(freqs, times, cur, gu.TS0)
+    assert len(full) == 40
+    with pytest.raises(_native.NativeError) as e:
+        small.extract_signals(freqs, times, cur, gu.TS0)
+    assert e.value.code == _native.RT_E_CAPACITY
+    nat = small._batch.native
+    import torch
+    d = torch.from_numpy(np.ascontiguousarray(cur.T)).cuda()
+    nat.extract_device(d.data_ptr(), T, F, None, 0)
+    part = nat.fetch(allow_truncated=True)
+    assert nat.last_truncated and len(part) == 10
+    assert part.tobytes() == an._last_records[:10].tobytes()
+
+
 def test_pipelined_uint8_host_buffers_of_growing_length():
     """uint8 host buffers of different lengths, two calls in flight, the first one re-run dense when it is fetched:
     the staged bytes of a call stay in place (and allocated) until it is fetched (found by the randomised soak: the

@@ -127,12 +127,14 @@ def test_blocks_on_separate_handles_equal_single_batch_in_process():
     assert [a.tobytes() for a in laned] == [a.tobytes() for a in whole]
 
 
-def _run_bench(n_gpus, extra):
+def _run_bench(n_gpus, extra, launcher=True):
     env = dict(os.environ, RT_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
     args = ["--gpus", str(n_gpus), "--steps", "3", "--warmup", "1", "--settle", "2", "--isolated-steps", "2", "--cpu-streams", "4",
             "--parity-streams", "4"] + extra
-    if n_gpus == 1:
-        cmd = [sys.executable, os.path.join(REPO, "bench.py")] + args
+    if n_gpus == 1 or not launcher:
+        cmd = [sys.executable, os.path.join(REPO, "bench.py")] + args  # N > 1: bench.py starts its ranks itself
     else:
         # the driver's launch line; the launcher is a fresh process that never touches the GPU itself
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
@@ -151,6 +153,31 @@ def test_bench_two_ranks_share_one_gpu_weak():
     assert d["value"] > 0 and d["config"]["fallbacks"] == 0 and d["config"]["records_per_step"] > 0
     assert d["parity"]["streams_checked"] == 4 and d["parity"]["streams_mismatched"] == 0  # first + last of both shards
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` typed by hand (no RANK / WORLD_SIZE): the script spawns the two ranks itself before it
+    touches a GPU, relays rank 0's one JSON line, names each rank's device"""
+    d = _run_bench(2, ["--streams", "32"], launcher=False)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["streams_total"] == 64
+    assert d["value"] > 0 and d["config"]["fallbacks"] == 0 and d["config"]["records_per_step"] > 0
+    assert d["parity"]["streams_checked"] == 4 and d["parity"]["streams_mismatched"] == 0
+    devs = d["config"]["devices"]
+    assert [x["rank"] for x in devs] == [0, 1] and all(x["ordinal"] == 0 for x in devs)  # RT_BENCH_SHARE_GPU: both on GPU 0
+    assert all(x["name"] for x in devs)
+
+
+def test_bench_line_prices_the_isolated_launch():
+    """`roofline.frac` / `kernel_ms` describe the scan launch alone (one lane); the per-launch figures of the two-lane
+    timed region sit beside them; the host sinks are reported outside `value`"""
+    d = _run_bench(1, ["--streams", "32"])
+    r = d["roofline"]
+    assert r["kernel_ms"] > 0 and r["kernel_ms_concurrent"] > 0 and r["launches_per_step_timed_region"] == 2
+    assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 2e-3 * max(r["frac"], 1e-3) + 1e-4
+    assert r["algorithmic_bytes_per_launch"] == 32 * 8000 * 256 * 8
+    h = d["host_sinks"]
+    assert h["records_per_s_produced"] > 0 and h["signal_objects_per_s"] > 0 and h["csv_rows_per_s"] > 0
+    assert d["config"]["devices"][0]["ordinal"] == 0 and len(d["config"]["devices"]) == 1
 
 
 def test_bench_strong_scaling_population_is_the_same_at_every_n():

@@ -28,3 +28,4 @@ for i in range(12):
     if i >= 2: acc += an.native.call_info().ms_stft
 ms = acc / 10
 print(f"N={nperseg} S={S} lib={os.environ.get('RT_ANALYZE_LIB','default').split('/')[-1]} load-only {ms_load:.3f} ms ({gb/ms_load:.0f} GB/s)  scan {ms:.3f} ms ({gb/ms:.0f} GB/s)")
+an.close()
