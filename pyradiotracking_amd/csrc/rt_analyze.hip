@@ -104,7 +104,10 @@ struct rt_handle {
     bool own_scan_stream = false;
     std::string err;
 
+    int n_cu = 256;            // compute units of the device (the scan's grid: launch_stft_lin)
+    uint32_t *d_work = nullptr;  // the scan kernels' item counters (StftParams::work), zero between launches
     float *d_window = nullptr;
+    float *d_window_t = nullptr;  // nperseg 4096: the window in lane order (StftParams::window_t)
     cf *d_tw1 = nullptr, *d_tw2 = nullptr;
     float *d_tail[kTails] = {nullptr, nullptr, nullptr};
     float *d_spec = nullptr;                   // lazily allocated dense spectrogram (shared)
@@ -169,14 +172,25 @@ int next_pow2(int v) {
     return p;
 }
 
+// `items` work items (one per stream and group of GPW chunks).  Every mode but the selective pass runs them on a grid
+// that just fills the chip: CUs x the workgroups of this instantiation a CU holds (its __launch_bounds__), each
+// workgroup drawing further items from p.work (rt_kernels.h: "Work items") -- more workgroups than that would only
+// queue in the dispatcher and find the counter exhausted.
 template <int MODE, bool U8, bool LIN>
-void launch_stft_lin(rt_handle *h, const StftParams &p, int blocks) {
+void launch_stft_lin(rt_handle *h, const StftParams &p, int items) {
+    const int blk = scan_block(h->R3);
+    // workgroups a CU holds: three waves per SIMD by registers (four for the leaner uint8 / RT_WG4 instantiations), and at
+    // nperseg 256 twelve one-wave workgroups by LDS whatever the registers allow
+    const int per_cu = std::min(((h->R3 <= RT_WG4_MAX_R3 || (U8 && h->R3 == 1)) ? 4 : 3) * (kBlock / blk), blk == 64 ? 12 : 4);
+    // (A/B on one box, whole path, profiles/r03_h_persistent_ab.txt: config 3 one lane 662 k -> 684 k MS/s, config 5 share +1 %)
+    const bool persist = scan_persistent(h->R3, MODE);
+    const int blocks = persist ? std::min(items, h->n_cu * per_cu) : items;
     switch (h->R3) {
-        case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
-        default: hipLaunchKernelGGL((stft_scan<16, MODE, U8, LIN>), dim3(blocks), dim3(kBlock), 0, h->s_scan, p); break;
+        case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+        case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+        case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+        case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+        default: hipLaunchKernelGGL((stft_scan<16, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
     }
 }
 
@@ -204,7 +218,7 @@ long long min_run_cells(const rt_handle *h) { return min_run_cells(h->cfg, h->N)
 // parent's choice, so that a stream's row sums are added in the same order however the batch is split into lanes)
 int choose_chunk(const rt_config &cfg, int R3, int n_streams, int n_seg) {
     if (cfg.segs_per_chunk > 0) return cfg.segs_per_chunk;
-    const int N = 256 * R3, GPW = kBlock / (16 * R3);
+    const int N = 256 * R3, GPW = scan_block(R3) / (16 * R3);
     // enough workgroups to fill 256 CUs several times over, halo overhead <= 1/L
     int L = 32;
     // ... but where the run-length pre-filter is possible with chunks of 32 (minimum duration >= 64 hops) the chunks
@@ -227,13 +241,16 @@ int choose_chunk(const rt_config &cfg, int R3, int n_streams, int n_seg) {
         // four chunks to a workgroup: L = 28 / 31 (84 / 76 chunks: 21 / 19 full workgroups) take 4 % less than 32 (19
         // workgroups, three chunk slots idle), 36 and 64 more: c0 = 2.  (No term for the end of the launch: the choice
         // must not depend on the number of streams, or shards of one population would add their row sums in different orders.)
-        const double c0 = R3 >= 8 ? 3.8 : 2.0;
+        // nperseg 2048 (no halo step: c0 = 2.8; 512 streams x 1 000 segments): L = 72 (7 workgroups per stream) 2 % less
+        // than 32, but 48 / 62 / 77 take 4 - 13 % more -- with 3 584 workgroups the launch is under five rounds of the
+        // chip's 768 slots and its last round counts: the search keeps at least eight rounds.
+        const double c0 = R3 >= 16 ? 3.8 : R3 >= 8 ? 2.8 : 2.0;
         const int lo = 24, hi = R3 >= 8 ? 80 : 40;
         double best = 0.0;
         for (int cand = lo; cand <= hi; ++cand) {
             const int64_t chunks = (n_seg + cand - 1) / cand;
             const int64_t wgs = (chunks + GPW - 1) / GPW;
-            if ((int64_t)n_streams * wgs < 2048) break;
+            if ((int64_t)n_streams * wgs < 8 * 768) break;  // (nothing qualifies: L stays 32)
             const double cost = (double)wgs * (cand + c0);
             if (best == 0.0 || cost < best * (1.0 - 1e-9)) {
                 best = cost;
@@ -260,7 +277,9 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.chunks = (n_seg + h->L - 1) / h->L;
     p.blocks_per_stream = (p.chunks + h->GPW - 1) / h->GPW;
     p.tail_cols = h->K;
+    p.work = h->d_work;
     p.window = h->d_window;
+    p.window_t = h->d_window_t;
     p.tw1 = h->d_tw1;
     p.tw2 = h->d_tw2;
     p.scale = h->cfg.scale;
@@ -391,7 +410,57 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
                            sp.item_chunks, sp.item_count, h->LG, sp.segs_per_chunk, c.n_seg, sp.chunks, sp.blocks_per_stream, h->GPW);
         launch_scan<5>(h, sp, blocks, c.u8);
     } else {
+#ifdef RT_STAMPS  // diagnostic build: per-stage cycle sums of every wave of the sparse scan, averaged and printed (stderr)
+        static uint32_t *d_dbg = nullptr;
+        static size_t dbg_words = 0;
+        const size_t words = (size_t)blocks * (scan_block(h->R3) / 64) * kStamps;
+        if (words > dbg_words) {
+            if (d_dbg) (void)hipFree(d_dbg);
+            RT_HIP(h, hipMalloc(&d_dbg, words * sizeof(uint32_t)));
+            dbg_words = words;
+        }
+        RT_HIP(h, hipMemsetAsync(d_dbg, 0, words * sizeof(uint32_t), h->s_scan));
+        sp.dbg = d_dbg;
+#endif
         launch_scan<0>(h, sp, blocks, c.u8);
+#ifdef RT_STAMPS
+        {
+            std::vector<uint32_t> hd(words);
+            RT_HIP(h, hipStreamSynchronize(h->s_scan));
+            RT_HIP(h, hipMemcpy(hd.data(), d_dbg, words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            double sum[kStamps] = {};
+            double waves = 0;
+            for (size_t w = 0; w < words / kStamps; ++w) {
+                if (hd[w * kStamps + 11] == 0) continue;
+                waves += 1;
+                for (int k = 0; k < kStamps; ++k) sum[k] += hd[w * kStamps + k];
+            }
+            if (const char *dump = std::getenv("RT_STAMPS_DUMP")) {  // raw per-wave words of the last launch, for timelines
+                if (FILE *f = std::fopen(dump, "wb")) {
+                    std::fwrite(hd.data(), sizeof(uint32_t), words, f);
+                    std::fclose(f);
+                }
+            }
+            uint32_t t_min = 0xFFFFFFFFu, t_max = 0;
+            double resident = 0;  // wave lifetimes, 100-MHz ticks
+            for (size_t w = 0; w < words / kStamps; ++w) {
+                if (hd[w * kStamps + 11] == 0) continue;
+                t_min = std::min(t_min, hd[w * kStamps + 14]);
+                t_max = std::max(t_max, hd[w * kStamps + 15]);
+                resident += (double)(hd[w * kStamps + 15] - hd[w * kStamps + 14]);
+            }
+            const double span = (double)(t_max - t_min);
+            std::fprintf(stderr, "RT_STAMPS launch span %.1f us, %.2f waves resident per SIMD on average, %.1f %% of a wave's life inside the step loop; ",
+                         span / 100.0, resident / span / 1024.0, 100.0 * sum[13] / resident);
+            const double steps = sum[11];
+            double tot = 0;
+            for (int k = 0; k <= 10; ++k) tot += sum[k];
+            std::fprintf(stderr, "RT_STAMPS nperseg %d: %.0f waves, %.1f steps per wave, %.0f cycles per step, in-kernel clock %.0f MHz:", h->N, waves,
+                         steps / waves, tot / steps, sum[13] > 0 ? sum[12] / sum[13] * 100.0 : 0.0);
+            for (int k = 0; k <= 10; ++k) std::fprintf(stderr, " [%d] %.0f", k, sum[k] / steps);
+            std::fprintf(stderr, "\n");
+        }
+#endif
     }
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
@@ -574,7 +643,9 @@ void rt_destroy(rt_handle *h) {
     }
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
+    (void)hipFree(h->d_work);
     (void)hipFree(h->d_window);
+    (void)hipFree(h->d_window_t);
     (void)hipFree(h->d_tw1);
     (void)hipFree(h->d_tw2);
     for (auto &t : h->d_tail) (void)hipFree(t);
@@ -664,7 +735,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->R3 = R3;
     h->N = cfg->nperseg;
     h->LG = 16 * R3;
-    h->GPW = kBlock / h->LG;
+    h->GPW = scan_block(R3) / h->LG;
     h->timing = (cfg->flags & RT_FLAG_TIMING) != 0;
     h->rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : 1024;
     h->stride = probe_stride(h->N, cfg->sample_rate, cfg->min_duration_s);
@@ -752,6 +823,13 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             const double ang = -two_pi * (double)e / (double)LG;
             tw2[(size_t)b * 16 + q1] = cf{(float)std::cos(ang), (float)std::sin(ang)};
         }
+    {
+        int cus = 0;
+        RT_CREATE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
+        if (cus > 0) h->n_cu = cus;
+    }
+    RT_CREATE_HIP(hipMalloc(&h->d_work, 2 * sizeof(uint32_t)));
+    RT_CREATE_HIP(hipMemset(h->d_work, 0, 2 * sizeof(uint32_t)));
     RT_CREATE_HIP(hipMalloc(&h->d_window, sizeof(float) * N));
     RT_CREATE_HIP(hipMalloc(&h->d_tw1, sizeof(cf) * tw1.size()));
     RT_CREATE_HIP(hipMalloc(&h->d_tw2, sizeof(cf) * tw2.size()));
@@ -762,6 +840,13 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         const double root = std::sqrt((double)cfg->scale);
         for (int i = 0; i < N; ++i) ws[(size_t)i] = (float)((double)cfg->window[i] * root);
         RT_CREATE_HIP(hipMemcpy(h->d_window, ws.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        if (R3 == 16) {
+            std::vector<float> wt((size_t)N);
+            for (int l = 0; l < LG; ++l)
+                for (int m = 0; m < 16; ++m) wt[(size_t)l * 16 + m] = ws[(size_t)l + (size_t)LG * m];
+            RT_CREATE_HIP(hipMalloc(&h->d_window_t, sizeof(float) * N));
+            RT_CREATE_HIP(hipMemcpy(h->d_window_t, wt.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        }
         // Transform of the coefficients as the kernel uses them.  If it is real and confined to bins 0 and +-1 (hamming,
         // hann, boxcar: every cosine-sum window of order <= 1 in get_window's periodic form) the constant detrend is
         // applied to the transform (LIN kernels); any other window keeps the subtract-first kernels.

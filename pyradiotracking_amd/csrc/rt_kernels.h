@@ -51,6 +51,7 @@ struct StftParams {
     int32_t blocks_per_stream;
     int32_t tail_cols;       // K
     const float *window;     // [N] window coefficients times sqrt(scale)
+    const float *window_t;   // nperseg 4096: the same in lane order, [LG][16]: element [lane][m] = window[lane + LG * m]
     const cf *tw1;           // [LG][16]   W_N^(a*k1)
     const cf *tw2;           // [R3][16]   W_LG^(b*q1)
     float scale;
@@ -74,6 +75,10 @@ struct StftParams {
     int32_t *item_chunks;    // [S][blocks_per_stream][lane groups per workgroup] MODE 5: the chunks a workgroup transforms (plan_pass_b;
                              // `chunks` = none), item_count[s] workgroups per stream
     int32_t *item_count;     // [S]
+    uint32_t *work;          // two words, zero between launches: tickets drawn for further items, workgroups that have left
+#ifdef RT_STAMPS
+    uint32_t *dbg;           // [workgroups][4 waves][kStamps] cycles per stage, [kStamps - 1] = steps taken
+#endif
 };
 
 // Run-length pre-filter (inputs whose noise crosses the absolute threshold, so that MODE 0 overflows its candidate
@@ -172,20 +177,50 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(moved);
 }
 
-// all-reduce (sum) over the LG lanes of a lane group.  Within a row of 16 lanes: quad
-// butterflies (quad_perm [1,0,3,2], [2,3,0,1]), then row_half_mirror and row_mirror fold the
-// other quad / other half in -- every lane ends with the same bits.
+// v + (lane 15 of the previous row | lane 31) for the rows in ROW_MASK (DPP row_bcast15 / row_bcast31), v elsewhere
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_rows(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+
+// Sum over the lanes of a lane group that sit in this wave, the same bits in every lane of the group (LG <= 64: the
+// group's sum; LG > 64: this wave's share of it).  Within a row of 16 lanes: quad butterflies (quad_perm [1,0,3,2],
+// [2,3,0,1]), then row_half_mirror and row_mirror fold the other quad / other half in.  Across rows: row_bcast15 adds
+// a row's sum into the next row, row_bcast31 the lower half's into the upper rows, and the row that ends up with the
+// total hands it out through a scalar register (v_readlane) -- no LDS round trip: the two dependent ds_bpermute steps
+// this replaces cost the wave ~250 cycles per step at nperseg 1024 and, with the workgroup exchange behind them,
+// ~1 000 at nperseg 4096 (profiles/r03_d_stage_stamps.txt, stage 3).
 template <int LG>
-__device__ __forceinline__ cf group_sum(cf v, cf *red /* [kBlock/64] LDS */) {
+__device__ __forceinline__ cf wave_sum(cf v) {
     v.x = dpp_add<0xB1>(v.x);   v.y = dpp_add<0xB1>(v.y);    // quad_perm [1,0,3,2]
     v.x = dpp_add<0x4E>(v.x);   v.y = dpp_add<0x4E>(v.y);    // quad_perm [2,3,0,1]
     v.x = dpp_add<0x141>(v.x);  v.y = dpp_add<0x141>(v.y);   // row_half_mirror
     v.x = dpp_add<0x140>(v.x);  v.y = dpp_add<0x140>(v.y);   // row_mirror
-#pragma unroll
-    for (int off = 16; off < (LG < 64 ? LG : 64); off <<= 1) {
-        v.x += __shfl_xor(v.x, off, 64);
-        v.y += __shfl_xor(v.y, off, 64);
+    if constexpr (LG >= 32) {
+        v.x = dpp_add_rows<0x142, 0xA>(v.x);  v.y = dpp_add_rows<0x142, 0xA>(v.y);  // rows 1, 3 += rows 0, 2
+        if constexpr (LG >= 64) {
+            v.x = dpp_add_rows<0x143, 0xC>(v.x);  v.y = dpp_add_rows<0x143, 0xC>(v.y);  // rows 2, 3 += (rows 0 + 1)
+            v.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), 63));
+            v.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), 63));
+        } else {
+            // two groups of 32 lanes: their sums sit in rows 1 and 3
+            const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), 31));
+            const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), 31));
+            const float bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), 63));
+            const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), 63));
+            const bool upper = (threadIdx.x & 32) != 0;
+            v.x = upper ? bx : ax;
+            v.y = upper ? by : ay;
+        }
     }
+    return v;
+}
+
+// all-reduce (sum) over the LG lanes of a lane group
+template <int LG>
+__device__ __forceinline__ cf group_sum(cf v, cf *red /* [kBlock/64] LDS */) {
+    v = wave_sum<LG>(v);
     if constexpr (LG > 64) {
         // One workgroup barrier.  `red` needs no barrier before the write: its readers of the previous step
         // all read it before they reached that step's exchange barrier, which this wave has passed since.
@@ -255,9 +290,35 @@ constexpr BinSlot slot_of_bin(int bin) {
 #endif
 
 
+// diagnostic builds only (-DRT_STAMPS, tools/r3/stamps.sh): s_memtime stamps between the stages of the scan step; every
+// wave adds up the cycles it spent in each stage (scalar registers) and leaves the sums in StftParams::dbg.  The
+// stamps pin the instruction order (sched_barrier) and wait for the wave's LDS operations: the stage sums show where
+// a wave's time goes, the kernel as a whole runs ~10 % slower than the product build.
+#ifdef RT_STAMPS
+#define RT_STAMP(k)                                                         \
+    do {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();       \
+        st_acc[k] += now_ - st_prev;                                        \
+        st_prev = now_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+constexpr int kStamps = 16;  // 0 .. 10 stage sums, 11 steps, 12 / 13 shader-clock and 100-MHz ticks over the step loop, 14 / 15 the 100-MHz clock at the wave's start and end
+#else
+#define RT_STAMP(k)
+#endif
+
+// end of a step: this wave is done with its group's exchange rows (stft_scan: rows_done)
+#define RT_ROWS_RELEASE()                        \
+    if constexpr (LIN && LG > 64) {              \
+        rows_arrive(rows_done + g);              \
+        ++steps_done;                            \
+    }
+
 #define RT_ABLATE_STOP(n)                                               \
     if constexpr (RT_ABLATE == (n)) {                                   \
         _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) acc[q_] += v[q_].x + v[q_].y; \
+        RT_ROWS_RELEASE();                                              \
         continue;                                                       \
     }
 
@@ -282,6 +343,8 @@ typedef int rsrc_t __attribute__((ext_vector_type(4)));
 typedef float buf_f2 __attribute__((ext_vector_type(2)));
 __device__ buf_f2 raw_buffer_load_f2(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ float raw_buffer_load_f1(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+typedef float buf_f4 __attribute__((ext_vector_type(4)));
+__device__ buf_f4 raw_buffer_load_f4(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ short raw_buffer_load_i16(rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i16");
 
 // `base` must be wave-uniform (the descriptor lives in SGPRs)
@@ -311,6 +374,36 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
     return cf{__builtin_fmaf((float)(x.iq & 0xFFu), c, -1.0f), __builtin_fmaf((float)(x.iq >> 8), c, -1.0f)};
 }
 
+// see stft_scan: rows_done
+__device__ __forceinline__ void rows_arrive(uint32_t *cnt) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (LDS operations of a wave execute in order: this is for the compiler)
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void rows_wait(uint32_t *cnt, uint32_t want) {
+    // every wave of the group arrives once per step whatever happens, and a wave waits only for steps it has
+    // finished itself: the loop ends
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Threads per workgroup of the scan: 256.  One wave per workgroup at nperseg 256 (its lane groups never meet a workgroup
+// barrier inside the step loop, and with four waves to a workgroup every wave waits at the end of an item for the slowest
+// of the four: 12.7 us of a 109-us item, profiles/r03_g_wave_skew.txt) was built and measured: the scan launch 4 - 8 %
+// shorter, but one partial row of sums per wave instead of per workgroup (63 per stream at config 2) makes every bucket
+// wave of the detection wait for four times the loads: config 2 two lanes 742 k -> 661 k MS/s, one lane +-0, config 4 -1.5 %
+// (profiles/r03_h_persistent_ab.txt).
+#ifndef RT_ONE_WAVE_MAX_R3  // measured and dropped, kept as a switch: -DRT_ONE_WAVE_MAX_R3=1 = one wave per workgroup at nperseg 256
+#define RT_ONE_WAVE_MAX_R3 0
+#endif
+// Which scans run their items on a chip-filling grid of persistent workgroups (stft_scan: "Work items"): nperseg >= 1024,
+// every mode but the selective pass.  -DRT_NO_PERSIST=1: none (diagnostic).
+#ifndef RT_NO_PERSIST
+#define RT_NO_PERSIST 0
+#endif
+__host__ __device__ constexpr bool scan_persistent(int R3, int mode) { return mode != 5 && !RT_NO_PERSIST && R3 >= 4; }
+__host__ __device__ constexpr int scan_block(int R3) { return R3 <= RT_ONE_WAVE_MAX_R3 ? 64 : kBlock; }
+
 // LIN: constant detrend by linearity.  FFT(w (x - m)) = FFT(w x) - m W with W = FFT(w); for a cosine-sum window of
 // order <= 1 (hamming, hann, boxcar -- anything get_window() makes of them) W is real and zero outside bins 0 and +-1,
 // so "subtract the mean from every sample" (32 subtractions per lane and step, and the transform waiting for the
@@ -323,12 +416,13 @@ template <int R3, int MODE, bool U8 = false, bool LIN = false>
 #ifndef RT_WG4_MAX_R3
 #define RT_WG4_MAX_R3 0
 #endif
-__global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
+__global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
     constexpr int LG = 16 * R3;
-    constexpr int GPW = kBlock / LG;  // lane groups per workgroup
+    constexpr int BLK = scan_block(R3);  // threads per workgroup
+    constexpr int GPW = BLK / LG;  // lane groups per workgroup
     constexpr int G = 16 / R3;
 
     // One LDS block carved by hand: at nperseg 256 the pieces add up to exactly 40 960 B, a quarter of a CU's LDS
@@ -337,37 +431,30 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     constexpr bool T1_IN_LDS = (R3 <= 4);
     constexpr bool T1_FACTORED = !T1_IN_LDS;
     // (uint8 input at nperseg 256 does run at four workgroups per CU: 106 VGPRs, +3 %)
-    constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 32 : kStageCap;  // candidate cells staged per wave before a flush
-    constexpr size_t kXchB = sizeof(cf) * kBlock * kRowF2;
-    constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (kBlock / 64) + 16 : 0;  // + the three tail_any words
+    // (nperseg 2048: 96 -- with 128 the block is 54 576 B, and LDS is handed out in 512-byte pieces: three workgroups
+    // would need 164 352 of the CU's 163 840 B, so the kernel ran at two; profiles/r03_d_stage_stamps.txt)
+    constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 32 : (R3 == 8) ? 96 : kStageCap;  // candidate cells staged per wave before a flush
+    constexpr size_t kXchB = sizeof(cf) * BLK * kRowF2;
+    constexpr size_t kRedB = (LG > 64) ? 2 * sizeof(cf) * (BLK / 64) + 16 + 16 : 0;  // two sets of wave sums + the three tail_any words + the rows_done counters
     constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
     constexpr size_t kT1fB = T1_FACTORED ? sizeof(float4) * 2 * LG : 0;
     constexpr size_t kT1B = T1_IN_LDS ? sizeof(float4) * 8 * LG : 0;
     constexpr size_t kT2B = (R3 > 1) ? sizeof(float4) * 8 * R3 : 0;
-    constexpr size_t kStageB = (MODE == 0 || MODE == 5) ? sizeof(uint2) * (kBlock / 64) * kStage : 0;
+    constexpr size_t kStageB = (MODE == 0 || MODE == 5) ? sizeof(uint2) * (BLK / 64) * kStage : 0;
     __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB];
     cf *const xch = reinterpret_cast<cf *>(lds_block);
     cf *const red = reinterpret_cast<cf *>(lds_block + kXchB);
-    uint32_t *const tail_any = reinterpret_cast<uint32_t *>(lds_block + kXchB + sizeof(cf) * (kBlock / 64));  // LG > 64, see the tail columns below
+    uint32_t *const tail_any = reinterpret_cast<uint32_t *>(lds_block + kXchB + 2 * sizeof(cf) * (BLK / 64));  // LG > 64, see the tail columns below
+    // LG > 64, LIN: per lane group, how many (wave, step) pairs of the current item are done with the group's exchange
+    // rows -- a wave adds one at the end of a step and, before it stores the next step's pass-1 results into the rows,
+    // waits until every wave of its group has finished the step before (rows_wait).  This replaces a workgroup barrier
+    // at the head of the step, where the waves arrived ~1 000 cycles apart (profiles/r03_d_stage_stamps.txt, stage 3):
+    // by the time a wave gets to its stores -- a third of a step later -- the others have long arrived.
+    uint32_t *const rows_done = tail_any + 4;
 
     const int tid = threadIdx.x;
     const int g = tid / LG;
     const int lt = tid % LG;
-    // Workgroups are dispatched in index order.  The ones holding a stream's last segments also write the
-    // look-back tail columns and run longer; they go first so that their extra time is hidden behind the
-    // rest of the launch instead of stretching its end.
-    const int s_pos = blockIdx.x % p.n_streams;
-    const int s = p.stream_list ? p.stream_list[s_pos] : s_pos;
-    const int cb = p.blocks_per_stream - 1 - blockIdx.x / p.n_streams;
-    int chunk = cb * GPW + g;
-    if constexpr (MODE == 5) {
-        // pass B of the run-length pre-filter: the stream's workgroups take the chunks plan_pass_b packed for them
-        const int item = blockIdx.x / p.n_streams;
-        if (item >= p.item_count[s]) return;
-        chunk = p.item_chunks[((int64_t)s * p.blocks_per_stream + item) * GPW + g];
-    }
-    const bool chunk_ok = chunk < p.chunks;
-    const int c0 = chunk * p.segs_per_chunk;
     const int T = p.n_seg;
     const int L = p.segs_per_chunk;
 
@@ -386,37 +473,78 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     float4 *const t1_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB + kT1fB);   // [k/2][lane]: (tw1[lane][2*(k/2)], tw1[lane][2*(k/2)+1])
     float4 *const t2_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B);  // [q/2][b]
     if constexpr (W_IN_LDS) {
-        for (int idx = tid; idx < 4 * LG; idx += kBlock) {
+        for (int idx = tid; idx < 4 * LG; idx += BLK) {
             const int mm = idx / LG, l = idx % LG;
             w_lds[idx] = make_float4(p.window[l + LG * (4 * mm)], p.window[l + LG * (4 * mm + 1)],
                                      p.window[l + LG * (4 * mm + 2)], p.window[l + LG * (4 * mm + 3)]);
         }
     }
     if constexpr (T1_IN_LDS) {
-        for (int idx = tid; idx < 8 * LG; idx += kBlock) {
+        for (int idx = tid; idx < 8 * LG; idx += BLK) {
             const int kk = idx / LG, l = idx % LG;
             const cf a = p.tw1[l * 16 + 2 * kk], b = p.tw1[l * 16 + 2 * kk + 1];
             t1_lds[idx] = make_float4(a.x, a.y, b.x, b.y);
         }
     }
     if constexpr (T1_FACTORED) {
-        for (int l = tid; l < LG; l += kBlock) {
+        for (int l = tid; l < LG; l += BLK) {
             const cf w1 = p.tw1[l * 16 + 1], w2 = p.tw1[l * 16 + 2], w4 = p.tw1[l * 16 + 4], w8 = p.tw1[l * 16 + 8];
             t1f_lds[l] = make_float4(w1.x, w1.y, w2.x, w2.y);
             t1f_lds[LG + l] = make_float4(w4.x, w4.y, w8.x, w8.y);
         }
     }
     if constexpr (R3 > 1) {
-        for (int idx = tid; idx < 8 * R3; idx += kBlock) {
+        for (int idx = tid; idx < 8 * R3; idx += BLK) {
             const int kk = idx / R3, b = idx % R3;
             const cf x = p.tw2[b * 16 + 2 * kk], y = p.tw2[b * 16 + 2 * kk + 1];
             t2_lds[idx] = make_float4(x.x, x.y, y.x, y.y);
         }
     }
+    // Work items.  An item is what a workgroup of the plain launch did: the chunks cb * GPW .. of one stream.  The
+    // launch has just enough workgroups to fill the chip (rt_analyze.hip: scan_grid) and every workgroup keeps taking
+    // items from a counter until none is left -- the tables above are staged once, and no slot waits for the
+    // dispatcher: with one workgroup per item the hardware queue kept 2.2 - 2.7 of the 3 wave slots per SIMD filled
+    // (it deals workgroups to the XCDs in strict rotation, so one full XCD holds back the others;
+    // profiles/r03_f_wave_residency_timeline_*), at nperseg 256 a quarter of the launch.  Items are numbered latest
+    // chunks first, across all streams: the ones that also write the look-back tail run longest and start first.
+    // The first item is the workgroup's index; the ticket for the next one is drawn at the start of an item, so
+    // its latency is covered.  MODE 5 keeps one workgroup per item (its items are listed per stream by plan_pass_b), and so
+    // do nperseg 256 / 512 (scan_persistent): their launches at config 2 are 2.7 rounds of items per lane, and with two
+    // lanes a chip-filling grid of long-lived workgroups shuts the other lane's kernels out until it ends (config 2, two
+    // lanes: 740 k -> 676 k MS/s, one lane unchanged; a run-time choice per launch cost the nperseg-256 loop 5 %).
+    constexpr bool PERSIST = scan_persistent(R3, MODE);
+    uint32_t *const item_word = reinterpret_cast<uint32_t *>(lds_block + sizeof(cf) * 16);  // (padding of exchange row 0: never exchanged)
+    const int n_items = p.n_streams * p.blocks_per_stream;
+    int item = blockIdx.x;
     if constexpr (LG > 64) {
-        if (tid < 3) tail_any[tid] = (tid == 1) ? 1u : 0u;  // the first step (i = 1) writes its whole column
+        if (tid < GPW) rows_done[tid] = 0u;
     }
     __syncthreads();
+  for (;;) {  // one item per round
+#ifdef RT_STAMPS
+    const uint32_t st_wave_start = (uint32_t)__builtin_amdgcn_s_memrealtime();  // (per item)
+#endif
+    uint32_t ticket = 0;
+    if constexpr (PERSIST) {
+        if (item >= n_items) break;  // (uniform: every thread of the workgroup holds the same item)
+        if (tid == 0) ticket = atomicAdd(p.work, 1u);
+    }
+    const int s_pos = item % p.n_streams;
+    const int s = p.stream_list ? p.stream_list[s_pos] : s_pos;
+    const int cb = p.blocks_per_stream - 1 - item / p.n_streams;
+    int chunk = cb * GPW + g;
+    if constexpr (MODE == 5) {
+        // pass B of the run-length pre-filter: the stream's workgroups take the chunks plan_pass_b packed for them
+        const int pb = item / p.n_streams;
+        if (pb >= p.item_count[s]) return;
+        chunk = p.item_chunks[((int64_t)s * p.blocks_per_stream + pb) * GPW + g];
+    }
+    const bool chunk_ok = chunk < p.chunks;
+    const int c0 = chunk * p.segs_per_chunk;
+    if constexpr (LG > 64) {
+        // (behind the barrier that ended the previous item, ahead of this item's first one: group_sum / the rows barrier)
+        if (tid < 3) tail_any[tid] = (tid == 1) ? 1u : 0u;  // the first step (i = 1) writes its whole column
+    }
 
     float acc[16];
 #pragma unroll
@@ -455,7 +583,10 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     // and transformed by every chunk cost 1/33 of all loads and arithmetic.
     // nperseg 4096 keeps that halo segment (BELOW = false: step 0 on segment c0 + L, whose only product is next_hot):
     // there the extra workgroup barrier and registers of the conditional step cost more than the halo (+2.5 %).
-    constexpr bool BELOW = (R3 < 16);
+#ifndef RT_BELOW_MAX_R3
+#define RT_BELOW_MAX_R3 8
+#endif
+    constexpr bool BELOW = (R3 <= RT_BELOW_MAX_R3);
     const int i_first = (!BELOW && EMIT) ? 0 : 1;
     int n_steps = L;
 
@@ -527,8 +658,15 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
         }
     };
     request_segment(c0 + L - i_first);
+#ifdef RT_STAMPS
+    uint32_t st_acc[kStamps] = {};
+    uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+    const uint32_t st_t0 = st_prev, st_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 
+    uint32_t steps_done = 0;  // LIN, LG > 64: steps of this item after which this wave has released the exchange rows
     for (int i = i_first; i <= n_steps; ++i) {
+        RT_STAMP(0);  // loop control, the previous step's candidate test
         const int seg = c0 + L - i;
         const bool halo = BELOW ? (i > L) : (i == 0);  // the step below (above) the chunk: no sums, tail, chunk bits
         const bool active = chunk_ok && seg < T && seg >= 0;
@@ -546,9 +684,15 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
 #pragma unroll
             for (int m = 0; m < 16; ++m) wreg[m] = 0.5f + 0.01f * m;
 #else
-            const rsrc_t rw = make_rsrc(p.window, (uint32_t)(N * sizeof(float)));
+            // (a lane's sixteen coefficients lie side by side in the transposed table: four 16-byte loads instead of
+            // sixteen dword loads -- a vector-memory instruction costs the issuing wave ~50 cycles behind the other
+            // waves' HBM requests, L2 hit or not: profiles/r03_d_stage_stamps.txt, stage 1)
+            const rsrc_t rw = make_rsrc(p.window_t, (uint32_t)(N * sizeof(float)));
 #pragma unroll
-            for (int m = 0; m < 16; ++m) wreg[m] = raw_buffer_load_f1(rw, lt * 4, LG * m * 4, 0);
+            for (int mm = 0; mm < 4; ++mm) {
+                const buf_f4 w4 = raw_buffer_load_f4(rw, lt * 64, mm * 16, 0);
+                wreg[4 * mm] = w4.x;  wreg[4 * mm + 1] = w4.y;  wreg[4 * mm + 2] = w4.z;  wreg[4 * mm + 3] = w4.w;
+            }
             __builtin_amdgcn_sched_barrier(0);  // keep the order of the two groups of loads
 #endif
         }
@@ -559,6 +703,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             request_segment((i < L) ? seg - 1 : seg);  // (the last step re-reads its own: harmless, keeps the loop uniform)
         }
 
+        RT_STAMP(1);  // issue of the window loads (nperseg 4096) and the next segment's loads
         if constexpr (MODE == 3) {
             // traffic calibration: the scan's exact load stream, nothing else
 #pragma unroll
@@ -576,7 +721,19 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             for (int m = 0; m < 4; ++m) s4[m] = cadd(s8[m], s8[m + 4]);
             sum = cadd(cadd(s4[0], s4[2]), cadd(s4[1], s4[3]));
         }
-        sum = group_sum<LG>(sum, red);  // LIN: only needed after pass 3 (for LG > 64 its barrier also frees the exchange rows)
+        RT_STAMP(2);  // wait for this segment's samples (requested a step ago) + the in-lane sums
+        if constexpr (LIN && LG > 64) {
+            // The sum is only needed after pass 3.  This wave's share goes to `red` and is read back behind this step's
+            // exchange barrier, where its latency hides under two passes -- instead of a write / barrier / read chain
+            // at the head of the step.  No barrier here: the exchange rows are guarded by rows_done.
+            // (two sets of shares, by the parity of the step: a set is rewritten two steps later, and between the two
+            // lies an exchange barrier that the readers of the old values pass only after they have read them)
+            sum = wave_sum<LG>(sum);
+            if ((threadIdx.x & 63) == 0) red[(i & 1) * (BLK / 64) + (threadIdx.x >> 6)] = sum;
+        } else {
+            sum = group_sum<LG>(sum, red);  // (for LG > 64 its barrier also frees the exchange rows)
+        }
+        RT_STAMP(3);  // group sum (lane shuffles, nperseg >= 2048: workgroup barrier)
         const cf mean = LIN ? cf{0.f, 0.f} : cscale(sum, 1.0f / (float)N);
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
@@ -599,6 +756,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             }
         }
 
+        RT_STAMP(4);  // window multiply (nperseg 4096: waits for the window loads)
         RT_ABLATE_STOP(1)  // loads + detrend + window
         // pass 1
         dft16(v);
@@ -630,14 +788,26 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             }
         }
 
+        RT_STAMP(5);  // pass 1 and its twiddles
         RT_ABLATE_STOP(2)  // + pass 1 and twiddles
         // exchange 1: element (a = lt, k1) -> row k1*R3 + b, column c
+        if constexpr (LIN && LG > 64) rows_wait(rows_done + g, (uint32_t)(LG / 64) * steps_done);
         {
             const int b = lt % R3, c = (lt / R3 + x1_rotation<R3>(lt % R3)) & 15;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) gx[(k1 * R3 + b) * kRowF2 + c] = v[k1];
         }
+        RT_STAMP(6);  // exchange 1: stores
         group_sync<LG>();
+        RT_STAMP(7);  // exchange 1: barrier (nperseg >= 2048)
+        if constexpr (LIN && LG > 64) {
+            constexpr int WPG = LG / 64;
+            const int w0 = ((threadIdx.x >> 6) / WPG) * WPG;
+            cf t{0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WPG; ++w) t = cadd(t, red[(i & 1) * (BLK / 64) + w0 + w]);
+            sum = t;  // (used after pass 3)
+        }
         {
             const float4 *row = reinterpret_cast<const float4 *>(gx + lt * kRowF2);
 #pragma unroll
@@ -651,6 +821,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
         RT_ABLATE_STOP(3)  // + LDS exchange
         // pass 2
         dft16(v);
+        RT_STAMP(8);  // exchange 1: loads, pass 2
         RT_ABLATE_STOP(4)  // + pass 2
 
         if constexpr (R3 > 1) {
@@ -686,6 +857,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
         // rows are free for the next segment: inside a wave by program order; across the waves of a larger
         // group the next step's mean reduction has the barrier (group_sum)
         wave_sync();
+        RT_STAMP(9);  // pass-2 twiddles, exchange 2, pass 3
         RT_ABLATE_STOP(6)  // + pass 3
 
         if constexpr (LIN) {
@@ -707,7 +879,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                 for (int r = 0; r < 16; ++r) acc[r] += P[r];
             }
         }
-        if constexpr (RT_ABLATE == 8) continue;  // + power and row sums only
+        if constexpr (RT_ABLATE == 8) { RT_ROWS_RELEASE(); continue; }  // + power and row sums only
         {
             // spectrogram row (dense modes) and look-back tail column (last K segments)
             const int col = seg - (T - p.tail_cols);
@@ -790,7 +962,8 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
             }
         }
 
-        if constexpr (RT_ABLATE == 7) continue;  // + power, row sums, tail columns (no candidate test)
+        RT_STAMP(10);  // detrend correction, power, row sums, tail columns
+        if constexpr (RT_ABLATE == 7) { RT_ROWS_RELEASE(); continue; }  // + power, row sums, tail columns (no candidate test)
         if constexpr (EMIT || FLAGS) {
             // candidates are rare: one max over the lane's 16 cells and a single compare in the
             // common path, the per-cell tests only where that fires.  (A NaN cell means the whole
@@ -890,8 +1063,21 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
                 }
             }
         }
+        RT_ROWS_RELEASE();
     }
 
+#ifdef RT_STAMPS
+    RT_STAMP(0);
+    st_acc[11] = (uint32_t)(n_steps - i_first + 1);
+    st_acc[12] = st_prev - st_t0;
+    st_acc[13] = (uint32_t)__builtin_amdgcn_s_memrealtime() - st_r0;
+    st_acc[14] = st_wave_start;
+    st_acc[15] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if (p.dbg && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < kStamps; ++k) p.dbg[((int64_t)item * (BLK / 64) + (threadIdx.x >> 6)) * kStamps + k] = st_acc[k];
+    }
+#endif
     if constexpr (EMIT) {
         if (stg_n) flush_stage(p, s, stg, stg_n);
     }
@@ -900,9 +1086,7 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
     }
     if constexpr (MODE == 3) {
         if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
-        return;
-    }
-    if constexpr (SUMS) {
+    } else if constexpr (SUMS) {
         // deterministic workgroup reduction of the lane groups' row sums: one
         // partial row per workgroup (fixed summation order, no float atomics)
         __syncthreads();
@@ -912,12 +1096,32 @@ __global__ __launch_bounds__(kBlock, (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 
         __syncthreads();
         float *dst = p.psum + ((int64_t)s * p.blocks_per_stream + cb) * N;
 #pragma unroll
-        for (int j = 0; j < R3; ++j) {
-            const int bin = tid + kBlock * j;
+        for (int j = 0; j < N / BLK; ++j) {
+            const int bin = tid + BLK * j;
             float sum = 0.f;
 #pragma unroll
             for (int gg = 0; gg < GPW; ++gg) sum += part[gg * N + bin];
             dst[bin] = sum;
+        }
+    }
+    if constexpr (!PERSIST) break;
+    // next item: the ticket drawn at the start of this one
+    __syncthreads();  // every wave is done with this item's LDS (exchange rows, row-sum scratch, item word)
+    if (tid == 0) *item_word = ticket;
+    if constexpr (LG > 64) {
+        if (tid < GPW) rows_done[tid] = 0u;
+    }
+    __syncthreads();
+    item = (int)gridDim.x + (int)*item_word;
+  }
+    if constexpr (PERSIST) {
+        // the workgroup that leaves last puts the counters back for the next launch on this stream
+        if (tid == 0) {
+            const uint32_t left = atomicAdd(p.work + 1, 1u);
+            if (left + 1u == gridDim.x) {
+                atomicExch(p.work, 0u);
+                atomicExch(p.work + 1, 0u);
+            }
         }
     }
 }

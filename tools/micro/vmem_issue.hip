@@ -1,0 +1,101 @@
+// Microbenchmark: a streaming read with arithmetic between the requests, in the shape of the scan step -- per wave
+// and step, request the NEXT 8 KiB (register double buffer), then V independent float32 FMAs on the CURRENT 8 KiB --
+// at 3 workgroups of 4 waves per CU (LDS-limited, like the scan kernels).  Question: with the same bytes per step,
+// does the width of the load instruction matter (16 x dwordx2 per lane, the scan's shape, against 8 x dwordx4), and
+// how does the achieved HBM rate fall as V grows?  (tools only; not part of the product)
+// Build and run on the GPU box:  hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -o /tmp/vmem_issue tools/micro/vmem_issue.hip && /tmp/vmem_issue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// one wave reads `steps` consecutive 8 KiB pieces of its own contiguous region
+template <int WIDTH /* bytes per lane and load: 8 or 16 */, int V /* FMAs per step and lane */, int SPLIT /* request in SPLIT parts spread over the step */>
+__global__ __launch_bounds__(256, 3) void k(const float *src, float *out, int steps) {
+    extern __shared__ float pad[];  // 48 KiB: three workgroups per CU
+    constexpr int NLOAD = 8192 / 64 / WIDTH;  // loads per lane and step: 16 or 8
+    constexpr int NF = 32;                    // floats per lane and step
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const char *base = reinterpret_cast<const char *>(src) + (size_t)wave * steps * 8192;
+    float cur[NF], nxt[NF];
+    auto request = [&](int step, int part) {
+        const char *p = base + (size_t)step * 8192 + lane * WIDTH;
+#pragma unroll
+        for (int m = part * (NLOAD / SPLIT); m < (part + 1) * (NLOAD / SPLIT); ++m) {
+            if constexpr (WIDTH == 8) {
+                const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p + m * 64 * WIDTH));
+                nxt[2 * m] = v.x; nxt[2 * m + 1] = v.y;
+            } else {
+                const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p + m * 64 * WIDTH));
+                nxt[4 * m] = v.x; nxt[4 * m + 1] = v.y; nxt[4 * m + 2] = v.z; nxt[4 * m + 3] = v.w;
+            }
+        }
+    };
+#pragma unroll
+    for (int part = 0; part < SPLIT; ++part) request(0, part);
+    float acc[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[i] = 0.f;
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) cur[i] = nxt[i];
+        const int sn = (s + 1 < steps) ? s + 1 : s;
+        constexpr int ROUNDS = V / NF;
+#pragma unroll
+        for (int part = 0; part < SPLIT; ++part) {
+            request(sn, part);
+#pragma unroll
+            for (int r = part * (ROUNDS / SPLIT); r < (part + 1) * (ROUNDS / SPLIT); ++r) {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) acc[i] = __builtin_fmaf(acc[i], 0.999f, cur[i]);
+            }
+            if constexpr (SPLIT > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (ROUNDS == 0) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) acc[i] += cur[i];
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) t += acc[i];
+    if (t == 123.456f) out[wave * 64 + lane] = t + pad[lane];
+}
+
+template <int WIDTH, int V, int SPLIT>
+void run(const float *src, float *out, size_t bytes) {
+    const int steps = 64;
+    const int waves = (int)(bytes / ((size_t)steps * 8192));
+    const int blocks = waves / 4;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k<WIDTH, V, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) k<WIDTH, V, SPLIT><<<blocks, 256, 48 * 1024>>>(src, out, steps);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) k<WIDTH, V, SPLIT><<<blocks, 256, 48 * 1024>>>(src, out, steps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const double moved = (double)blocks * 4 * steps * 8192;
+    printf("load width %2d B x %2d per step, %3d FMAs per step%s: %.3f ms  %.2f TB/s\n", WIDTH, 8192 / 64 / WIDTH, V,
+           SPLIT > 1 ? ", requests spread over the step in 4 parts" : "", ms, moved / (ms * 1e-3) * 1e-12);
+}
+
+int main() {
+    const size_t bytes = (size_t)8 << 30;  // 8 GiB: far beyond the Infinity Cache
+    float *src, *out;
+    if (hipMalloc(&src, bytes) != hipSuccess) return 1;
+    hipMalloc(&out, 64 << 20);
+    hipMemset(src, 0x3c, bytes);
+    run<8, 0, 1>(src, out, bytes);    run<16, 0, 1>(src, out, bytes);
+    run<8, 256, 1>(src, out, bytes);  run<16, 256, 1>(src, out, bytes);
+    run<8, 512, 1>(src, out, bytes);  run<16, 512, 1>(src, out, bytes);
+    run<8, 768, 1>(src, out, bytes);  run<16, 768, 1>(src, out, bytes);
+    run<8, 1024, 1>(src, out, bytes); run<16, 1024, 1>(src, out, bytes);
+    run<8, 768, 4>(src, out, bytes);  run<16, 768, 4>(src, out, bytes);
+    run<8, 1024, 4>(src, out, bytes); run<16, 1024, 4>(src, out, bytes);
+    hipFree(src); hipFree(out);
+    return 0;
+}
