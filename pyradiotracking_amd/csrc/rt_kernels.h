@@ -308,17 +308,9 @@ constexpr int kStamps = 16;  // 0 .. 10 stage sums, 11 steps, 12 / 13 shader-clo
 #define RT_STAMP(k)
 #endif
 
-// end of a step: this wave is done with its group's exchange rows (stft_scan: rows_done)
-#define RT_ROWS_RELEASE()                        \
-    if constexpr (LIN && LG > 64) {              \
-        rows_arrive(rows_done + g);              \
-        ++steps_done;                            \
-    }
-
 #define RT_ABLATE_STOP(n)                                               \
     if constexpr (RT_ABLATE == (n)) {                                   \
         _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) acc[q_] += v[q_].x + v[q_].y; \
-        RT_ROWS_RELEASE();                                              \
         continue;                                                       \
     }
 
@@ -374,19 +366,6 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
     return cf{__builtin_fmaf((float)(x.iq & 0xFFu), c, -1.0f), __builtin_fmaf((float)(x.iq >> 8), c, -1.0f)};
 }
 
-// see stft_scan: rows_done
-__device__ __forceinline__ void rows_arrive(uint32_t *cnt) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (LDS operations of a wave execute in order: this is for the compiler)
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void rows_wait(uint32_t *cnt, uint32_t want) {
-    // every wave of the group arrives once per step whatever happens, and a wave waits only for steps it has
-    // finished itself: the loop ends
-    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want)
-        __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 // Threads per workgroup of the scan: 256.  One wave per workgroup at nperseg 256 (its lane groups never meet a workgroup
 // barrier inside the step loop, and with four waves to a workgroup every wave waits at the end of an item for the slowest
 // of the four: 12.7 us of a 109-us item, profiles/r03_g_wave_skew.txt) was built and measured: the scan launch 4 - 8 %
@@ -435,7 +414,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // would need 164 352 of the CU's 163 840 B, so the kernel ran at two; profiles/r03_d_stage_stamps.txt)
     constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 32 : (R3 == 8) ? 96 : kStageCap;  // candidate cells staged per wave before a flush
     constexpr size_t kXchB = sizeof(cf) * BLK * kRowF2;
-    constexpr size_t kRedB = (LG > 64) ? 2 * sizeof(cf) * (BLK / 64) + 16 + 16 : 0;  // two sets of wave sums + the three tail_any words + the rows_done counters
+    constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (BLK / 64) + 16 : 0;  // + the three tail_any words
     constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
     constexpr size_t kT1fB = T1_FACTORED ? sizeof(float4) * 2 * LG : 0;
     constexpr size_t kT1B = T1_IN_LDS ? sizeof(float4) * 8 * LG : 0;
@@ -444,13 +423,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB];
     cf *const xch = reinterpret_cast<cf *>(lds_block);
     cf *const red = reinterpret_cast<cf *>(lds_block + kXchB);
-    uint32_t *const tail_any = reinterpret_cast<uint32_t *>(lds_block + kXchB + 2 * sizeof(cf) * (BLK / 64));  // LG > 64, see the tail columns below
-    // LG > 64, LIN: per lane group, how many (wave, step) pairs of the current item are done with the group's exchange
-    // rows -- a wave adds one at the end of a step and, before it stores the next step's pass-1 results into the rows,
-    // waits until every wave of its group has finished the step before (rows_wait).  This replaces a workgroup barrier
-    // at the head of the step, where the waves arrived ~1 000 cycles apart (profiles/r03_d_stage_stamps.txt, stage 3):
-    // by the time a wave gets to its stores -- a third of a step later -- the others have long arrived.
-    uint32_t *const rows_done = tail_any + 4;
+    uint32_t *const tail_any = reinterpret_cast<uint32_t *>(lds_block + kXchB + sizeof(cf) * (BLK / 64));  // LG > 64, see the tail columns below
 
     const int tid = threadIdx.x;
     const int g = tid / LG;
@@ -516,9 +489,6 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     uint32_t *const item_word = reinterpret_cast<uint32_t *>(lds_block + sizeof(cf) * 16);  // (padding of exchange row 0: never exchanged)
     const int n_items = p.n_streams * p.blocks_per_stream;
     int item = blockIdx.x;
-    if constexpr (LG > 64) {
-        if (tid < GPW) rows_done[tid] = 0u;
-    }
     __syncthreads();
   for (;;) {  // one item per round
 #ifdef RT_STAMPS
@@ -664,7 +634,6 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     const uint32_t st_t0 = st_prev, st_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
 
-    uint32_t steps_done = 0;  // LIN, LG > 64: steps of this item after which this wave has released the exchange rows
     for (int i = i_first; i <= n_steps; ++i) {
         RT_STAMP(0);  // loop control, the previous step's candidate test
         const int seg = c0 + L - i;
@@ -723,13 +692,17 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         }
         RT_STAMP(2);  // wait for this segment's samples (requested a step ago) + the in-lane sums
         if constexpr (LIN && LG > 64) {
-            // The sum is only needed after pass 3.  This wave's share goes to `red` and is read back behind this step's
-            // exchange barrier, where its latency hides under two passes -- instead of a write / barrier / read chain
-            // at the head of the step.  No barrier here: the exchange rows are guarded by rows_done.
-            // (two sets of shares, by the parity of the step: a set is rewritten two steps later, and between the two
-            // lies an exchange barrier that the readers of the old values pass only after they have read them)
+            // The sum is only needed after pass 3.  This wave's share goes to `red` behind the barrier that frees the
+            // exchange rows (every wave has read the previous step's shares by then: it read them right behind that
+            // step's exchange barrier) and is read back behind this step's exchange barrier, where its latency hides
+            // under two passes -- instead of a write / barrier / read chain at the head of the step.
+            // (Measured and dropped: counters in LDS instead of this barrier -- a wave adds one when it is done with the
+            // rows and waits only before its next stores into them.  The waves of a group reach the first barrier of a
+            // step ~1 000 cycles apart; without this one they wait as long at the exchange barrier instead:
+            // profiles/r03_d_stage_stamps.txt, profiles/r03_g_wave_skew.txt.)
             sum = wave_sum<LG>(sum);
-            if ((threadIdx.x & 63) == 0) red[(i & 1) * (BLK / 64) + (threadIdx.x >> 6)] = sum;
+            __syncthreads();  // the previous step's last use of the exchange rows is over in every wave
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
         } else {
             sum = group_sum<LG>(sum, red);  // (for LG > 64 its barrier also frees the exchange rows)
         }
@@ -791,7 +764,6 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         RT_STAMP(5);  // pass 1 and its twiddles
         RT_ABLATE_STOP(2)  // + pass 1 and twiddles
         // exchange 1: element (a = lt, k1) -> row k1*R3 + b, column c
-        if constexpr (LIN && LG > 64) rows_wait(rows_done + g, (uint32_t)(LG / 64) * steps_done);
         {
             const int b = lt % R3, c = (lt / R3 + x1_rotation<R3>(lt % R3)) & 15;
 #pragma unroll
@@ -805,7 +777,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             const int w0 = ((threadIdx.x >> 6) / WPG) * WPG;
             cf t{0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < WPG; ++w) t = cadd(t, red[(i & 1) * (BLK / 64) + w0 + w]);
+            for (int w = 0; w < WPG; ++w) t = cadd(t, red[w0 + w]);
             sum = t;  // (used after pass 3)
         }
         {
@@ -879,7 +851,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 for (int r = 0; r < 16; ++r) acc[r] += P[r];
             }
         }
-        if constexpr (RT_ABLATE == 8) { RT_ROWS_RELEASE(); continue; }  // + power and row sums only
+        if constexpr (RT_ABLATE == 8) continue;  // + power and row sums only
         {
             // spectrogram row (dense modes) and look-back tail column (last K segments)
             const int col = seg - (T - p.tail_cols);
@@ -963,7 +935,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         }
 
         RT_STAMP(10);  // detrend correction, power, row sums, tail columns
-        if constexpr (RT_ABLATE == 7) { RT_ROWS_RELEASE(); continue; }  // + power, row sums, tail columns (no candidate test)
+        if constexpr (RT_ABLATE == 7) continue;  // + power, row sums, tail columns (no candidate test)
         if constexpr (EMIT || FLAGS) {
             // candidates are rare: one max over the lane's 16 cells and a single compare in the
             // common path, the per-cell tests only where that fires.  (A NaN cell means the whole
@@ -1063,7 +1035,6 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 }
             }
         }
-        RT_ROWS_RELEASE();
     }
 
 #ifdef RT_STAMPS
@@ -1108,9 +1079,6 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // next item: the ticket drawn at the start of this one
     __syncthreads();  // every wave is done with this item's LDS (exchange rows, row-sum scratch, item word)
     if (tid == 0) *item_word = ticket;
-    if constexpr (LG > 64) {
-        if (tid < GPW) rows_done[tid] = 0u;
-    }
     __syncthreads();
     item = (int)gridDim.x + (int)*item_word;
   }
