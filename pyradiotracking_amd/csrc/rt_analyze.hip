@@ -133,6 +133,7 @@ struct rt_handle {
     int dense_sticky = 0;  // calls left on auto_level before the next probe
     int sticky_len = 16;
     uint64_t n_calls = 0;  // calls enqueued so far
+    uint64_t test_enqueues = 0;  // laned handle: rt_process calls seen (RT_TEST_FAIL_LANE)
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
     std::vector<uint8_t> reset_pending;  // [S] streams whose look-back is dropped at the next rt_process
@@ -601,8 +602,37 @@ Slot *oldest_pending(rt_handle *h) {
 // are rolled back, so that no lane holds a pending call the others lack (FIFO fetches pair calls by position).
 template <class F>
 int for_each_lane(rt_handle *h, F call, bool enqueues = false) {
+    if (enqueues) {
+        // The slot every lane is about to claim may still hold a call that was never fetched (a third rt_process without
+        // an rt_fetch): it is dropped HERE, in all lanes, before any of them starts -- if a later lane then fails, the
+        // lanes before it roll their new call back and all of them are left with the same pending calls (a lane that
+        // failed before its first launch used to put the old call back while the others had lost it).
+        for (rt_handle *k : h->kids) {
+            Slot &sl = k->slot[k->n_calls % kSlots];
+            if (sl.call.pending) {
+                (void)hipSetDevice(k->cfg.device);
+                (void)hipEventSynchronize(sl.ev_done);
+                sl.call.pending = false;
+            }
+        }
+    }
+    // test hook (tests/test_gpu_parity.py, fault injection): RT_TEST_FAIL_LANE=<k>:<n> makes lane k refuse the n-th
+    // enqueue seen while the variable is set, as a device allocation failure inside that lane would
+    int fail_lane = -1;
+    if (enqueues) {
+        if (const char *spec = std::getenv("RT_TEST_FAIL_LANE")) {
+            int lane = -1, nth = 0;
+            if (std::sscanf(spec, "%d:%d", &lane, &nth) == 2 && ++h->test_enqueues == (uint64_t)nth) fail_lane = lane;
+        }
+    }
     for (size_t k = 0; k < h->kids.size(); ++k) {
-        const int rc = call(h->kids[k], (int64_t)h->kid_base[k]);
+        int rc;
+        if ((int)k == fail_lane) {
+            h->kids[k]->err = "injected failure (RT_TEST_FAIL_LANE)";
+            rc = RT_E_NOMEM;
+        } else {
+            rc = call(h->kids[k], (int64_t)h->kid_base[k]);
+        }
         if (rc != RT_OK) {
             h->err = h->kids[k]->err;
             if (enqueues)
@@ -1054,55 +1084,60 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
     c.tail_read = h->tail_cur;
     c.tail_write = (h->tail_cur + 1) % kTails;
     c.n_seg_last = h->n_seg_last;
-    if (h->any_reset_pending) {
-        // the slot's previous call (two calls back) may still be reading its flags if it was never fetched
-        if (sl.ev_done && h->n_calls >= (uint64_t)kSlots) RT_HIP(h, hipEventSynchronize(sl.ev_done));
-        for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_no_last[s] = h->reset_pending[(size_t)s];
-        std::fill(h->reset_pending.begin(), h->reset_pending.end(), (uint8_t)0);
-        h->any_reset_pending = false;
-        c.no_last = true;
-    }
-    c.mode_used = h->cfg.mode;
-    if (h->cfg.mode == RT_MODE_AUTO) {
-        // the level the input last needed, for `dense_sticky` more calls; then a probe of the level below
-        if (h->dense_sticky > 0) {
-            c.mode_used = h->auto_level;
-            --h->dense_sticky;
-        } else {
-            c.mode_used = level_down(h, h->auto_level);
+    // Everything that can fail from here on runs inside `enqueue`; one block below undoes a failed call: nothing stays
+    // enqueued, the look-back state and the pending stream resets are the ones before the call, and the call the slot
+    // held (possibly still unfetched) is put back unless a launch has already rewritten its scratch (include/rt_analyze.h).
+    bool launched = false;
+    auto enqueue = [&]() -> int {
+        if (h->any_reset_pending) {
+            // the slot's previous call (two calls back) may still be reading its flags if it was never fetched
+            if (sl.ev_done && h->n_calls >= (uint64_t)kSlots) RT_HIP(h, hipEventSynchronize(sl.ev_done));
+            for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_no_last[s] = h->reset_pending[(size_t)s];
+            std::fill(h->reset_pending.begin(), h->reset_pending.end(), (uint8_t)0);
+            h->any_reset_pending = false;
+            c.no_last = true;
         }
-    }
-    if (T == 0) {
-        // empty spectrogram: no signals; `_spectrogram_last` becomes an empty map
-        const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
-        RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
-        RT_HIP(h, hipMemsetAsync(sl.h_rec_count, 0, sb, h->s_scan));
-        RT_HIP(h, hipMemsetAsync(sl.h_rec_offset, 0, sb, h->s_scan));
-        RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
-        RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
-        rc = enqueue_readback(h, sl, h->s_scan);
-        if (rc != RT_OK) return rc;
-        RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
-    } else {
-        bool launched = false;
-        rc = enqueue_analysis(h, sl, c.mode_used, &launched);
-        if (rc != RT_OK) {
-            // nothing stays enqueued for a failed call.  Before the first launch the slot's scratch is untouched:
-            // the call it held (possibly still unfetched) is put back; afterwards its results are gone with it.
-            h->dense_sticky = c.prev_dense_sticky;
-            if (c.no_last) {
-                for (int s = 0; s < h->cfg.n_streams; ++s)
-                    if (sl.h_no_last[s]) h->reset_pending[(size_t)s] = 1;
-                h->any_reset_pending = true;
-            }
-            if (launched) {
-                (void)hipStreamSynchronize(h->s_scan);
-                sl.call = CallCtx{};
+        c.mode_used = h->cfg.mode;
+        if (h->cfg.mode == RT_MODE_AUTO) {
+            // the level the input last needed, for `dense_sticky` more calls; then a probe of the level below
+            if (h->dense_sticky > 0) {
+                c.mode_used = h->auto_level;
+                --h->dense_sticky;
             } else {
-                sl.call = saved;
+                c.mode_used = level_down(h, h->auto_level);
             }
-            return rc;
         }
+        if (T == 0) {
+            // empty spectrogram: no signals; `_spectrogram_last` becomes an empty map
+            const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
+            launched = true;  // (the slot's result arrays are rewritten from here on)
+            RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
+            RT_HIP(h, hipMemsetAsync(sl.h_rec_count, 0, sb, h->s_scan));
+            RT_HIP(h, hipMemsetAsync(sl.h_rec_offset, 0, sb, h->s_scan));
+            RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
+            RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
+            const int rc2 = enqueue_readback(h, sl, h->s_scan);
+            if (rc2 != RT_OK) return rc2;
+            RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
+            return RT_OK;
+        }
+        return enqueue_analysis(h, sl, c.mode_used, &launched);
+    };
+    rc = enqueue();
+    if (rc != RT_OK) {
+        h->dense_sticky = c.prev_dense_sticky;
+        if (c.no_last) {
+            for (int s = 0; s < h->cfg.n_streams; ++s)
+                if (sl.h_no_last[s]) h->reset_pending[(size_t)s] = 1;
+            h->any_reset_pending = true;
+        }
+        if (launched) {
+            (void)hipStreamSynchronize(h->s_scan);
+            sl.call = CallCtx{};
+        } else {
+            sl.call = saved;
+        }
+        return rc;
     }
     c.pending = true;
     h->n_calls++;

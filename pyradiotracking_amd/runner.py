@@ -254,8 +254,11 @@ class BatchRunner:
                     self.analyzers[gpu].fetch_records(allow_truncated=True)
                 except Exception as e:  # the step is lost anyway; keep draining the other GPUs
                     logger.error(f"GPU {gpu}: dropping the enqueued step failed: {e}")
-            for i in resets:
-                self.streams[i].stale = True  # the look-back reset is repeated with the stream's next buffer
+            # The step is lost on every GPU.  On the ones that accepted it the handles now hold the dropped buffer as
+            # "previous buffer" (a retry of the same buffer would look back into itself), on the refusing one the buffer
+            # before it (a gap): no stream may look back from its next buffer -- each starts it with reset_stream.
+            for st in self.streams:
+                st.stale = True
             raise
 
         ts_starts: List[Optional[datetime.datetime]] = [None] * n

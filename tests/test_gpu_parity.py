@@ -595,6 +595,229 @@ def test_detrend_by_linearity_equals_subtract_first(nperseg, window):
     assert len(recs[0]) > 0
 
 
+@pytest.mark.parametrize("nperseg", [256, 1024, 4096])
+@pytest.mark.parametrize("noise_sigma", [1e-4, 1e-5])
+def test_detrend_by_linearity_under_a_large_dc_offset(nperseg, noise_sigma):
+    """An RTL-SDR's DC spike is 0.05 .. 0.1 of full scale.  The linearity form carries the whole offset through the
+    window multiply and every butterfly (the subtract-first form removes it first): float32 round-off of the offset,
+    ~eps * |DC| * (butterfly growth), lands in every bin.  Pinned here, offset 0.1 - 0.07j, every bin but 0 and +-1, cells at
+    the noise level or above, against the oracle:
+      * offset 60 dB over the noise (sigma 1e-4; a 16-bit front end cannot show more): both forms within 0.03 dB
+        (measured 0.011 .. 0.019 for the linearity form, 0.005 .. 0.02 for subtract-first);
+      * offset 80 dB over the noise (sigma 1e-5): subtract-first within 0.05 dB; the linearity form 0.06 dB at
+        nperseg 256, 0.11 dB at 1024 and 0.17 dB at nperseg 4096 -- beyond the +-0.1 dB bar there, which is why such input wants
+        `subtract_first=True`; asserted: < 0.25 dB, and the records still the oracle's."""
+    _need_gpu()
+    fs, n = 2048000, 48 * 4096
+    n_seg = n // nperseg
+    window = "hamming"
+    dc = complex(0.1, -0.07)
+    w = oracle.window_coefficients(window, nperseg)
+    rng = np.random.default_rng(nperseg + 7)
+    peak = (-60.0, -45.0) if noise_sigma > 5e-5 else (-80.0, -60.0)
+    iq = np.stack([synth.make_stream(synth.StreamSpec(n, fs, synth.random_pulses(rng, n, fs, w, 3, dur_ms=(3, 9), peak_dbw=peak), noise_sigma=noise_sigma, dc=dc), 300 + s)
+                   for s in range(2)])
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_min_duration_ms=2, signal_threshold_dbw=-90.0 if noise_sigma < 5e-5 else -75.0)
+    others = np.ones(nperseg, bool)
+    others[[0, 1, nperseg - 1]] = False
+    worst = {}
+    for first in (False, True):
+        b = _batch_for(kw, 2, n, "sparse", subtract_first=first)
+        d_iq = _native.DeviceBuffer(0, iq.nbytes)
+        d_iq.upload(iq)
+        d_out = _native.DeviceBuffer(0, 2 * n_seg * nperseg * 4)
+        b.native.spectrogram_device(d_iq.ptr, n, n, d_out.ptr)
+        spec = d_out.download(np.float32, 2 * n_seg * nperseg).reshape(2, n_seg, nperseg)
+        b.enqueue(iq)
+        rec = b.fetch_records()
+        bound = 0.03 if noise_sigma > 5e-5 else (0.05 if first else 0.25)
+        for s in range(2):
+            _, _, want = oracle.stft_power(iq[s], fs, window, nperseg)
+            o = want.T[:, others].astype(np.float64)  # [T, bins]
+            g = spec[s][:, others].astype(np.float64)
+            sel = o > 0.5 * np.median(o)
+            dev = np.abs(10 * np.log10(g[sel] / o[sel]))
+            worst[("subtract-first" if first else "linearity", s)] = round(float(dev.max()), 5)
+            assert dev.max() < bound, (nperseg, noise_sigma, "subtract-first" if first else "linearity", s, float(dev.max()))
+            sigs, kept = oracle.OracleAnalyzer(device=str(s), **kw).process(iq[s], gu.TS0)
+            mine = rec[rec["stream"] == s]
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(v.fi, v.start, v.end) for v in sigs], (nperseg, first, s)
+            assert len(sigs) > 0
+        b.close()
+    print(f"nperseg {nperseg} sigma {noise_sigma}: worst dB deviation {worst}")
+
+
+# ---------------------------------------------------------------------------
+# the three kinds of difference the randomised soaks keep finding (DESIGN section 2), pinned: what may differ, and
+# what is guaranteed around it
+# ---------------------------------------------------------------------------
+def _oracle_records(x, fs, nperseg, window, params, spec=None):
+    freqs, times, sp = oracle.stft_power(x, fs, window, nperseg)
+    if spec is not None:
+        sp = spec
+    recs = oracle.extract_records(times, sp, None, params)
+    sigs = oracle.records_to_signals(recs, freqs, gu.TS0, "0", 150150000)
+    kept = {id(v) for v in oracle.filter_shadows(sigs)}
+    return sp, sigs, [id(v) in kept for v in sigs]
+
+
+def _db_for_float32(value32: np.float32) -> float:
+    """a dB figure x with float32(10 ** (x / 10)) == value32 (the analyzers compare float32 data with the float32 threshold)"""
+    x = 10.0 * np.log10(np.float64(value32))
+    for _ in range(200):
+        got = np.float32(10.0 ** (x / 10.0))
+        if got == value32:
+            return float(x)
+        x += (np.float64(value32) - np.float64(got)) / np.float64(value32) * 4.0
+    raise AssertionError("no dB figure maps onto that float32")
+
+
+@pytest.mark.parametrize("kind", ["threshold", "snr"])
+def test_pinned_deviation_a_decision_within_one_ulp_of_a_threshold(kind):
+    """reference analyze.py:370 / :378.  The threshold is put EXACTLY on the weakest interior cell of a plateau (as the
+    oracle's float32 FFT computes it): in the reference that cell passes (`not (P < thr)`), on the GPU it may come out
+    one ulp lower and split the plateau in two.  Guaranteed: every other bin is untouched, and the bin of the named
+    cell holds either the oracle's records or the oracle's records for that one cell failing -- nothing else."""
+    _need_gpu()
+    fs, nperseg, window = 2048000, 256, "hamming"
+    blen = nperseg * 1200
+    w = oracle.window_coefficients(window, nperseg)
+    kb = 57
+    x = synth.make_stream(synth.StreamSpec(blen, fs, [synth.Pulse(300 * nperseg + 40, 240 * nperseg, kb * fs / nperseg, synth.amp_for_peak_dbw(-70.0, w, fs), 0.1)]), seed=77)
+    base = oracle.ExtractParams(-90.0, 5.0, 8, 40, 0.0)
+    sp, sigs0, _ = _oracle_records(x, fs, nperseg, window, base)
+    run = [v for v in sigs0 if v.fi == kb]
+    assert len(run) == 1 and run[0].end - run[0].start > 200
+    t_lo, t_hi = run[0].start + 60, run[0].end - 60  # both halves of a split plateau still pass the duration gate
+    tc = t_lo + int(np.argmin(sp[kb, t_lo:t_hi]))
+    row_mean = np.mean(sp[kb])
+    if kind == "threshold":
+        thr_db, snr_db = _db_for_float32(sp[kb, tc]), 5.0
+    else:
+        thr_db, snr_db = -90.0, _db_for_float32(np.float32(sp[kb, tc] / row_mean))
+    params = oracle.ExtractParams(thr_db, snr_db, 8, 40, 0.0)
+    thr32, snr32 = np.float32(params.signal_threshold), np.float32(params.snr_threshold)
+    assert (sp[kb, tc] == thr32) if kind == "threshold" else (np.float32(sp[kb, tc] / row_mean) == snr32)
+    # the construction: no other cell of the whole map sits that close to its decision
+    with np.errstate(divide="ignore", invalid="ignore"):
+        margin = np.minimum(np.abs(sp / thr32 - 1.0), np.abs(sp / np.mean(sp, axis=1, keepdims=True) / snr32 - 1.0))
+    margin[kb, tc] = 1.0
+    assert margin.min() > 1e-5, np.unravel_index(np.argmin(margin), margin.shape)
+    _, want, want_kept = _oracle_records(x, fs, nperseg, window, params)
+    nudged = sp.copy()
+    nudged[kb, tc] = np.nextafter(np.nextafter(np.nextafter(sp[kb, tc], np.float32(0)), np.float32(0)), np.float32(0))
+    _, alt, alt_kept = _oracle_records(x, fs, nperseg, window, params, spec=nudged)
+    key = lambda v: (v.fi, v.start, v.end)
+    assert [key(v) for v in want] != [key(v) for v in alt], "the named cell decides nothing"
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_threshold_dbw=thr_db, snr_threshold_db=snr_db)
+    for mode in ("sparse", "dense"):
+        b = _batch_for(kw, 1, blen, mode)
+        b.enqueue(x[None, :])
+        rec = b.fetch_records()
+        got = [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in rec]
+        assert got in ([key(v) for v in want], [key(v) for v in alt]), (mode, got)
+        ref, ref_kept = (want, want_kept) if got == [key(v) for v in want] else (alt, alt_kept)
+        assert [not bool(r["shadowed"]) for r in rec] == ref_kept
+        sg = b.decoder.signals(rec, ["0"], [gu.TS0])
+        for g, v in zip(sg, ref):
+            for name in ("max", "avg", "noise", "snr"):
+                assert abs(getattr(g, name) - getattr(v, name)) < POWER_TOL_DB, (mode, name, key(v))
+        b.close()
+
+
+def test_pinned_deviation_shadow_verdict_between_equal_maxima():
+    """reference analyze.py:310 (`f.max > sig.max`, strict).  A tone half-way between two bins puts the same maximum
+    into both (the oracle: equal to the bit, both kept); one float32 ulp of dB apart, one of the two is a shadow of
+    the other.  Guaranteed: same records, every figure within tolerance, every other verdict equal, and of the two
+    at least the louder (or both) is kept."""
+    _need_gpu()
+    fs, nperseg, window = 2048000, 256, "hamming"
+    blen = nperseg * 400
+    w = oracle.window_coefficients(window, nperseg)
+    x = synth.make_stream(synth.StreamSpec(blen, fs, [synth.Pulse(100 * nperseg, 120 * nperseg, 40.5 * fs / nperseg, synth.amp_for_peak_dbw(-70.0, w, fs), 0.0)],
+                                           noise_sigma=1e-9), seed=5)
+    params = oracle.ExtractParams(-90.0, 5.0, 8, 40, 0.0)
+    _, want, want_kept = _oracle_records(x, fs, nperseg, window, params)
+    tie = [i for i, v in enumerate(want) if v.fi in (40, 41)]
+    assert len(want) == 4 and len(tie) == 2 and abs(float(want[tie[0]].max) - float(want[tie[1]].max)) <= 8e-6  # one float32 ulp of dB at 70 dB
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window)
+    for mode in ("sparse", "dense"):
+        b = _batch_for(kw, 1, blen, mode)
+        b.enqueue(x[None, :])
+        rec = b.fetch_records()
+        assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in rec] == [(v.fi, v.start, v.end) for v in want]
+        sg = b.decoder.signals(rec, ["0"], [gu.TS0])
+        for g, v in zip(sg, want):
+            for name in ("max", "avg", "noise", "snr", "std"):
+                assert abs(getattr(g, name) - getattr(v, name)) < POWER_TOL_DB, (mode, name, v.fi)
+        got_kept = [not bool(r["shadowed"]) for r in rec]
+        for i in range(len(want)):
+            if i not in tie:
+                assert got_kept[i] == want_kept[i], (mode, i)
+        a, c = tie
+        assert got_kept[a] or got_kept[c], "two records of equal loudness cannot shadow each other both"
+        if not (got_kept[a] and got_kept[c]):
+            dropped, winner = (a, c) if not got_kept[a] else (c, a)
+            assert float(rec[winner]["max_p"]) > float(rec[dropped]["max_p"])  # strictly louder on the device's own figures
+        b.close()
+
+
+@pytest.mark.parametrize("wire", ["complex64", "uint8"])
+def test_pinned_deviation_std_of_a_plateau_holding_a_round_off_cell(wire):
+    """reference analyze.py:445 (`np.std(dB(data))` over cells that start ON the sub-threshold cell before the run, :382-398).
+    With a minimum duration of zero a one-segment pulse is a signal of two cells; here the first of them lies in a
+    segment that holds nothing but a strong bin-centred tone elsewhere -- 130 dB under its neighbour, i.e. float32
+    round-off of that tone in whatever FFT computes it.  `std` (65 dB here) then differs by more than 0.1 dB between
+    any two float32 FFTs: it is the ONE figure without a bound in that case; everything else holds.  uint8: the
+    segment before the pulse is saturated (constant bytes): every cell of it is exactly zero in the reference and
+    here (subtract-first detrend), dB = -inf, std = NaN on both sides."""
+    _need_gpu()
+    fs, nperseg, window = 2048000, 256, "hamming"
+    blen = nperseg * 200
+    w = oracle.window_coefficients(window, nperseg)
+    ka, kb, t = 30, 100, 80
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_min_duration_ms=0.0)
+    if wire == "complex64":
+        pulses = [synth.Pulse((t - 1) * nperseg, nperseg, ka * fs / nperseg, 0.5, 0.0),
+                  synth.Pulse(t * nperseg, nperseg, kb * fs / nperseg, synth.amp_for_peak_dbw(-75.0, w, fs), 0.0)]
+        x = synth.make_stream(synth.StreamSpec(blen, fs, pulses, noise_sigma=1e-9), seed=6)
+        feed = x[None, :]
+    else:
+        kw["signal_threshold_dbw"] = -80.0
+        pulses = [synth.Pulse(t * nperseg, nperseg, kb * fs / nperseg, synth.amp_for_peak_dbw(-55.0, w, fs), 0.0)]
+        raw = synth.quantize_u8(synth.make_stream(synth.StreamSpec(blen, fs, pulses, noise_sigma=0.012), seed=6))
+        raw[2 * (t - 1) * nperseg: 2 * t * nperseg] = 255  # the front end clipped for one segment
+        feed = raw[None, :]
+        x = synth.u8_to_complex64_like_kernel(raw)
+    params = oracle.ExtractParams(kw.get("signal_threshold_dbw", -90.0), 5.0, 0.0, 40, 0.0)
+    sp, want, want_kept = _oracle_records(x, fs, nperseg, window, params)
+    mine_i = [i for i, v in enumerate(want) if v.fi == kb and v.start == t - 1 and v.end == t + 1]
+    assert len(mine_i) == 1, [(v.fi, v.start, v.end) for v in want if abs(v.fi - kb) < 2]
+    if wire == "complex64":
+        assert sp[kb, t] / sp[kb, t - 1] > 1e10 and sp[ka, t - 1] / sp[kb, t - 1] > 1e12  # a round-off cell under a strong tone
+        assert np.isfinite(float(want[mine_i[0]].std)) and float(want[mine_i[0]].std) > 50.0
+    else:
+        assert sp[kb, t - 1] == 0.0 and np.isnan(float(want[mine_i[0]].std))
+    for mode in ("sparse", "dense"):
+        b = _batch_for(kw, 1, blen, mode)
+        (b.enqueue_bytes if wire == "uint8" else b.enqueue)(feed)
+        rec = b.fetch_records()
+        assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in rec] == [(v.fi, v.start, v.end) for v in want], mode
+        assert [not bool(r["shadowed"]) for r in rec] == want_kept
+        sg = b.decoder.signals(rec, ["0"], [gu.TS0])
+        for i, (g, v) in enumerate(zip(sg, want)):
+            holds_round_off = wire == "complex64" and v.start <= t - 1 < v.end  # any plateau with a cell of the strong tone's segment
+            for name in ("max", "avg", "noise", "snr"):
+                assert abs(getattr(g, name) - getattr(v, name)) < POWER_TOL_DB, (mode, name, v.fi)
+            if np.isnan(float(v.std)):
+                assert np.isnan(float(g.std)), (mode, v.fi)
+            elif holds_round_off and v.fi not in (ka - 1, ka, ka + 1):
+                assert np.isfinite(float(g.std)) and float(g.std) > 40.0  # the one unbounded figure: tens of dB either way, never NaN
+            else:
+                assert abs(float(g.std) - float(v.std)) < STD_TOL_DB, (mode, v.fi)
+        b.close()
+
+
 # ---------------------------------------------------------------------------
 # capacity handling and degenerate inputs
 # ---------------------------------------------------------------------------
@@ -977,6 +1200,40 @@ def test_lanes_stay_in_step_after_a_sparse_overflow_in_one_lane():
     ref.enqueue(good)
     want2 = ref.fetch_records()  # streams 2 and 3 saw the same two buffers in both analyzers
     assert got[got["stream"] >= 2].tobytes() == want2[want2["stream"] >= 2].tobytes()
+
+
+def test_lanes_stay_in_step_when_a_later_lane_refuses_an_enqueue(monkeypatch):
+    """Three rt_process calls without a fetch, the third refused by the SECOND lane (fault injection,
+    RT_TEST_FAIL_LANE): the call the third one would have overwritten (the first, never fetched) is dropped in every lane
+    before any lane starts, the first lane's new call is rolled back -- both lanes are left holding exactly the second
+    call, the look-back state is the one after it, and the next buffer is analysed as if the refused call had never
+    been made (advisor finding, round 2: the lanes before the failing one had lost the old call, the others kept it)."""
+    _need_gpu()
+    fs, nperseg, blen, S = 2048000, 256, 600 * 256, 4
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(33)
+    kw = dict(sample_rate=fs)
+    bufs = [np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 4, dur_ms=(9, 14), keep_clear_tail=0)), 500 + 10 * k + s)
+                      for s in range(S)]) for k in range(4)]
+    ref = _batch_for(kw, S, blen, "sparse", lanes=2)
+    want = {}
+    for k in (0, 1, 3):  # the refused call (buffer 2) never happened
+        ref.enqueue(bufs[k])
+        want[k] = ref.fetch_records()
+    b = _batch_for(kw, S, blen, "sparse", lanes=2)
+    b.enqueue(bufs[0])
+    b.enqueue(bufs[1])
+    monkeypatch.setenv("RT_TEST_FAIL_LANE", "1:1")
+    with pytest.raises(_native.NativeError) as e:
+        b.enqueue(bufs[2])
+    assert e.value.code == _native.RT_E_NOMEM
+    monkeypatch.delenv("RT_TEST_FAIL_LANE")
+    assert b.fetch_records().tobytes() == want[1].tobytes()  # the one call both lanes still hold
+    with pytest.raises(_native.NativeError):
+        b.fetch_records()  # nothing else is pending, in either lane
+    b.enqueue(bufs[3])
+    assert b.fetch_records().tobytes() == want[3].tobytes()  # look-back from buffer 1, as in the reference run
+    assert len(want[1]) > 0 and len(want[3]) > 0
 
 
 def test_lanes_stay_in_step_after_a_fetch_with_a_short_buffer():
