@@ -42,7 +42,7 @@ typedef enum rt_status {
     RT_E_UNSUPPORTED = -2,  /* e.g. nperseg not in {256,512,1024,2048,4096}     */
     RT_E_NO_DEVICE = -3,    /* no usable GPU / HIP failure at create            */
     RT_E_HIP = -4,          /* HIP runtime error (see rt_last_error)            */
-    RT_E_CAPACITY = -5,     /* record capacity exceeded (results truncated)     */
+    RT_E_CAPACITY = -5,     /* record capacity exceeded (results truncated, never dropped: rt_fetch) */
     RT_E_ONE_SEGMENT = -6,  /* exactly one segment: the reference raises
                                IndexError there (analyze.py:354, times[1])      */
     RT_E_NOMEM = -7,
@@ -205,7 +205,12 @@ int rt_process_u8_host(rt_handle *h, const void *iq_u8_host, int64_t n_samples, 
  * with a buffer consumes the call whatever `cap` is (records beyond `cap` are
  * lost; with cfg.lanes > 1 in every lane alike).
  * RT_E_CAPACITY: a stream had more than record_capacity records, the result is
- * truncated (and still delivered).  RT_E_HOT_OVERFLOW (RT_MODE_SPARSE): no
+ * truncated (and still delivered).  The record pool of a call is no limit (ABI v5):
+ * a call that finds more records than the pool holds grows the pool and is analysed
+ * again inside this function -- only rt_extract (whose spectrogram the library does
+ * not keep) or a host without memory for the larger pool end in RT_E_CAPACITY for
+ * that reason, and then every stream still delivers the first records, in emission
+ * order, that fit (never an empty list).  RT_E_HOT_OVERFLOW (RT_MODE_SPARSE): no
  * result, the call is consumed.
  * If an rt_process fails, nothing stays enqueued for it (with lanes: in no lane),
  * and the look-back state is the one before the call.
