@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=None, help="buffer length per stream")
     ap.add_argument("--nperseg", type=int, default=None)
     ap.add_argument("--window", default=None)
-    ap.add_argument("--mode", default="auto", choices=["auto", "dense", "sparse", "prefilter"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "dense", "sparse", "prefilter", "runfilter"])
     ap.add_argument("--segs-per-chunk", type=int, default=0)
     ap.add_argument("--input", default="c64", choices=["c64", "u8"],
                     help="IQ representation in HBM: complex64 (the BASELINE workload) or the RTL-SDR wire format "
@@ -443,7 +443,7 @@ def main():
             "streams_rank0": S,
             "samples_per_stream": blen,
             "segments_per_stream": n_seg,
-            "mode": {1: "dense", 2: "sparse", 3: "prefilter"}.get(info.mode_used, "?"),
+            "mode": {1: "dense", 2: "sparse", 3: "prefilter", 4: "runfilter"}.get(info.mode_used, "?"),
             "fallbacks": fell_back,
             "records_per_step": n_records_total,
             "candidate_cells_per_step": n_hot_total,

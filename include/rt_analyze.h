@@ -59,12 +59,19 @@ typedef enum rt_mode {
                            the level below keep overflowing) */
     RT_MODE_DENSE = 1,  /* materialise the power spectrogram (any input)        */
     RT_MODE_SPARSE = 2, /* fused sparse path only; overflow -> RT_E_HOT_OVERFLOW */
-    RT_MODE_PREFILTER = 3 /* sparse path behind the run-length pre-filter (two scan passes: per chunk of
+    RT_MODE_PREFILTER = 3, /* sparse path behind the run-length pre-filter (two scan passes: per chunk of
                              segments and bin "every cell passes the absolute threshold", then candidate
                              cells only from such chunks and their neighbours): for inputs whose noise
                              crosses the threshold.  Needs signal_min_duration >= 2 * segs_per_chunk hops
                              (else RT_E_UNSUPPORTED); overflow -> RT_E_HOT_OVERFLOW.  RT_MODE_AUTO goes
                              through it between the sparse and the dense path where it is available. */
+    RT_MODE_RUNFILTER = 4 /* ABI v5: sparse path behind the EXACT run-length pre-filter: a first scan keeps the
+                             threshold bit of every cell, a planning kernel keeps the cells of threshold runs of
+                             at least the minimum plateau length (or through t = 0), a second scan transforms only
+                             the segments that hold such cells.  Any segs_per_chunk; the geometry where
+                             RT_MODE_PREFILTER is unavailable (the reference's defaults: 300 kS/s, 8 ms) is where
+                             RT_MODE_AUTO uses it between the sparse and the dense path.  RT_E_UNSUPPORTED where the
+                             minimum plateau length does not fit the planning tiles; overflow -> RT_E_HOT_OVERFLOW. */
 } rt_mode;
 
 /*
@@ -248,7 +255,7 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
 /* Per-call figures of the last rt_process (valid after rt_fetch). */
 typedef struct rt_call_info {
     int32_t n_seg;            /* T of the call                                           */
-    int32_t mode_used;        /* RT_MODE_DENSE, RT_MODE_SPARSE or RT_MODE_PREFILTER       */
+    int32_t mode_used;        /* RT_MODE_DENSE, RT_MODE_SPARSE, RT_MODE_PREFILTER or RT_MODE_RUNFILTER */
     int32_t fell_back;        /* 1 if candidate lists overflowed and (part of) the call was re-run */
     int32_t n_dense_streams;  /* RT_MODE_AUTO: streams re-run dense on their own because only they overflowed
                                  (a few noisy SDRs in a batch; mode_used then still names the batch's path) */

@@ -24,7 +24,7 @@ RT_E_ONE_SEGMENT = -6
 RT_E_NOMEM = -7
 RT_E_HOT_OVERFLOW = -8  # RT_MODE_SPARSE: a candidate list overflowed, the call has no result and is consumed
 
-RT_MODE_AUTO, RT_MODE_DENSE, RT_MODE_SPARSE, RT_MODE_PREFILTER = 0, 1, 2, 3
+RT_MODE_AUTO, RT_MODE_DENSE, RT_MODE_SPARSE, RT_MODE_PREFILTER, RT_MODE_RUNFILTER = 0, 1, 2, 3, 4
 RT_FLAG_TIMING = 1
 RT_FLAG_NO_LIN_DETREND = 2  # subtract the segment mean before windowing even for hamming / hann / boxcar windows
 

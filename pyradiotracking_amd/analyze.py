@@ -214,7 +214,8 @@ class BatchSignalAnalyzer:
             min_duration_s=self.signal_min_duration,
             max_duration_s=self.signal_max_duration,
             device=gpu,
-            mode={"auto": _native.RT_MODE_AUTO, "dense": _native.RT_MODE_DENSE, "sparse": _native.RT_MODE_SPARSE, "prefilter": _native.RT_MODE_PREFILTER}[mode],
+            mode={"auto": _native.RT_MODE_AUTO, "dense": _native.RT_MODE_DENSE, "sparse": _native.RT_MODE_SPARSE, "prefilter": _native.RT_MODE_PREFILTER,
+                  "runfilter": _native.RT_MODE_RUNFILTER}[mode],
             hot_capacity=hot_capacity,
             record_capacity=record_capacity,
             segs_per_chunk=segs_per_chunk,

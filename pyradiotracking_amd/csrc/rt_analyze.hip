@@ -70,6 +70,9 @@ struct Slot {
     int32_t *h_hot_total = nullptr;   // pinned, [S]
     float *d_psum = nullptr;
     uint16_t *d_full = nullptr;       // [S][max_chunks][LG] chunk bits of the run-length pre-filter, then [S][L][LG] bits of chunk 0 by segment (null: not available)
+    uint16_t *d_cell_hot = nullptr, *d_cell_need = nullptr;  // [S][max_seg][LG] threshold bits of every cell / the cells to emit (RT_MODE_RUNFILTER)
+    int32_t *d_seg_list = nullptr;    // [S][max_seg] segments holding such cells, then [S] their number per stream and [1] the batch's total
+    int32_t *h_seg_total = nullptr;   // pinned: that total, copied behind plan_runs
     rt_record *d_raw = nullptr;
     int32_t *d_raw_count = nullptr;
     unsigned long long *d_counters = nullptr;  // 4 words (atomics: device memory)
@@ -129,6 +132,9 @@ struct rt_handle {
     // lists overflow is re-run one level up when it is fetched; the handle then stays on that level for `dense_sticky`
     // calls before it probes the level below again (a failed probe costs a wasted scan: the interval doubles, 16 .. 1024).
     bool prefilter_ok = false;
+    bool runfilter_ok = false;  // RT_MODE_RUNFILTER is possible and its scratch is allocated
+    int run_cells = 1;          // r: cells a plateau needs unless it runs through t = 0 (plan_runs)
+    int plan_tile = 0;          // rows per planning tile
     int auto_level = RT_MODE_SPARSE;
     int dense_sticky = 0;  // calls left on auto_level before the next probe
     int sticky_len = 16;
@@ -298,6 +304,10 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.first = sl.d_full ? sl.d_full + (size_t)h->cfg.n_streams * h->max_chunks * h->LG : nullptr;
     p.item_chunks = sl.d_items;
     p.item_count = sl.d_items ? sl.d_items + (size_t)h->cfg.n_streams * h->max_blocks * h->GPW : nullptr;
+    p.cell_hot = sl.d_cell_hot;
+    p.cell_need = sl.d_cell_need;
+    p.seg_list = sl.d_seg_list;
+    p.seg_count = sl.d_seg_list ? sl.d_seg_list + (size_t)h->cfg.n_streams * h->max_seg : nullptr;
     return p;
 }
 
@@ -319,7 +329,7 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.hot = sl.d_hot;
     a.hot_count = sl.d_hot_count;
     a.hot_count_rw = sl.d_hot_count;
-    a.hot_seen = sl.d_hot_seen;
+    a.large_any = sl.d_hot_seen;  // (one word per stream of the array's S * 16)
     a.hot_total = sl.h_hot_total;
     a.lds_cells = next_pow2(std::max(h->hot_cap, 64));
     a.cand_cap = h->cand_cap;
@@ -362,12 +372,14 @@ int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
 }
 
 // the level above / below `mode` in AUTO's order SPARSE < PREFILTER < DENSE
+// (the middle level is the chunk-bit pre-filter where the geometry allows it, else the exact one)
+int middle_level(const rt_handle *h) { return h->prefilter_ok ? RT_MODE_PREFILTER : h->runfilter_ok ? RT_MODE_RUNFILTER : RT_MODE_DENSE; }
 int level_up(const rt_handle *h, int mode) {
-    if (mode == RT_MODE_SPARSE && h->prefilter_ok) return RT_MODE_PREFILTER;
+    if (mode == RT_MODE_SPARSE) return middle_level(h);
     return RT_MODE_DENSE;
 }
 int level_down(const rt_handle *h, int mode) {
-    if (mode == RT_MODE_DENSE && h->prefilter_ok) return RT_MODE_PREFILTER;
+    if (mode == RT_MODE_DENSE && middle_level(h) != RT_MODE_DENSE) return middle_level(h);
     return RT_MODE_SPARSE;
 }
 
@@ -397,7 +409,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         if (rc != RT_OK) return rc;
         sp.spec = h->d_spec;
     }
-    if (mode == RT_MODE_PREFILTER && !sl.d_full) {
+    if ((mode == RT_MODE_PREFILTER && !sl.d_full) || (mode == RT_MODE_RUNFILTER && !sl.d_cell_hot)) {
         h->err = "internal: pre-filter without its scratch";
         return RT_E_INVALID;
     }
@@ -405,6 +417,15 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     if (launched) *launched = true;
     if (dense) {
         launch_scan<1>(h, sp, blocks, c.u8);
+    } else if (mode == RT_MODE_RUNFILTER) {
+        // threshold bits of every cell (+ row sums, tail) -> cells of runs long enough -> only their segments again
+        launch_scan<6>(h, sp, blocks, c.u8);
+        RT_HIP(h, hipMemsetAsync(const_cast<int32_t *>(sp.seg_count), 0, ((size_t)S + 1) * sizeof(int32_t), h->s_scan));
+        const int tiles = (c.n_seg + h->plan_tile - 1) / h->plan_tile;
+        hipLaunchKernelGGL(plan_runs, dim3(tiles, S), dim3(256), 0, h->s_scan, sp.cell_hot, sl.d_cell_need,
+                           sl.d_seg_list, const_cast<int32_t *>(sp.seg_count), c.n_seg, h->LG, h->run_cells, h->plan_tile);
+        RT_HIP(h, hipMemcpyAsync(sl.h_seg_total, sp.seg_count + S, sizeof(int32_t), hipMemcpyDeviceToHost, h->s_scan));
+        launch_scan<7>(h, sp, blocks, c.u8);
     } else if (mode == RT_MODE_PREFILTER) {
         if (!second_pass_only) launch_scan<4>(h, sp, blocks, c.u8);
         hipLaunchKernelGGL(plan_pass_b, dim3(S), dim3(256), sizeof(uint32_t) * ((sp.chunks + 31) / 32), h->s_scan, sp.full, sp.first,
@@ -472,14 +493,14 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     a.prev_cols = h->K;
     a.chunks = sp.blocks_per_stream;
     a.spec = h->d_spec;
-    a.filtered = (mode == RT_MODE_PREFILTER) ? 1 : 0;
+    a.filtered = (mode == RT_MODE_PREFILTER || mode == RT_MODE_RUNFILTER) ? 1 : 0;
     if (dense) {
         hipLaunchKernelGGL(detect_dense, dim3(S), dim3(kDetBlock), h->lds_dense, sd, a);
     } else {
         const int waves = S * kBuckets;
         hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
         // always launched: it is also the pass that re-zeroes the per-bucket counters
-        hipLaunchKernelGGL(detect_bucket<true>, dim3(waves), dim3(256), h->lds_large, sd, a);
+        hipLaunchKernelGGL(detect_bucket<true>, dim3(S), dim3(256), h->lds_large, sd, a);  // one workgroup per stream: its 16 buckets in turn
         hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), 0, sd, a);
     }
     RT_HIP(h, hipGetLastError());
@@ -692,6 +713,10 @@ void rt_destroy(rt_handle *h) {
         (void)hipHostFree(sl.h_hot_total);
         (void)hipFree(sl.d_psum);
         (void)hipFree(sl.d_full);
+        (void)hipFree(sl.d_cell_hot);
+        (void)hipFree(sl.d_cell_need);
+        (void)hipFree(sl.d_seg_list);
+        (void)hipHostFree(sl.h_seg_total);
         (void)hipFree(sl.d_raw);
         (void)hipFree(sl.d_raw_count);
         (void)hipFree(sl.d_counters);
@@ -723,7 +748,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     for (int r : {1, 2, 4, 8, 16})
         if (cfg->nperseg == 256 * r) R3 = r;
     if (!R3) return fail_create(RT_E_UNSUPPORTED, "nperseg must be one of 256, 512, 1024, 2048, 4096");
-    if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_PREFILTER) return fail_create(RT_E_INVALID, "bad mode");
+    if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_RUNFILTER) return fail_create(RT_E_INVALID, "bad mode");
     if (cfg->lanes > 1 && cfg->n_streams > 1) {
         // stream groups on their own handles and HIP streams: the detection kernels, launch gaps and last
         // workgroup round of one group overlap the scan of another
@@ -791,6 +816,18 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             delete h;
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_PREFILTER needs signal_min_duration >= 2 * segs_per_chunk STFT hops");
         }
+        // Exact run-length pre-filter: any chunk length; its planning tiles (kPlanWords words of LDS per buffer, a halo
+        // of r rows either side) must leave room for rows of their own.  Built where it is asked for, and in AUTO mode
+        // where the chunk-bit pre-filter is not available.
+        h->run_cells = (int)std::max<long long>(1, std::min<long long>(r_min, 1 << 20));
+        const int rows_max = kPlanWords / (h->LG / 4);  // rows of 64-bit words (four lanes each) per LDS buffer
+        h->plan_tile = std::min(rows_max - 2 * h->run_cells, kPlanWords / 4);
+        const bool fits = h->plan_tile >= 8 && h->max_seg >= 2;
+        if (cfg->mode == RT_MODE_RUNFILTER && !fits) {
+            delete h;
+            return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length does not fit the planning tiles at this nperseg");
+        }
+        h->runfilter_ok = fits && (cfg->mode == RT_MODE_RUNFILTER || (cfg->mode == RT_MODE_AUTO && !h->prefilter_ok));
     }
     if (((long long)h->N << key_tbits(std::max(h->max_seg, 2))) > 0x100000000ll) {
         delete h;
@@ -920,6 +957,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         if (h->prefilter_ok && cfg->mode != RT_MODE_DENSE)
             RT_CREATE_HIP(hipMalloc(&sl.d_full, (size_t)S * (h->max_chunks + h->L) * LG * sizeof(uint16_t)));  // + the bits of chunk 0 by segment
         if (sl.d_full) RT_CREATE_HIP(hipMalloc(&sl.d_items, ((size_t)S * h->max_blocks * h->GPW + S) * sizeof(int32_t)));
+        if (h->runfilter_ok) {
+            const size_t cells = (size_t)S * std::max(h->max_seg, 1) * LG;
+            RT_CREATE_HIP(hipMalloc(&sl.d_cell_hot, cells * sizeof(uint16_t)));
+            RT_CREATE_HIP(hipMalloc(&sl.d_cell_need, cells * sizeof(uint16_t)));
+            RT_CREATE_HIP(hipMalloc(&sl.d_seg_list, ((size_t)S * std::max(h->max_seg, 1) + S + 1) * sizeof(int32_t)));
+            RT_CREATE_HIP(hipHostMalloc(&sl.h_seg_total, sizeof(int32_t)));
+            *sl.h_seg_total = 0;
+        }
         RT_CREATE_HIP(hipMalloc(&sl.d_hot, (size_t)S * kBuckets * h->hot_cap * sizeof(uint2)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_count, (size_t)S * kBuckets * sizeof(uint32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_seen, (size_t)S * kBuckets * sizeof(uint32_t)));
@@ -1365,13 +1410,25 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
   }
     if (c.mode_used != RT_MODE_DENSE && !c.is_extract && c.n_seg > 0)
         for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
-    auto rank = [](int mode) { return mode == RT_MODE_SPARSE ? 0 : mode == RT_MODE_PREFILTER ? 1 : 2; };
-    if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && rank(c.mode_used) < rank(h->auto_level)) {
+    auto rank = [](int mode) { return mode == RT_MODE_SPARSE ? 0 : (mode == RT_MODE_PREFILTER || mode == RT_MODE_RUNFILTER) ? 1 : 2; };
+    // (the exact pre-filter on input where it is not selective: see below)
+    const bool unselective = h->cfg.mode == RT_MODE_AUTO && c.mode_used == RT_MODE_RUNFILTER && !c.is_extract && c.n_seg > 0 && sl.h_seg_total &&
+                             (int64_t)*sl.h_seg_total * 2 > (int64_t)h->cfg.n_streams * c.n_seg;
+    if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && rank(c.mode_used) < rank(h->auto_level) && !unselective) {
         // a probe of a lower level went through: the handle moves there (and from the pre-filter level it will
         // probe the plain sparse path after the usual interval)
         h->auto_level = c.mode_used;
         h->sticky_len = 16;
         h->dense_sticky = (c.mode_used == RT_MODE_SPARSE) ? 0 : 16;
+    }
+    if (unselective) {
+        // The exact pre-filter went through, but more than half of all segments held cells it has to keep: its second scan
+        // is then most of a scan, and the dense path (one scan, 16 B per sample) is faster -- measured at the reference's
+        // default geometry with the noise floor 2 dB over the threshold: 213 k against 241 k MS/s.  The handle moves up like
+        // after an overflow (without analysing this call again: its result stands) and probes this level later.
+        h->auto_level = RT_MODE_DENSE;
+        h->dense_sticky = h->sticky_len;
+        h->sticky_len = std::min(h->sticky_len * 2, 1024);
     }
     if (flags & kFlagInconsistent) {
         std::memset(sl.h_incons, 0, (size_t)h->cfg.n_streams * sizeof(int32_t));

@@ -76,6 +76,11 @@ struct StftParams {
                              // `chunks` = none), item_count[s] workgroups per stream
     int32_t *item_count;     // [S]
     uint32_t *work;          // two words, zero between launches: tickets drawn for further items, workgroups that have left
+    // exact run-length pre-filter (MODE 6 / plan_runs / MODE 7, see plan_runs)
+    uint16_t *cell_hot;      // [S][T][LG] per lane: bit r = "cell (t, lane's bin r) passes the absolute threshold" (MODE 6 writes)
+    const uint16_t *cell_need;  // [S][T][LG] the cells the selective pass emits (plan_runs writes, MODE 7 reads)
+    const int32_t *seg_list; // [S][T] the segments that hold such cells, in any order; seg_count[s] of them
+    const int32_t *seg_count;
 #ifdef RT_STAMPS
     uint32_t *dbg;           // [workgroups][4 waves][kStamps] cycles per stage, [kStamps - 1] = steps taken
 #endif
@@ -380,7 +385,7 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
 #ifndef RT_NO_PERSIST
 #define RT_NO_PERSIST 0
 #endif
-__host__ __device__ constexpr bool scan_persistent(int R3, int mode) { return mode != 5 && !RT_NO_PERSIST && R3 >= 4; }
+__host__ __device__ constexpr bool scan_persistent(int R3, int mode) { return mode != 5 && mode != 7 && !RT_NO_PERSIST && R3 >= 4; }
 __host__ __device__ constexpr int scan_block(int R3) { return R3 <= RT_ONE_WAVE_MAX_R3 ? 64 : kBlock; }
 
 // LIN: constant detrend by linearity.  FFT(w (x - m)) = FFT(w x) - m W with W = FFT(w); for a cosine-sum window of
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     constexpr size_t kT1fB = T1_FACTORED ? sizeof(float4) * 2 * LG : 0;
     constexpr size_t kT1B = T1_IN_LDS ? sizeof(float4) * 8 * LG : 0;
     constexpr size_t kT2B = (R3 > 1) ? sizeof(float4) * 8 * R3 : 0;
-    constexpr size_t kStageB = (MODE == 0 || MODE == 5) ? sizeof(uint2) * (BLK / 64) * kStage : 0;
+    constexpr size_t kStageB = (MODE == 0 || MODE == 5 || MODE == 7) ? sizeof(uint2) * (BLK / 64) * kStage : 0;
     __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB];
     cf *const xch = reinterpret_cast<cf *>(lds_block);
     cf *const red = reinterpret_cast<cf *>(lds_block + kXchB);
@@ -509,7 +514,17 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         if (pb >= p.item_count[s]) return;
         chunk = p.item_chunks[((int64_t)s * p.blocks_per_stream + pb) * GPW + g];
     }
-    const bool chunk_ok = chunk < p.chunks;
+    // MODE 7: the item is GPW * L entries of the stream's segment list; this lane group takes L consecutive ones
+    int e0 = 0, n_mine = 0;
+    if constexpr (MODE == 7) {
+        const int pb = item / p.n_streams;
+        const int cnt = p.seg_count[s];
+        if (pb * GPW * p.segs_per_chunk >= cnt) return;  // (workgroup-uniform)
+        e0 = (pb * GPW + g) * p.segs_per_chunk;
+        n_mine = cnt - e0;
+        n_mine = n_mine < 0 ? 0 : (n_mine > p.segs_per_chunk ? p.segs_per_chunk : n_mine);
+    }
+    const bool chunk_ok = (MODE == 7) ? (n_mine > 0) : (chunk < p.chunks);
     const int c0 = chunk * p.segs_per_chunk;
     if constexpr (LG > 64) {
         // (behind the barrier that ended the previous item, ahead of this item's first one: group_sum / the rows barrier)
@@ -536,15 +551,16 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     uint32_t next_hot = 0;  // hot bits of the segment one later in time (MODE 0)
     // candidate staging: 128 cells per wave, flushed with one returned atomic per bucket
     uint2 *const stage = reinterpret_cast<uint2 *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B);
-    uint2 *stg = stage + ((MODE == 0 || MODE == 5) ? (tid >> 6) * kStage : 0);  // this wave's staging area
+    uint2 *stg = stage + ((MODE == 0 || MODE == 5 || MODE == 7) ? (tid >> 6) * kStage : 0);  // this wave's staging area
     constexpr int kStageLimit = kStage;
     int stg_n = 0;                                                    // wave-uniform fill level
     bool gave_up = false;  // wave-uniform: a candidate list of this stream has overflowed, the call will be re-run dense
 
     const raw_t *stream_iq = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride;
-    constexpr bool EMIT = (MODE == 0 || MODE == 5);   // candidate cells go to the bucket lists
-    constexpr bool FLAGS = (MODE == 0 || MODE == 4);  // chunk bits of the run-length pre-filter are written
-    constexpr bool SUMS = (MODE != 2 && MODE != 5);   // row sums and look-back tail (MODE 5 repeats chunks of a scan that wrote them)
+    constexpr bool EMIT = (MODE == 0 || MODE == 5 || MODE == 7);   // candidate cells go to the bucket lists
+    constexpr bool FLAGS = (MODE == 0 || MODE == 4 || MODE == 6);  // threshold bits are kept (chunk bits of the run-length pre-filter; MODE 6: every cell's)
+    constexpr bool SUMS = (MODE != 2 && MODE != 5 && MODE != 7);   // row sums and look-back tail (MODE 5 / 7 repeat segments of a scan that wrote them)
+    constexpr bool LISTED = (MODE == 7);  // the steps take the segments plan_runs listed, not a chunk's
     // Steps 1 .. L walk the chunk down from its latest segment.  A cell is a candidate cell if it passes the threshold or
     // directly precedes one that does (T11); for the chunk's lowest segment c0 that concerns a cell of the neighbour
     // below, whose owner cannot know.  So where (and only where) a lowest cell is hot, the wave (workgroup, for lane
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #define RT_BELOW_MAX_R3 8
 #endif
     constexpr bool BELOW = (R3 <= RT_BELOW_MAX_R3);
-    const int i_first = (!BELOW && EMIT) ? 0 : 1;
+    const int i_first = (!BELOW && EMIT && !LISTED) ? 0 : 1;
     int n_steps = L;
 
     uint32_t allhot = 0xFFFFu;  // FLAGS: the chunk's bits so far
@@ -586,6 +602,21 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         }
     }
 
+    if constexpr (LISTED) {
+        need = 0u;  // (what a step emits comes with its segment: first_nxt)
+        if constexpr (LG <= 64) {
+            const unsigned long long any = __builtin_amdgcn_ballot_w64(n_mine > 0);
+            if (any == 0ull) return;  // (no workgroup barrier follows in MODE 7 either)
+            if constexpr (LG < 64) group_need = n_mine > 0;
+        }
+    }
+    int seg7_cur = -1, seg7_nxt = -1;  // LISTED: this step's segment and the next step's (-1: none)
+    if constexpr (LISTED) {
+        const int32_t *lst = p.seg_list + (int64_t)s * T + e0;
+        if (n_mine > 0) seg7_cur = lst[0];
+        if (n_mine > 1) seg7_nxt = lst[1];
+    }
+
     // software pipeline: the 16 loads of the next segment are issued before the
     // current one is transformed, so their HBM latency hides under ~700 VALU ops.
     // Loads are unconditional (segment index clamped into the stream): lanes of
@@ -602,8 +633,13 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             first_nxt = 0u;
             if (chunk == 0 && chunk_ok && seg_req >= 0 && seg_req < L) first_nxt = p.first[((int64_t)s * L + seg_req) * LG + lt];
         }
+        if constexpr (LISTED) {
+            first_nxt = 0u;
+            if (seg_req >= 0) first_nxt = p.cell_need[((int64_t)s * T + seg_req) * LG + lt];  // the cells of that segment to emit
+        }
         if constexpr (BUF_LOADS) {
-            const int sg = __builtin_amdgcn_readfirstlane(chunk_u * L + (seg_req - c0));  // == seg_req, in SGPRs
+            const int sg = LISTED ? __builtin_amdgcn_readfirstlane(seg_req)
+                                  : __builtin_amdgcn_readfirstlane(chunk_u * L + (seg_req - c0));  // == seg_req, in SGPRs
 #ifdef RT_EXP_ALIAS
             const raw_t *base = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(sg & RT_EXP_ALIAS) * N;
             const rsrc_t r = make_rsrc(base, (uint32_t)(N * sizeof(raw_t)));
@@ -613,7 +649,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #endif
 #pragma unroll
             for (int m = 0; m < 16; ++m) nxt[m] = buf_load_iq(r, lt * (int)sizeof(raw_t), LG * m * (int)sizeof(raw_t), raw_t{});
-        } else if (MODE != 5 || group_need) {
+        } else if ((MODE != 5 && MODE != 7) || group_need) {
             int sc = seg_req < seg_hi ? seg_req : seg_hi;
             sc = sc < 0 ? 0 : sc;  // (step L + 1 of a wave that also holds chunk 0)
 #ifdef RT_EXP_ALIAS  // diagnostic build (tools/variant.sh alias -DRT_EXP_ALIAS=63): every load hits the same 64 segments of
@@ -627,7 +663,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
         }
     };
-    request_segment(c0 + L - i_first);
+    request_segment(LISTED ? seg7_cur : c0 + L - i_first);
 #ifdef RT_STAMPS
     uint32_t st_acc[kStamps] = {};
     uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -636,8 +672,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 
     for (int i = i_first; i <= n_steps; ++i) {
         RT_STAMP(0);  // loop control, the previous step's candidate test
-        const int seg = c0 + L - i;
-        const bool halo = BELOW ? (i > L) : (i == 0);  // the step below (above) the chunk: no sums, tail, chunk bits
+        const int seg = LISTED ? seg7_cur : c0 + L - i;
+        const bool halo = LISTED ? false : (BELOW ? (i > L) : (i == 0));  // the step below (above) the chunk: no sums, tail, chunk bits
         const bool active = chunk_ok && seg < T && seg >= 0;
 
         cf v[16];
@@ -666,7 +702,11 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #endif
         }
         // next step's segment (the segment below the chunk is requested at the end of step L, once it is known to be needed)
-        if constexpr (BELOW) {
+        if constexpr (LISTED) {
+            request_segment(seg7_nxt);
+            seg7_cur = seg7_nxt;  // (for the next step; `seg` above is this step's)
+            seg7_nxt = (i + 1 < n_mine) ? p.seg_list[(int64_t)s * T + e0 + i + 1] : -1;  // consumed a step later: its latency is covered
+        } else if constexpr (BELOW) {
             if (i < L) request_segment(seg - 1);
         } else {
             request_segment((i < L) ? seg - 1 : seg);  // (the last step re-reads its own: harmless, keeps the loop uniform)
@@ -955,6 +995,13 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             if constexpr (FLAGS) {
                 // pre-filter bits: every cell of the chunk so far at or above the threshold; the run through t = 0
                 // (it may continue a run of the previous buffer) counts whatever its length
+                if constexpr (MODE == 6) {
+                    if (active && !halo) {  // (lane index opaque: the address stays out of the loop's registers)
+                        int lt_b = lt;
+                        asm volatile("" : "+v"(lt_b));
+                        p.cell_hot[((int64_t)s * T + seg) * LG + lt_b] = (uint16_t)hot;
+                    }
+                }
                 if (active && !halo) {
                     allhot &= hot;
                     if (chunk == 0 && p.full) {  // (lane index opaque: the address stays out of the loop's registers)
@@ -968,7 +1015,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 }
             }
             // a cell is kept if it is a candidate itself or directly precedes one (T11)
-            const uint32_t emit = (EMIT && active) ? ((halo ? (BELOW ? (next_hot & ~hot) : 0u) : (hot | next_hot)) & need_seg) : 0u;
+            const uint32_t emit = LISTED ? (active ? need_seg : 0u)  // the cells plan_runs asked for, whether they pass the threshold or precede one that does
+                                         : (EMIT && active) ? ((halo ? (BELOW ? (next_hot & ~hot) : 0u) : (hot | next_hot)) & need_seg) : 0u;
             if (EMIT && RT_ABLATE != 9 && !gave_up && __builtin_amdgcn_ballot_w64(emit != 0) != 0) {  // wave-uniform, rare (RT_ABLATE 9: test without emission)
                 // Candidates are staged per wave in LDS and flushed with ONE returned atomic per
                 // flush: an atomic per cell would stall on vmcnt(0) and drain the prefetch.
@@ -1019,7 +1067,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 }
             }
             next_hot = hot;
-            if constexpr (EMIT && BELOW) {
+            if constexpr (EMIT && BELOW && !LISTED) {
                 if (i == L) {
                     const bool below = chunk_ok && c0 > 0 && (hot & need) != 0u;  // a lowest cell of the chunk is a candidate
                     bool any_below;
@@ -1149,6 +1197,122 @@ __global__ __launch_bounds__(256) void plan_pass_b(const uint16_t *full, uint16_
     if (tid == 0) item_count[s] = n_items;
 }
 
+// Exact run-length pre-filter (RT_MODE_RUNFILTER), between its two scans.  Where the chunk bits above need
+// `signal_min_duration >= 2 L - 1` hops (the reference's default geometry, 300 kS/s: 8 ms = 9.4 hops, does not qualify for any
+// useful L), this one works on the threshold bit of EVERY cell (MODE 6 writes them: 2 B per lane and segment, 1.6 % of the IQ
+// bytes) and is exact for any chunk length.  A plateau can only become a signal if it has at least r = min_run_cells cells
+// (the duration gate, rt_core.h: gate_run) or contains t = 0 (it may continue a plateau of the previous buffer), and every
+// plateau lies inside a run of cells that pass the absolute threshold.  So the cells the detection needs are
+//     C = { cells of threshold runs of length >= r }  u  { cells of the run through t = 0 },   plus the cell before each
+// (`data` starts on it, analyze.py:382-398), and only the segments holding such cells are transformed again (MODE 7).
+// Per bin these are window operations along t, done for the 16 bins of a lane at once on its 16-bit words:
+//     E[t] = AND_{j<r} H[t+j]   (a window of r set bits starts at t)      by doubling: P_1 = H, P_2k[t] = P_k[t] & P_k[t+k]
+//     C[t] = OR_{j<r}  E[t-j]   (t lies in such a window)                 likewise with OR and negative offsets
+// One workgroup per (tile of rows, stream), the tile with a halo of r rows either side in LDS (three buffers of 32 KiB).
+// Writes need[t] = C[t] | C[t+1] for the tile's rows and appends the rows with any bit set to the stream's segment list
+// (order irrelevant: the detection sorts its cells).
+// The 16-bit words of four neighbouring lanes are handled as one 64-bit word (the operations are bitwise, lg is a multiple of
+// 16), tiles are short (a few halos long), so that several workgroups share a CU: the first version -- 16-bit words, tiles
+// of 1 000 rows, one workgroup of 100 KiB of LDS per CU -- took 3.3 ms per call at 4 096 streams of the reference's
+// default geometry, twice the scan it serves.
+constexpr int kPlanWords = 2048;  // 64-bit words per LDS buffer (16 KiB; three buffers)
+__global__ __launch_bounds__(256) void plan_runs(const uint16_t *hot, uint16_t *need, int32_t *seg_list, int32_t *seg_count,
+                                                 int n_seg, int lg, int r, int tile_rows) {
+    __shared__ unsigned long long plan_buf[3 * kPlanWords];
+    __shared__ uint32_t row_any[kPlanWords / 4];  // (tile_rows <= kPlanWords / (lg / 4) <= kPlanWords / 4)
+    unsigned long long *A = plan_buf, *B = plan_buf + kPlanWords, *Cb = plan_buf + 2 * kPlanWords;
+    const int s = blockIdx.y, tid = threadIdx.x;
+    const int w = lg / 4;                                  // 64-bit words per row
+    const int t0 = blockIdx.x * tile_rows;                 // first row of the tile
+    const int rows = tile_rows + 2 * r;                    // with the halo
+    const int words = rows * w;
+    const unsigned long long *H = reinterpret_cast<const unsigned long long *>(hot + (int64_t)s * n_seg * lg);
+    // A = H on rows t0 - r .. t0 + tile_rows + r - 1 (zero outside the buffer)
+    for (int i = tid; i < words; i += 256) {
+        const int t = t0 - r + i / w;
+        A[i] = (t >= 0 && t < n_seg) ? H[(int64_t)t * w + i % w] : 0ull;
+    }
+    for (int i = tid; i < tile_rows; i += 256) row_any[i] = 0u;
+    __syncthreads();
+    auto at = [&](const unsigned long long *X, int i, int shift_rows) -> unsigned long long {  // X[row + shift], zero outside the staged rows
+        const int j = i + shift_rows * w;
+        return (j >= 0 && j < words) ? X[j] : 0ull;
+    };
+    // E = AND over r rows starting at t: binary decomposition of r over the doubled windows P (span k)
+    {
+        unsigned long long *P = A, *Q = B;
+        bool first = true;
+        int off = 0;
+        for (int k = 1; k <= r; k <<= 1) {
+            if (r & k) {
+                for (int i = tid; i < words; i += 256) Cb[i] = first ? at(P, i, off) : (Cb[i] & at(P, i, off));
+                first = false;
+                off += k;
+            }
+            if ((k << 1) <= r) {
+                __syncthreads();
+                for (int i = tid; i < words; i += 256) Q[i] = P[i] & at(P, i, k);
+                unsigned long long *tmp = P; P = Q; Q = tmp;
+            }
+            __syncthreads();
+        }
+    }
+    // C = OR over the r rows ending at t of E (now in Cb): same scheme, negative offsets
+    unsigned long long *Cres;
+    {
+        unsigned long long *P = Cb, *Q = A, *R = B;
+        bool first = true;
+        int off = 0;
+        for (int k = 1; k <= r; k <<= 1) {
+            if (r & k) {
+                for (int i = tid; i < words; i += 256) R[i] = first ? at(P, i, -off) : (R[i] | at(P, i, -off));
+                first = false;
+                off += k;
+            }
+            if ((k << 1) <= r) {
+                __syncthreads();
+                for (int i = tid; i < words; i += 256) Q[i] = P[i] | at(P, i, -k);
+                unsigned long long *tmp = P; P = Q; Q = tmp;
+            }
+            __syncthreads();
+        }
+        Cres = R;
+    }
+    // the run through t = 0, whatever its length (first tile only): and the rows up from t = 0 until nothing is left
+    if (t0 == 0) {
+        for (int l = tid; l < w; l += 256) {
+            unsigned long long z = ~0ull;
+            for (int t = 0; t < tile_rows + r && t < n_seg && z; ++t) {
+                z &= H[(int64_t)t * w + l];
+                Cres[(t + r) * w + l] |= z;
+            }
+        }
+    }
+    __syncthreads();
+    // need[t] = C[t] | C[t + 1] (the cell before a run), rows of this tile only; remember which rows hold anything
+    unsigned long long *Nd = reinterpret_cast<unsigned long long *>(need + (int64_t)s * n_seg * lg);
+    for (int i = tid; i < tile_rows * w; i += 256) {
+        const int row = i / w, t = t0 + row;
+        if (t >= n_seg) break;
+        const int j = (row + r) * w + i % w;
+        unsigned long long v = Cres[j];
+        if (t + 1 < n_seg) v |= Cres[j + w];
+        Nd[(int64_t)t * w + i % w] = v;
+        if (v) row_any[row] = 1u;  // (benign race: every writer stores 1)
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int row = tid; row < tile_rows; row += 256) {
+        if (row_any[row] && t0 + row < n_seg) {
+            const int idx = atomicAdd(&seg_count[s], 1);
+            seg_list[(int64_t)s * n_seg + idx] = t0 + row;
+            ++mine;
+        }
+    }
+    // the batch's total (word [S] of the counts) tells the host how selective the level is on this input
+    if (mine) atomicAdd(&seg_count[gridDim.y], mine);
+}
+
 // ---------------------------------------------------------------------------
 // detection
 // ---------------------------------------------------------------------------
@@ -1165,7 +1329,7 @@ struct DetectArgs {
     const uint2 *hot;          // [S][kBuckets][hot_cap]
     const uint32_t *hot_count; // [S][kBuckets]
     uint32_t *hot_count_rw;    // same array, zeroed by its last reader
-    uint32_t *hot_seen;        // [S][kBuckets] copy of the counts for statistics
+    uint32_t *large_any;       // [S] a bucket of the stream has more than kSmallBucket cells (small instantiation -> large one; zeroed by finalize_records)
     int32_t *hot_total;        // [S] (host-visible) candidate cells per stream
     int32_t lds_cells;         // cells the large instantiation's LDS holds (power of two)
     int32_t cand_cap;          // plateaus a wave can stage per bucket (LDS)
@@ -1628,31 +1792,13 @@ __device__ __forceinline__ void sort_bucket_bitmap(const uint2 *src, int n, int 
 // rare bigger ones (up to hot_cap cells, dynamic LDS).  Both are launched; a
 // wave whose bucket belongs to the other instantiation exits at once.
 template <bool LARGE>
-__global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    // small: 4 waves = 4 buckets per workgroup; large: the 4 waves sort ONE bucket together in
-    // LDS, then wave 0 finishes it alone
-    // wave index made provably uniform; lane id from mbcnt (hipcc's value tracking on
-    // `threadIdx.x & 63` sends the unrolled register sort into a compile-time blow-up)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int sb = LARGE ? blockIdx.x : blockIdx.x * 4 + wave;
+__device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int sb, const int wave, const int lane, unsigned char *dyn_smem) {
     if (sb >= a.n_streams * kBuckets) return;
     const int s = sb / kBuckets, bkt = sb % kBuckets;
     const int F = a.n_bins;
     const int T = a.dp.n_seg;
-    const uint32_t n_raw = a.hot_count[sb];
-    if (LARGE) {
-        // last reader of the counter: keep the value for the statistics (finalize_records sums
-        // them per stream -- one atomic per bucket on a single word would serialise ~11 ns each)
-        // and leave the counter zero for the slot's next call -- after every wave of the
-        // workgroup has read it (they must all take the same exits below)
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            a.hot_seen[sb] = n_raw;
-            if (n_raw) a.hot_count_rw[sb] = 0u;
-        }
-    }
+    const uint32_t n_raw = a.hot_count[sb];  // (finalize_records, the call's last kernel, sums the counters per stream and leaves them zero)
+    if (!LARGE && lane == 0 && n_raw > (uint32_t)kSmallBucket && n_raw <= (uint32_t)a.hot_cap) a.large_any[s] = 1u;  // the large instantiation has work in this stream
     if (n_raw == 0) return;
     if (n_raw > (uint32_t)a.hot_cap) {
         if (!LARGE && lane == 0) {
@@ -1865,6 +2011,29 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     if (ncand) drain(ncand);
 }
 
+template <bool LARGE>
+__global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    // small: 4 waves = 4 buckets per workgroup; large: the 4 waves sort ONE bucket together in
+    // LDS, then wave 0 finishes it alone
+    // wave index made provably uniform; lane id from mbcnt (hipcc's value tracking on
+    // `threadIdx.x & 63` sends the unrolled register sort into a compile-time blow-up)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if constexpr (!LARGE) {
+        detect_bucket_one<false>(a, (int)blockIdx.x * 4 + wave, wave, lane, dyn_smem);
+    } else {
+        // one workgroup per STREAM; it walks the stream's 16 buckets only where the small instantiation has seen a
+        // large one.  (One workgroup per bucket, each reading its counter, keeping it for the statistics and zeroing it,
+        // cost 0.45 - 0.5 ms per call at 4 096 streams for doing almost nothing; that bookkeeping is finalize_records' now.)
+        if ((int)blockIdx.x >= a.n_streams || a.large_any[blockIdx.x] == 0u) return;  // (set by the small instantiation, which ran before)
+        for (int b = 0; b < kBuckets; ++b) {
+            detect_bucket_one<true>(a, (int)blockIdx.x * kBuckets + b, wave, lane, dyn_smem);
+            __syncthreads();  // the next bucket reuses the workgroup's LDS
+        }
+    }
+}
+
 // One workgroup per stream: order the stream's records by (fi, start), shadow verdicts, publish.
 // (rt::rank_and_shadow against tiles of 256 records in 16 KiB of static LDS: with room for `rec_cap` records -- 64 KiB at
 // the default -- two workgroups fit a CU, and a batch of thousands of streams with a dozen records each spent most of this
@@ -1887,9 +2056,15 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     __syncthreads();
     if (tid == 0) {
         if (n) a.raw_count[s] = 0;  // ready for the slot's next call
+        // last reader of the stream's candidate counters: their sum for the statistics, then zero for the slot's next call
         uint32_t tot = 0;
-        for (int b = 0; b < kBuckets; ++b) tot += a.hot_seen[s * kBuckets + b];
+        for (int b = 0; b < kBuckets; ++b) {
+            const uint32_t c = a.hot_count[s * kBuckets + b];
+            tot += c;
+            if (c) a.hot_count_rw[s * kBuckets + b] = 0u;
+        }
         a.hot_total[s] = (int32_t)tot;
+        a.large_any[s] = 0u;
         const unsigned long long v = atomicAdd(&a.counters[0], (unsigned long long)n | (1ull << kTicketShift));
         const unsigned long long mask = (1ull << kTicketShift) - 1ull;
         const long long base = (long long)(v & mask);

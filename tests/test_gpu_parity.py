@@ -1090,6 +1090,68 @@ def test_run_length_prefilter_equals_dense(threshold_dbw):
     assert len(w8) > n_streams and p8.fetch_records().tobytes() == w8.tobytes()
 
 
+@pytest.mark.parametrize("fs,nperseg,n_seg,floor_db", [
+    (300000, 256, 1171, -2.0), (300000, 256, 1171, 0.0), (300000, 256, 1171, 2.0),  # the reference's default geometry (__main__.py:48-64)
+    (2048000, 256, 1500, 0.0),    # config-2 geometry: plateaus need 63 cells
+    (2400000, 1024, 600, 0.0),    # a lane group = one wave
+    (3200000, 4096, 200, 0.0),    # a lane group = four waves
+])
+def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
+    """RT_MODE_RUNFILTER: threshold bits of every cell, cells of threshold runs of at least the minimum plateau length (or
+    through t = 0) plus the cell before each, a second scan over the segments that hold such cells.  Noise floor 2 dB
+    under, at and 2 dB over the reference's -90 dBW threshold (20 .. 53 % of all cells pass it; the plain sparse path
+    overflows): records byte-identical to the dense path over two buffers, look-back and runs from t = 0 included, one and
+    two lanes; where the chunk-bit pre-filter does not exist (300 kS/s: 8 ms = 9.4 hops) AUTO gets there by itself."""
+    _need_gpu()
+    blen, n_streams = nperseg * n_seg + 24, 6
+    thr_dbw = -90.0
+    sigma = float(np.sqrt(10.0 ** ((thr_dbw + floor_db) / 10.0) * fs / 2.0))  # PSD per bin = 2 sigma^2 / fs
+    iq = _noisy_batch(n_streams, blen, fs, nperseg, seed=int(fs // 1000 + nperseg + floor_db), noise_sigma=sigma,
+                      peak_dbw=(thr_dbw + floor_db + 20.0, thr_dbw + floor_db + 34.0))
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, signal_threshold_dbw=thr_dbw)
+    default_geometry = fs == 300000
+    # (default geometry: chunks of 32 segments, as a batch large enough to fill the chip gets -- the chunk-bit pre-filter
+    # then needs a minimum duration of 63 hops; a batch of six streams would otherwise get chunks of 4 and AUTO would use
+    # that one.  Every handle the same chunk length: it sets the order in which a row's partial sums are added.)
+    extra = dict(segs_per_chunk=32) if default_geometry else {}
+    dense = _batch_for(kw, n_streams, blen, "dense", **extra)
+    run = _batch_for(kw, n_streams, blen, "runfilter", **extra)
+    run2 = _batch_for(kw, n_streams, blen, "runfilter", lanes=2, **extra)
+    auto = _batch_for(kw, n_streams, blen, "auto", **extra) if default_geometry else None
+    n_neg = n_zero = 0
+    for k in range(2):
+        chunk = np.ascontiguousarray(iq[:, k])
+        for b in (dense, run, run2, auto):
+            if b is not None:
+                b.enqueue(chunk)
+        want = dense.fetch_records()
+        got = run.fetch_records()
+        assert run.native.call_info().mode_used == _native.RT_MODE_RUNFILTER
+        assert len(want) > n_streams and got.tobytes() == want.tobytes(), (fs, nperseg, floor_db, k, len(got), len(want))
+        assert run2.fetch_records().tobytes() == want.tobytes()
+        if auto is not None:
+            got_a = auto.fetch_records()
+            info = auto.native.call_info()
+            assert got_a.tobytes() == want.tobytes()
+            # first buffer: the sparse attempt overflows and is finished on this level; the handle then stays -- unless more
+            # than half of all segments held cells to keep (floor 2 dB over the threshold): then the dense path is faster
+            # and the handle goes there for the next buffers
+            stays = floor_db < 2.0
+            assert info.mode_used == (_native.RT_MODE_RUNFILTER if (k == 0 or stays) else _native.RT_MODE_DENSE), (k, info.mode_used)
+            assert info.fell_back == (1 if k == 0 else 0), (k, info.fell_back)
+        n_neg += int((want["start"] < 0).sum())
+        n_zero += int((want["start"] == 0).sum())
+    assert n_neg > 0 and n_zero > 0, (n_neg, n_zero)
+    if default_geometry:
+        # the same streams as the RTL-SDR wire format
+        raw = synth.quantize_u8(iq[:, 0], gain=20.0)
+        kw8 = dict(kw, signal_threshold_dbw=thr_dbw + 26.0)  # the gain of 20 is 26 dB
+        d8, r8 = _batch_for(kw8, n_streams, blen, "dense", **extra), _batch_for(kw8, n_streams, blen, "runfilter", **extra)
+        d8.enqueue_bytes(raw); r8.enqueue_bytes(raw)
+        w8 = d8.fetch_records()
+        assert len(w8) > n_streams and r8.fetch_records().tobytes() == w8.tobytes()
+
+
 @pytest.mark.parametrize("lanes", [1, 2])
 def test_a_few_noisy_streams_go_dense_on_their_own(lanes):
     """One or two SDRs of a batch with their noise floor over the threshold: their candidate lists overflow, the others'
