@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--window", default=None)
     ap.add_argument("--mode", default="auto", choices=["auto", "dense", "sparse", "prefilter", "runfilter"])
     ap.add_argument("--segs-per-chunk", type=int, default=0)
+    ap.add_argument("--hot-capacity", type=int, default=0,
+                    help="candidate cells kept per (stream, bin mod 16 bucket) and call (rt_config.hot_capacity; 0 = default: one bin row "
+                         "times max(1, nperseg / 1024), at most 8192; up to 16384 fits the detection's LDS sort)")
     ap.add_argument("--input", default="c64", choices=["c64", "u8"],
                     help="IQ representation in HBM: complex64 (the BASELINE workload) or the RTL-SDR wire format "
                          "(interleaved uint8, converted inside the scan kernel; SURVEY 8(f) rank 1)")
@@ -283,6 +286,7 @@ def main():
             mode=args.mode,
             timing=True,
             segs_per_chunk=args.segs_per_chunk,
+            hot_capacity=args.hot_capacity,
             hip_stream=stream.cuda_stream if lanes <= 1 else None,
             lanes=lanes,
             **kw,
@@ -354,7 +358,7 @@ def main():
     bytes_per_launch = samples_per_step_rank * bytes_per_sample // lanes
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
-    default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw, args.noise_dbw) == ("config2", 256, 0, "auto", "c64", None, None)
+    default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw, args.noise_dbw, args.hot_capacity) == ("config2", 256, 0, "auto", "c64", None, None, 0)
     n_dense_streams = int(info.n_dense_streams)
     traffic, traffic_note = pmc_traffic(default_workload, 1)  # per launch over all 256 streams, like kernel_ms
 
@@ -455,6 +459,7 @@ def main():
             "noisy_streams_per_gpu": args.noisy_streams or (S if args.noise_dbw is not None else 0),
             "streams_rerun_dense_rank0": n_dense_streams,
             "threshold_dbw": kw.get("signal_threshold_dbw", -90.0),
+            "hot_capacity": args.hot_capacity or "default",
             "devices": devices,
         },
         "roofline": roofline,

@@ -1412,8 +1412,14 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
     auto rank = [](int mode) { return mode == RT_MODE_SPARSE ? 0 : (mode == RT_MODE_PREFILTER || mode == RT_MODE_RUNFILTER) ? 1 : 2; };
     // (the exact pre-filter on input where it is not selective: see below)
-    const bool unselective = h->cfg.mode == RT_MODE_AUTO && c.mode_used == RT_MODE_RUNFILTER && !c.is_extract && c.n_seg > 0 && sl.h_seg_total &&
-                             (int64_t)*sl.h_seg_total * 2 > (int64_t)h->cfg.n_streams * c.n_seg;
+    bool unselective = h->cfg.mode == RT_MODE_AUTO && c.mode_used == RT_MODE_RUNFILTER && !c.is_extract && c.n_seg > 0 && sl.h_seg_total &&
+                       (int64_t)*sl.h_seg_total * 2 > (int64_t)h->cfg.n_streams * c.n_seg;
+    // ... or a pre-filter level that went through with more than 1/32 of all cells on its candidate lists (possible where
+    // hot_capacity was raised: signals whose side lobes fill every bin put 9 % of the cells there, and ordering lists of
+    // 16 k cells per bucket took 14 - 18 ms per call where the dense path takes 1.9)
+    if (h->cfg.mode == RT_MODE_AUTO && (c.mode_used == RT_MODE_RUNFILTER || c.mode_used == RT_MODE_PREFILTER) && !c.is_extract && c.n_seg > 0 &&
+        h->info.n_hot * 32 > (int64_t)h->cfg.n_streams * c.n_seg * h->N)
+        unselective = true;
     if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && rank(c.mode_used) < rank(h->auto_level) && !unselective) {
         // a probe of a lower level went through: the handle moves there (and from the pre-filter level it will
         // probe the plain sparse path after the usual interval)
@@ -1422,7 +1428,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         h->dense_sticky = (c.mode_used == RT_MODE_SPARSE) ? 0 : 16;
     }
     if (unselective) {
-        // The exact pre-filter went through, but more than half of all segments held cells it has to keep: its second scan
+        // The pre-filter went through, but more than half of all segments held cells it has to keep (or see above): its second scan
         // is then most of a scan, and the dense path (one scan, 16 B per sample) is faster -- measured at the reference's
         // default geometry with the noise floor 2 dB over the threshold: 213 k against 241 k MS/s.  The handle moves up like
         // after an overflow (without analysing this call again: its result stands) and probes this level later.
