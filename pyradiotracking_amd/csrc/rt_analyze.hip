@@ -71,6 +71,7 @@ struct Slot {
     float *d_psum = nullptr;
     uint16_t *d_full = nullptr;       // [S][max_chunks][LG] chunk bits of the run-length pre-filter, then [S][L][LG] bits of chunk 0 by segment (null: not available)
     uint16_t *d_cell_hot = nullptr, *d_cell_need = nullptr;  // [S][max_seg][LG] threshold bits of every cell / the cells to emit (RT_MODE_RUNFILTER)
+    uint32_t *d_chunk_min = nullptr;  // [S][N] float bits: per bin the smallest complete-chunk sum of this slot's latest call (StftParams::chunk_min)
     int32_t *d_seg_list = nullptr;    // [S][max_seg] segments holding such cells, then [S] their number per stream and [1] the batch's total
     int32_t *h_seg_total = nullptr;   // pinned: that total, copied behind plan_runs
     rt_record *d_raw = nullptr;
@@ -133,6 +134,8 @@ struct rt_handle {
     // calls before it probes the level below again (a failed probe costs a wasted scan: the interval doubles, 16 .. 1024).
     bool prefilter_ok = false;
     bool runfilter_ok = false;  // RT_MODE_RUNFILTER is possible and its scratch is allocated
+    float *d_thr_bin = nullptr, *d_thr_nat = nullptr;  // [S][N] per-bin thresholds of the exact pre-filter, lane order / bin order (make_bin_thresholds)
+    int minsum_slot = -1;       // the slot whose d_chunk_min holds the latest call's chunk minima (-1: none yet)
     int run_cells = 1;          // r: cells a plateau needs unless it runs through t = 0 (plan_runs)
     int plan_tile = 0;          // rows per planning tile
     int auto_level = RT_MODE_SPARSE;
@@ -304,6 +307,8 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.first = sl.d_full ? sl.d_full + (size_t)h->cfg.n_streams * h->max_chunks * h->LG : nullptr;
     p.item_chunks = sl.d_items;
     p.item_count = sl.d_items ? sl.d_items + (size_t)h->cfg.n_streams * h->max_blocks * h->GPW : nullptr;
+    p.chunk_min = sl.d_chunk_min;
+    p.thr_bin = nullptr;
     p.cell_hot = sl.d_cell_hot;
     p.cell_need = sl.d_cell_need;
     p.seg_list = sl.d_seg_list;
@@ -415,11 +420,37 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     }
     if (!second_pass_only) RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
     if (launched) *launched = true;
+    const int slot_index = (int)(&sl - h->slot);
+    if (mode == RT_MODE_RUNFILTER) {
+        // per-bin thresholds from the latest chunk minima (the previous call's; on a re-run this call's own), before they are reset
+        const int64_t cells = (int64_t)S * h->N;
+        if (h->minsum_slot < 0) {
+            // the handle's very first call: no chunk minima yet.  A scan of this buffer provides them (its bits, taken with
+            // the absolute threshold alone, are overwritten by the scan proper below) -- once per handle.
+            RT_HIP(h, hipMemsetAsync(sl.d_chunk_min, 0x7f, (size_t)S * h->N * sizeof(uint32_t), h->s_scan));
+            launch_scan<6>(h, sp, blocks, c.u8);
+            h->minsum_slot = slot_index;
+        }
+        const uint32_t *prev = h->slot[h->minsum_slot].d_chunk_min;
+        hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, prev, h->d_thr_bin, h->d_thr_nat, S, h->R3,
+                           h->L, h->cfg.snr_threshold);
+    }
+    if (sl.d_chunk_min && !second_pass_only) {
+        RT_HIP(h, hipMemsetAsync(sl.d_chunk_min, 0x7f, (size_t)S * h->N * sizeof(uint32_t), h->s_scan));
+        h->minsum_slot = slot_index;
+    }
     if (dense) {
         launch_scan<1>(h, sp, blocks, c.u8);
     } else if (mode == RT_MODE_RUNFILTER) {
         // threshold bits of every cell (+ row sums, tail) -> cells of runs long enough -> only their segments again
+        sp.thr_bin = h->d_thr_bin;
         launch_scan<6>(h, sp, blocks, c.u8);
+        sp.thr_bin = nullptr;
+        {
+            const int64_t cells = (int64_t)S * h->N;
+            hipLaunchKernelGGL(check_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, h->d_thr_nat, sl.d_psum, S, h->N,
+                               sp.blocks_per_stream, c.n_seg, h->cfg.snr_threshold, sl.h_overflow, sl.d_counters, kFlagHotOverflow);
+        }
         RT_HIP(h, hipMemsetAsync(const_cast<int32_t *>(sp.seg_count), 0, ((size_t)S + 1) * sizeof(int32_t), h->s_scan));
         const int tiles = (c.n_seg + h->plan_tile - 1) / h->plan_tile;
         hipLaunchKernelGGL(plan_runs, dim3(tiles, S), dim3(256), 0, h->s_scan, sp.cell_hot, sl.d_cell_need,
@@ -695,6 +726,8 @@ void rt_destroy(rt_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_work);
+    (void)hipFree(h->d_thr_bin);
+    (void)hipFree(h->d_thr_nat);
     (void)hipFree(h->d_window);
     (void)hipFree(h->d_window_t);
     (void)hipFree(h->d_tw1);
@@ -715,6 +748,7 @@ void rt_destroy(rt_handle *h) {
         (void)hipFree(sl.d_full);
         (void)hipFree(sl.d_cell_hot);
         (void)hipFree(sl.d_cell_need);
+        (void)hipFree(sl.d_chunk_min);
         (void)hipFree(sl.d_seg_list);
         (void)hipHostFree(sl.h_seg_total);
         (void)hipFree(sl.d_raw);
@@ -961,6 +995,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             const size_t cells = (size_t)S * std::max(h->max_seg, 1) * LG;
             RT_CREATE_HIP(hipMalloc(&sl.d_cell_hot, cells * sizeof(uint16_t)));
             RT_CREATE_HIP(hipMalloc(&sl.d_cell_need, cells * sizeof(uint16_t)));
+            RT_CREATE_HIP(hipMalloc(&sl.d_chunk_min, (size_t)S * N * sizeof(uint32_t)));
+            RT_CREATE_HIP(hipMemset(sl.d_chunk_min, 0x7f, (size_t)S * N * sizeof(uint32_t)));
             RT_CREATE_HIP(hipMalloc(&sl.d_seg_list, ((size_t)S * std::max(h->max_seg, 1) + S + 1) * sizeof(int32_t)));
             RT_CREATE_HIP(hipHostMalloc(&sl.h_seg_total, sizeof(int32_t)));
             *sl.h_seg_total = 0;
@@ -994,6 +1030,10 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipEventCreate(&sl.ev_done));
     }
 
+    if (h->runfilter_ok) {
+        RT_CREATE_HIP(hipMalloc(&h->d_thr_bin, (size_t)S * N * sizeof(float)));
+        RT_CREATE_HIP(hipMalloc(&h->d_thr_nat, (size_t)S * N * sizeof(float)));
+    }
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),

@@ -81,6 +81,9 @@ struct StftParams {
     const uint16_t *cell_need;  // [S][T][LG] the cells the selective pass emits (plan_runs writes, MODE 7 reads)
     const int32_t *seg_list; // [S][T] the segments that hold such cells, in any order; seg_count[s] of them
     const int32_t *seg_count;
+    uint32_t *chunk_min;     // [S][N] float bits, or null: per bin the smallest sum of P over a complete chunk of this call (atomicMin;
+                             // the host presets 0x7f7f7f7f) -- the quiet level of the bin, for the next call's thr_bin (make_bin_thresholds)
+    const float *thr_bin;    // MODE 6, or null: [S][LG][16] a second, per-bin threshold in lane order; a cell's bit is set only if it passes both
 #ifdef RT_STAMPS
     uint32_t *dbg;           // [workgroups][4 waves][kStamps] cycles per stage, [kStamps - 1] = steps taken
 #endif
@@ -999,7 +1002,23 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                     if (active && !halo) {  // (lane index opaque: the address stays out of the loop's registers)
                         int lt_b = lt;
                         asm volatile("" : "+v"(lt_b));
-                        p.cell_hot[((int64_t)s * T + seg) * LG + lt_b] = (uint16_t)hot;
+                        uint32_t bits = hot;
+                        if (p.thr_bin && bits) {
+                            // the bin's own second threshold (a lower bound of snr * row mean, see make_bin_thresholds):
+                            // only cells that pass it too can be part of a plateau.  Sixteen floats per lane from L2.
+                            const float4 *tb = reinterpret_cast<const float4 *>(p.thr_bin + ((int64_t)s * LG + lt_b) * 16);
+                            uint32_t ok = 0;
+#pragma unroll
+                            for (int q = 3; q >= 0; --q) {
+                                const float4 t4 = tb[q];
+                                ok = (ok << 1) | ((P[4 * q + 3] < t4.w) ? 0u : 1u);
+                                ok = (ok << 1) | ((P[4 * q + 2] < t4.z) ? 0u : 1u);
+                                ok = (ok << 1) | ((P[4 * q + 1] < t4.y) ? 0u : 1u);
+                                ok = (ok << 1) | ((P[4 * q + 0] < t4.x) ? 0u : 1u);
+                            }
+                            bits &= ok;
+                        }
+                        p.cell_hot[((int64_t)s * T + seg) * LG + lt_b] = (uint16_t)bits;
                     }
                 }
                 if (active && !halo) {
@@ -1121,6 +1140,16 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
             for (int gg = 0; gg < GPW; ++gg) sum += part[gg * N + bin];
             dst[bin] = sum;
+            if (p.chunk_min) {
+                // the quietest complete chunk of the bin so far (positive floats order like their bits)
+                float mn = 3.0e38f;
+#pragma unroll
+                for (int gg = 0; gg < GPW; ++gg) {
+                    const int ch = cb * GPW + gg;
+                    if (ch < p.chunks && (ch + 1) * L <= T) mn = fminf(mn, part[gg * N + bin]);
+                }
+                if (mn < 3.0e38f) atomicMin(&p.chunk_min[(int64_t)s * N + bin], __float_as_uint(mn));
+            }
         }
     }
     if constexpr (!PERSIST) break;
@@ -1311,6 +1340,59 @@ __global__ __launch_bounds__(256) void plan_runs(const uint16_t *hot, uint16_t *
     }
     // the batch's total (word [S] of the counts) tells the host how selective the level is on this input
     if (mine) atomicAdd(&seg_count[gridDim.y], mine);
+}
+
+// bin of result register r in lane lt of a group, R3 at run time (bin_of<R3>)
+__device__ __forceinline__ int bin_of_rt(int R3, int lt, int r) {
+    if (R3 == 1) return lt + 16 * r;
+    const int G = 16 / R3;
+    const int k1 = lt / R3, qg = lt % R3;
+    const int u = (r / R3 - ((k1 * R3 / 8) & (G - 1))) & (G - 1), q2 = r % R3;
+    return k1 + 16 * (qg * G + u) + 256 * q2;
+}
+
+// Per-bin thresholds for the exact pre-filter's bits (MODE 6), from the PREVIOUS call's chunk minima.  The reference's
+// predicate is `!(P < thr) && !(P / row_mean < snr)` (analyze.py:370, 378); with the noise floor over the absolute
+// threshold the first test says nothing and the second decides -- but the row mean of a buffer is known only after its
+// scan.  The quietest complete chunk of the previous buffer gives a lower bound that survives tags coming and going
+// (a pulse sits in one or two chunks of dozens): theta = snr * (smallest chunk sum / L) is about 0.55 * snr * (noise mean)
+// for stationary noise.  A cell passes the full predicate only if it passes `P >= theta` -- PROVIDED theta <= snr * (this
+// buffer's row mean), which check_bin_thresholds verifies after the scan; a stream that fails it (its floor dropped by
+// more than ~2.5 dB from one buffer to the next) is analysed again on the dense path.  No estimate (first call, buffers
+// shorter than a chunk): theta = 0, the bits are the absolute threshold's alone.
+__global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk_min_prev, float *thr_bin /* lane order */, float *thr_nat /* [S][N] */,
+                                                          int n_streams, int R3, int L, float snr) {
+    const int N = 256 * R3, LG = 16 * R3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [S][LG][16]
+    if (i >= (int64_t)n_streams * N) return;
+    const int s = (int)(i / N), lt = (int)(i % N) / 16, r = (int)(i % 16);
+    const int bin = bin_of_rt(R3, lt, r);
+    float th = 0.f;
+    if (chunk_min_prev) {
+        const float mn = __uint_as_float(chunk_min_prev[(int64_t)s * N + bin]);
+        if (mn < 1.0e38f && mn == mn) th = snr * (mn / (float)L);
+    }
+    thr_bin[i] = th;
+    thr_nat[(int64_t)s * N + bin] = th;
+}
+
+// ... and the check behind the scan: theta <= snr * row_mean * (1 - 1e-6) for every bin of every stream (the row mean as
+// the detection computes it, from the same partial sums).  A stream that fails is marked like one whose candidate lists
+// overflowed: rt_fetch re-runs it dense (a few streams) or takes the batch one level up.
+__global__ __launch_bounds__(256) void check_bin_thresholds(const float *thr_nat, const float *psum, int n_streams, int N, int items_per_stream, int n_seg,
+                                                           float snr, int32_t *stream_overflow, unsigned long long *counters, unsigned long long flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n_streams * N) return;
+    const float th = thr_nat[i];
+    if (!(th > 0.f)) return;
+    const int s = (int)(i / N), bin = (int)(i % N);
+    double sum = 0.0;
+    for (int c = 0; c < items_per_stream; ++c) sum += (double)psum[((int64_t)s * items_per_stream + c) * N + bin];
+    const float avg = (float)sum / (float)n_seg;
+    if (!(th <= snr * avg * (1.0f - 1.0e-6f))) {
+        stream_overflow[s] = 1;
+        atomicOr(counters + 2, flag);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -43,7 +43,7 @@ while time.time() < t_end:
     thr = float(rng.choice([-90.0, -85.0, -100.0]))
     snr = float(rng.choice([5.0, 0.0, 8.0]))
     cal = [float(c) for c in rng.uniform(-6, 6, n_streams)] if rng.random() < 0.5 else 0.0
-    mode = str(rng.choice(["sparse", "dense", "auto", "auto", "prefilter"]))  # prefilter: refused where the minimum duration is too short
+    mode = str(rng.choice(["sparse", "dense", "auto", "auto", "prefilter", "runfilter"]))  # prefilter: refused where the minimum duration is too short; runfilter: where it does not fit the planning tiles
     subtract_first = bool(rng.random() < 0.3)  # SciPy's order of the constant detrend instead of the linearity form
     # round 2: a quarter of the cases with the noise floor around the absolute threshold (8 dB under .. 2 dB over): the
     # sparse path overflows, AUTO climbs to the run-length pre-filter or the dense path; decisions then sit on the noise

@@ -1091,7 +1091,7 @@ def test_run_length_prefilter_equals_dense(threshold_dbw):
 
 
 @pytest.mark.parametrize("fs,nperseg,n_seg,floor_db", [
-    (300000, 256, 1171, -2.0), (300000, 256, 1171, 0.0), (300000, 256, 1171, 2.0),  # the reference's default geometry (__main__.py:48-64)
+    (300000, 256, 1171, -2.0), (300000, 256, 1171, 0.0), (300000, 256, 1171, 2.0), (300000, 256, 1171, 4.0),  # the reference's default geometry (__main__.py:48-64)
     (2048000, 256, 1500, 0.0),    # config-2 geometry: plateaus need 63 cells
     (2400000, 1024, 600, 0.0),    # a lane group = one wave
     (3200000, 4096, 200, 0.0),    # a lane group = four waves
@@ -1101,7 +1101,9 @@ def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
     through t = 0) plus the cell before each, a second scan over the segments that hold such cells.  Noise floor 2 dB
     under, at and 2 dB over the reference's -90 dBW threshold (20 .. 53 % of all cells pass it; the plain sparse path
     overflows): records byte-identical to the dense path over two buffers, look-back and runs from t = 0 included, one and
-    two lanes; where the chunk-bit pre-filter does not exist (300 kS/s: 8 ms = 9.4 hops) AUTO gets there by itself."""
+    two lanes; where the chunk-bit pre-filter does not exist (300 kS/s: 8 ms = 9.4 hops) AUTO gets there by itself.  With
+    the floor 2 and 4 dB OVER the threshold (53 % / 67 % of the cells pass it) the absolute threshold says nothing: the bits
+    then come from per-bin thresholds below snr * row mean (make_bin_thresholds), checked against the row means after the scan."""
     _need_gpu()
     blen, n_streams = nperseg * n_seg + 24, 6
     thr_dbw = -90.0
@@ -1133,12 +1135,10 @@ def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
             got_a = auto.fetch_records()
             info = auto.native.call_info()
             assert got_a.tobytes() == want.tobytes()
-            # first buffer: the sparse attempt overflows and is finished on this level; the handle then stays -- unless more
-            # than half of all segments held cells to keep (floor 2 dB over the threshold): then the dense path is faster
-            # and the handle goes there for the next buffers
-            stays = floor_db < 2.0
-            assert info.mode_used == (_native.RT_MODE_RUNFILTER if (k == 0 or stays) else _native.RT_MODE_DENSE), (k, info.mode_used)
-            assert info.fell_back == (1 if k == 0 else 0), (k, info.fell_back)
+            # first buffer: the sparse attempt overflows and is finished on this level; the handle then stays -- also with
+            # the floor OVER the absolute threshold, where the bits come from the per-bin thresholds (snr * the quietest chunk of
+            # the buffer before, for the first buffer of the sparse attempt that has just overflowed)
+            assert info.mode_used == _native.RT_MODE_RUNFILTER and info.fell_back == (1 if k == 0 else 0), (k, info.mode_used, info.fell_back)
         n_neg += int((want["start"] < 0).sum())
         n_zero += int((want["start"] == 0).sum())
     assert n_neg > 0 and n_zero > 0, (n_neg, n_zero)
