@@ -1152,6 +1152,36 @@ def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
         assert len(w8) > n_streams and r8.fetch_records().tobytes() == w8.tobytes()
 
 
+def test_exact_prefilter_survives_a_noise_floor_that_drops():
+    """The per-bin thresholds of the exact pre-filter come from the buffer before (snr * its quietest chunk).  They are
+    only valid while they stay below snr * this buffer's row mean -- check_bin_thresholds verifies that behind the scan.
+    Here the noise of two SDRs of twelve falls by 6 dB from one buffer to the next: their thresholds are too high for the
+    second buffer, the check marks exactly those two, and they are analysed again on the dense path while the others
+    stand -- every record of both buffers byte-identical to the dense path."""
+    _need_gpu()
+    fs, nperseg, n_seg, n_streams = 300000, 256, 1171, 12
+    blen = nperseg * n_seg + 24
+    thr_dbw, floor_db = -90.0, 2.0
+    sigma = float(np.sqrt(10.0 ** ((thr_dbw + floor_db) / 10.0) * fs / 2.0))
+    iq = _noisy_batch(n_streams, blen, fs, nperseg, seed=77, noise_sigma=sigma, peak_dbw=(thr_dbw + floor_db + 20.0, thr_dbw + floor_db + 34.0))
+    quiet = _noisy_batch(n_streams, blen, fs, nperseg, seed=77, noise_sigma=sigma / 2.0, peak_dbw=(thr_dbw + floor_db + 20.0, thr_dbw + floor_db + 34.0))
+    bufs = [np.ascontiguousarray(iq[:, 0]), np.ascontiguousarray(iq[:, 1])]
+    for s in (2, 9):
+        bufs[1][s] = quiet[s, 1]  # the same pulses over half the noise amplitude
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, signal_threshold_dbw=thr_dbw, segs_per_chunk=32)
+    dense = _batch_for(kw, n_streams, blen, "dense")
+    auto = _batch_for(kw, n_streams, blen, "auto")
+    for k, chunk in enumerate(bufs):
+        dense.enqueue(chunk)
+        auto.enqueue(chunk)
+        want = dense.fetch_records()
+        got = auto.fetch_records()
+        info = auto.native.call_info()
+        assert len(want) > n_streams and got.tobytes() == want.tobytes(), k
+        assert info.mode_used == _native.RT_MODE_RUNFILTER, (k, info.mode_used)
+        assert info.n_dense_streams == (0 if k == 0 else 2), (k, info.n_dense_streams)
+
+
 @pytest.mark.parametrize("lanes", [1, 2])
 def test_a_few_noisy_streams_go_dense_on_their_own(lanes):
     """One or two SDRs of a batch with their noise floor over the threshold: their candidate lists overflow, the others'

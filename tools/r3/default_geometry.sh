@@ -6,7 +6,7 @@ out=gpurun_out/${1:-r3dg}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 common="--sample-rate 300000 --streams 4096 --steps 20 --warmup 5 --settle 20 --isolated-steps 0 --cpu-streams 64"
 for floor in -92 -90 -88 -86; do
-  for mode in auto dense; do
+  for mode in auto runfilter dense; do
     timeout -k 10 300 python bench.py $common --noise-dbw $floor --mode $mode 2>>$out/err.txt | tail -1 >> $out/floors.jsonl || exit 1
   done
 done
