@@ -1190,6 +1190,9 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
                 --h->dense_sticky;
             } else {
                 c.mode_used = level_down(h, h->auto_level);
+                // one probe at a time: the calls enqueued before this one's verdict is in (the caller may keep a slot's
+                // worth of calls in flight) stay on the handle's level instead of each paying for a failed probe
+                if (c.mode_used != h->auto_level) h->dense_sticky = kSlots;
             }
         }
         if (T == 0) {

@@ -1007,6 +1007,23 @@ def test_sparse_overflow_falls_back_to_dense():
         if fresh.native.call_info().fell_back:
             probes.append(k)
     assert probes == [0, 17, 50]
+    # two calls in flight (the next one enqueued before the last one's verdict is in): still ONE failed probe per
+    # interval -- the call enqueued behind a probe stays on the handle's level
+    piped = _batch_for(kwargs, 1, blen, "auto", hot_capacity=64)
+    ref = _batch_for(kwargs, 1, blen, "dense")
+    n = 1 + 1 + 1 + 32 + 1 + 4
+    probes = []
+    piped.enqueue(buffers[0].reshape(1, -1))
+    for k in range(n):
+        if k + 1 < n:
+            piped.enqueue(buffers[0].reshape(1, -1))
+        ref.enqueue(buffers[0].reshape(1, -1))
+        assert piped.fetch_records().tobytes() == ref.fetch_records().tobytes()
+        if piped.native.call_info().fell_back:
+            probes.append(k)
+    # calls 0 and 1 were both enqueued on the sparse path before anything was known (two doublings: 32 calls from call 3 on;
+    # call 2 was enqueued on the upper level before call 1's verdict)
+    assert probes == [0, 1, 35]
 
 
 def test_dense_input_everything_above_threshold():
