@@ -8,12 +8,28 @@
 
 namespace rt {
 
+// Experiment switch RT_PACKED: a complex value as a two-element vector in an aligned VGPR pair, so that the transform's
+// complex additions are one v_pk_add_f32 each and its quarter turns one v_pk_fma_f32 with a constant pair -- the same
+// IEEE operations in the same order as the scalar form (bit-identical spectra), in about half the instructions.
+#ifndef RT_PACKED
+#define RT_PACKED 0
+#endif
+#if RT_PACKED
+typedef float cf __attribute__((ext_vector_type(2)));
+#define RT_FMA2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+#else
 struct cf {
     float x, y;
 };
+#endif
 
+#if RT_PACKED
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+#else
 __device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+#endif
 // Contraction is spelled out (the library is built with -ffp-contract=off) so
 // every instantiation of the scan kernel computes bit-identical spectra.
 __device__ __forceinline__ cf cmul(cf a, cf b) {
@@ -21,17 +37,45 @@ __device__ __forceinline__ cf cmul(cf a, cf b) {
 }
 // multiply by -i  (forward-transform quarter turn): (x + iy)(-i) = y - ix
 __device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
+#if RT_PACKED
+__device__ __forceinline__ cf cscale(cf a, float s) { return a * s; }
+__device__ __forceinline__ cf cneg(cf a) { return -a; }
+// a * w for a compile-time w: the partner pair (-w.y, w.x) is a constant too, so the product is two packed operations
+// (a.y * -w.y == -(a.y * w.y) exactly: the same roundings as cmul)
+__device__ __forceinline__ cf cmul_const(cf a, float wx, float wy) {
+    const cf t = a.yy * cf{-wy, wx};
+    return RT_FMA2(a.xx, (cf{wx, wy}), t);
+}
+// b + c (-i) a without forming (-i) a:  (b.x + c a.y, b.y - c a.x) -- one packed fused multiply-add on the swapped pair
+// (c = +-1: the plain sums, exactly)
+template <int SIGN>
+__device__ __forceinline__ cf fma_mi(cf b, cf a, float c) { return RT_FMA2(a.yx, (cf{SIGN * c, -SIGN * c}), b); }
+__device__ __forceinline__ cf add_mi(cf b, cf a) { return fma_mi<1>(b, a, 1.f); }
+__device__ __forceinline__ cf sub_mi(cf b, cf a) { return fma_mi<-1>(b, a, 1.f); }
+// b + c a
+__device__ __forceinline__ cf fma_s(cf b, cf a, float c) { return RT_FMA2(a, (cf{c, c}), b); }
+#else
 __device__ __forceinline__ cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
 __device__ __forceinline__ cf cneg(cf a) { return cf{-a.x, -a.y}; }
+__device__ __forceinline__ cf cmul_const(cf a, float wx, float wy) { return cmul(a, cf{wx, wy}); }
+__device__ __forceinline__ cf add_mi(cf b, cf a) { return cadd(b, mul_mi(a)); }
+__device__ __forceinline__ cf sub_mi(cf b, cf a) { return csub(b, mul_mi(a)); }
+template <int SIGN>
+__device__ __forceinline__ cf fma_mi(cf b, cf a, float c) {
+    const cf r = mul_mi(a);
+    return cf{__builtin_fmaf(r.x, SIGN * c, b.x), __builtin_fmaf(r.y, SIGN * c, b.y)};
+}
+__device__ __forceinline__ cf fma_s(cf b, cf a, float c) { return cf{__builtin_fmaf(a.x, c, b.x), __builtin_fmaf(a.y, c, b.y)}; }
+#endif
 
 // 4-point DFT in place, natural order out.
 __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3) {
     cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
-    cf s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    cf s13 = cadd(a1, a3), e13 = csub(a1, a3);
     a0 = cadd(s02, s13);
     a2 = csub(s02, s13);
-    a1 = cadd(d02, d13);
-    a3 = csub(d02, d13);
+    a1 = add_mi(d02, e13);
+    a3 = sub_mi(d02, e13);
 }
 
 __device__ __forceinline__ void dft2(cf &a0, cf &a1) {
@@ -46,8 +90,11 @@ __device__ __forceinline__ void dft2(cf &a0, cf &a1) {
 
 // multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
 // (a + (-i)a) = (x + y, y - x);  ((-i)a - a) = (y - x, -(x + y)) -- the same sums, then one scale
-__device__ __forceinline__ cf mul_w8_1(cf a) { return cscale(cadd(a, mul_mi(a)), RT_SQRT1_2); }
-__device__ __forceinline__ cf mul_w8_3(cf a) { return cscale(csub(mul_mi(a), a), RT_SQRT1_2); }
+// rotations by W8^1 and W8^3 without their factor 1/sqrt2
+__device__ __forceinline__ cf rot_w8_1(cf a) { return add_mi(a, a); }          // (x + y, y - x)
+__device__ __forceinline__ cf rot_w8_3(cf a) { return add_mi(cneg(a), a); }    // (y - x, -(x + y))
+__device__ __forceinline__ cf mul_w8_1(cf a) { return cscale(rot_w8_1(a), RT_SQRT1_2); }
+__device__ __forceinline__ cf mul_w8_3(cf a) { return cscale(rot_w8_3(a), RT_SQRT1_2); }
 
 // 8-point DFT, natural order in and out:  n = n0 + 2*n1, k = ka + 4*kb
 // (4-point DFTs over n1 for each n0, twiddle W8^(n0*ka), 2-point over n0).
@@ -55,53 +102,42 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
     dft4(v[0], v[2], v[4], v[6]);  // n0 = 0 : Z0[ka] in v[0], v[2], v[4], v[6]
     dft4(v[1], v[3], v[5], v[7]);  // n0 = 1 : Z1[ka]
     v[3] = mul_w8_1(v[3]);         // ka = 1
-    v[5] = mul_mi(v[5]);           // ka = 2 : W8^2 = -i
-    v[7] = mul_w8_3(v[7]);         // ka = 3
+    v[7] = mul_w8_3(v[7]);         // ka = 3  (ka = 2: W8^2 = -i, folded into y2 / y6)
     // Y[ka + 4*kb] = Z0[ka] + (-1)^kb Z1[ka]
     cf y0 = cadd(v[0], v[1]), y4 = csub(v[0], v[1]);
     cf y1 = cadd(v[2], v[3]), y5 = csub(v[2], v[3]);
-    cf y2 = cadd(v[4], v[5]), y6 = csub(v[4], v[5]);
+    cf y2 = add_mi(v[4], v[5]), y6 = sub_mi(v[4], v[5]);
     cf y3 = cadd(v[6], v[7]), y7 = csub(v[6], v[7]);
     v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
     v[4] = y4; v[5] = y5; v[6] = y6; v[7] = y7;
 }
 
-// 4-point DFT whose inputs a1 and/or a3 still lack a factor 1/sqrt2 (the W8 rotations of the 16-point
+// 4-point DFT whose inputs a1 and a3 still lack a factor 1/sqrt2 (the W8 rotations of the 16-point
 // transform): the factor rides on the fused multiply-adds of the last butterfly level instead of
 // costing multiplications of its own.
-//   S1 = a1 scaled late, S3 = a3 scaled late; unscaled inputs are passed as they are.
-template <bool S1, bool S3>
-__device__ __forceinline__ void dft4_late_scale(cf &a0, cf &a1, cf &a2, cf &a3) {
+// Both odd inputs carry the factor: (a1 +- a3) unscaled, factor applied in the final level.
+// ROT2: the even input a2 still lacks its quarter turn (-i), which rides on the first level's sums.
+template <bool ROT2>
+__device__ __forceinline__ void dft4_late_odd(cf &a0, cf &a1, cf &a2, cf &a3) {
     constexpr float c = RT_SQRT1_2;
-    if constexpr (S1 && S3) {
-        // both odd inputs carry the factor: (a1 +- a3) unscaled, factor applied in the final level
-        const cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
-        const cf s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
-        a0 = cf{__builtin_fmaf(s13.x, c, s02.x), __builtin_fmaf(s13.y, c, s02.y)};
-        a2 = cf{__builtin_fmaf(s13.x, -c, s02.x), __builtin_fmaf(s13.y, -c, s02.y)};
-        a1 = cf{__builtin_fmaf(d13.x, c, d02.x), __builtin_fmaf(d13.y, c, d02.y)};
-        a3 = cf{__builtin_fmaf(d13.x, -c, d02.x), __builtin_fmaf(d13.y, -c, d02.y)};
-    } else {
-        static_assert(!S1 && !S3, "single late factors are applied on the even input (dft4_late_even)");
-        dft4(a0, a1, a2, a3);
-    }
+    const cf s02 = ROT2 ? add_mi(a0, a2) : cadd(a0, a2), d02 = ROT2 ? sub_mi(a0, a2) : csub(a0, a2);
+    const cf s13 = cadd(a1, a3), e13 = csub(a1, a3);
+    a0 = fma_s(s02, s13, c);
+    a2 = fma_s(s02, s13, -c);
+    a1 = fma_mi<1>(d02, e13, c);
+    a3 = fma_mi<-1>(d02, e13, c);
 }
 
 // 4-point DFT whose input a2 still lacks the factor 1/sqrt2: s02 / d02 become fused multiply-adds.
 __device__ __forceinline__ void dft4_late_even(cf &a0, cf &a1, cf &a2, cf &a3) {
     constexpr float c = RT_SQRT1_2;
-    const cf s02{__builtin_fmaf(a2.x, c, a0.x), __builtin_fmaf(a2.y, c, a0.y)};
-    const cf d02{__builtin_fmaf(a2.x, -c, a0.x), __builtin_fmaf(a2.y, -c, a0.y)};
-    const cf s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    const cf s02 = fma_s(a0, a2, c), d02 = fma_s(a0, a2, -c);
+    const cf s13 = cadd(a1, a3), e13 = csub(a1, a3);
     a0 = cadd(s02, s13);
     a2 = csub(s02, s13);
-    a1 = cadd(d02, d13);
-    a3 = csub(d02, d13);
+    a1 = add_mi(d02, e13);
+    a3 = sub_mi(d02, e13);
 }
-
-// rotations by W8^1 and W8^3 without their factor 1/sqrt2 (applied late, see above)
-__device__ __forceinline__ cf rot_w8_1(cf a) { return cadd(a, mul_mi(a)); }   // (x + y, y - x)
-__device__ __forceinline__ cf rot_w8_3(cf a) { return csub(mul_mi(a), a); }   // (y - x, -(x + y))
 
 // 16-point DFT, natural order in and out:  n = n0 + 4*n1, k = ka + 4*kb.
 __device__ __forceinline__ void dft16(cf (&v)[16]) {
@@ -111,22 +147,21 @@ __device__ __forceinline__ void dft16(cf (&v)[16]) {
     dft4(v[2], v[6], v[10], v[14]);
     dft4(v[3], v[7], v[11], v[15]);
     // twiddles W16^(n0*ka); the four that are W8 rotations keep their 1/sqrt2 for the next level
-    const cf w1{RT_COS_PI_8, -RT_SIN_PI_8};   // W16^1
-    const cf w3{RT_SIN_PI_8, -RT_COS_PI_8};   // W16^3
-    v[5] = cmul(v[5], w1);                    // n0=1 ka=1 : W^1
-    v[9] = rot_w8_1(v[9]);                    // n0=1 ka=2 : W^2 = W8^1   (x 1/sqrt2 late)
-    v[13] = cmul(v[13], w3);                  // n0=1 ka=3 : W^3
-    v[6] = rot_w8_1(v[6]);                    // n0=2 ka=1 : W^2          (x 1/sqrt2 late)
-    v[10] = mul_mi(v[10]);                    // n0=2 ka=2 : W^4 = -i
-    v[14] = rot_w8_3(v[14]);                  // n0=2 ka=3 : W^6 = W8^3   (x 1/sqrt2 late)
-    v[7] = cmul(v[7], w3);                    // n0=3 ka=1 : W^3
-    v[11] = rot_w8_3(v[11]);                  // n0=3 ka=2 : W^6          (x 1/sqrt2 late)
-    v[15] = cneg(cmul(v[15], w1));            // n0=3 ka=3 : W^9 = -W^1
+    // W16^1 = (cos pi/8, -sin pi/8), W16^3 = (sin pi/8, -cos pi/8)
+    v[5] = cmul_const(v[5], RT_COS_PI_8, -RT_SIN_PI_8);     // n0=1 ka=1 : W^1
+    v[9] = rot_w8_1(v[9]);                                  // n0=1 ka=2 : W^2 = W8^1   (x 1/sqrt2 late)
+    v[13] = cmul_const(v[13], RT_SIN_PI_8, -RT_COS_PI_8);   // n0=1 ka=3 : W^3
+    v[6] = rot_w8_1(v[6]);                                  // n0=2 ka=1 : W^2          (x 1/sqrt2 late)
+    //                                                         n0=2 ka=2 : W^4 = -i     (folded into the next level)
+    v[14] = rot_w8_3(v[14]);                                // n0=2 ka=3 : W^6 = W8^3   (x 1/sqrt2 late)
+    v[7] = cmul_const(v[7], RT_SIN_PI_8, -RT_COS_PI_8);     // n0=3 ka=1 : W^3
+    v[11] = rot_w8_3(v[11]);                                // n0=3 ka=2 : W^6          (x 1/sqrt2 late)
+    v[15] = cmul_const(v[15], -RT_COS_PI_8, RT_SIN_PI_8);   // n0=3 ka=3 : W^9 = -W^1
     // 4-point DFTs over n0 for each ka: Y[ka + 4*kb] lands in v[4*ka + kb]
     dft4(v[0], v[1], v[2], v[3]);
-    dft4_late_even(v[4], v[5], v[6], v[7]);              // v[6] lacks 1/sqrt2
-    dft4_late_scale<true, true>(v[8], v[9], v[10], v[11]);  // v[9] and v[11] lack 1/sqrt2
-    dft4_late_even(v[12], v[13], v[14], v[15]);          // v[14] lacks 1/sqrt2
+    dft4_late_even(v[4], v[5], v[6], v[7]);         // v[6] lacks 1/sqrt2
+    dft4_late_odd<true>(v[8], v[9], v[10], v[11]);  // v[9] and v[11] lack 1/sqrt2, v[10] its -i
+    dft4_late_even(v[12], v[13], v[14], v[15]);     // v[14] lacks 1/sqrt2
     // transpose to natural order: out[ka + 4*kb] = v[4*ka + kb]
     cf t;
     t = v[1];  v[1] = v[4];   v[4] = t;

@@ -497,6 +497,13 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     uint32_t *const item_word = reinterpret_cast<uint32_t *>(lds_block + sizeof(cf) * 16);  // (padding of exchange row 0: never exchanged)
     const int n_items = p.n_streams * p.blocks_per_stream;
     int item = blockIdx.x;
+#if defined(RT_EXP_PRIO) && RT_EXP_PRIO == 1  // experiment: a fixed issue priority per workgroup slot of a CU (the persistent grid is 3 x the CUs)
+    if constexpr (PERSIST) {
+        const unsigned slot = blockIdx.x / (gridDim.x / 3);
+        if (slot == 0) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     __syncthreads();
   for (;;) {  // one item per round
 #ifdef RT_STAMPS
@@ -704,6 +711,9 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             __builtin_amdgcn_sched_barrier(0);  // keep the order of the two groups of loads
 #endif
         }
+#if defined(RT_EXP_PRIO) && RT_EXP_PRIO == 2  // experiment: the wave that requests memory goes first
+        if constexpr (PERSIST) __builtin_amdgcn_s_setprio(3);
+#endif
         // next step's segment (the segment below the chunk is requested at the end of step L, once it is known to be needed)
         if constexpr (LISTED) {
             request_segment(seg7_nxt);
@@ -715,6 +725,9 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             request_segment((i < L) ? seg - 1 : seg);  // (the last step re-reads its own: harmless, keeps the loop uniform)
         }
 
+#if defined(RT_EXP_PRIO) && RT_EXP_PRIO == 2
+        if constexpr (PERSIST) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+#endif
         RT_STAMP(1);  // issue of the window loads (nperseg 4096) and the next segment's loads
         if constexpr (MODE == 3) {
             // traffic calibration: the scan's exact load stream, nothing else
