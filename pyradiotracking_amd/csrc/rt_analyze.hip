@@ -58,6 +58,8 @@ struct CallCtx {
     bool no_last = false;   // the slot's h_no_last flags apply (some stream was reset, rt_reset_stream)
     int n_dense_streams = 0;  // streams of this call that were re-run dense on their own (AUTO, partial fall-back)
     bool pool_grown = false;  // the record pool was enlarged for this call and the call analysed again (fetch_one)
+    bool thr_rerun = false;   // analysed again on RT_MODE_RUNFILTER with thresholds from its own row means (once per call)
+    bool abs_counted = false; // a MODE 4 / 6 scan of this call left the slot's h_abs_hot
     // handle state before this call (restored when the call is rolled back: a later lane failed to enqueue)
     int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0;
 };
@@ -71,6 +73,8 @@ struct Slot {
     float *d_psum = nullptr;
     uint16_t *d_full = nullptr;       // [S][max_chunks][LG] chunk bits of the run-length pre-filter, then [S][L][LG] bits of chunk 0 by segment (null: not available)
     uint16_t *d_cell_hot = nullptr, *d_cell_need = nullptr;  // [S][max_seg][LG] threshold bits of every cell / the cells to emit (RT_MODE_RUNFILTER)
+    uint32_t *d_abs_hot = nullptr;    // [S] cells at or above the absolute threshold per stream (StftParams::abs_hot; zero between calls)
+    uint32_t *h_abs_hot = nullptr;    // pinned: their maximum over the streams, of this slot's latest MODE 4 / 6 scan
     uint32_t *d_chunk_min = nullptr;  // [S][N] float bits: per bin the smallest complete-chunk sum of this slot's latest call (StftParams::chunk_min)
     int32_t *d_seg_list = nullptr;    // [S][max_seg] segments holding such cells, then [S] their number per stream and [1] the batch's total
     int32_t *h_seg_total = nullptr;   // pinned: that total, copied behind plan_runs
@@ -140,6 +144,10 @@ struct rt_handle {
     int plan_tile = 0;          // rows per planning tile
     int auto_level = RT_MODE_SPARSE;
     int dense_sticky = 0;  // calls left on auto_level before the next probe
+    // the most cells at or above the absolute threshold any stream had in the last call a pre-filter level analysed: more
+    // than the sparse lists hold (kBuckets x hot_capacity per stream) means a probe of the sparse level cannot succeed
+    uint32_t abs_hot_seen = 0;
+    bool abs_hot_valid = false;
     int sticky_len = 16;
     uint64_t n_calls = 0;  // calls enqueued so far
     uint64_t test_enqueues = 0;  // laned handle: rt_process calls seen (RT_TEST_FAIL_LANE)
@@ -308,6 +316,7 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.item_chunks = sl.d_items;
     p.item_count = sl.d_items ? sl.d_items + (size_t)h->cfg.n_streams * h->max_blocks * h->GPW : nullptr;
     p.chunk_min = sl.d_chunk_min;
+    p.abs_hot = nullptr;
     p.thr_bin = nullptr;
     p.cell_hot = sl.d_cell_hot;
     p.cell_need = sl.d_cell_need;
@@ -396,7 +405,9 @@ void launch_scan(rt_handle *h, const StftParams &sp, int blocks, bool u8) {
 // enqueue scan + detect + readback for the call described by sl.call, analysed the way `mode` says.
 // `second_pass_only`: RT_MODE_PREFILTER for a call whose RT_MODE_SPARSE attempt has just overflowed -- that scan
 // wrote the chunk bits, row sums and tail columns already, only the selective pass and the detection are repeated.
-int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr, bool second_pass_only = false) {
+// `own_means`: RT_MODE_RUNFILTER for a call whose per-bin thresholds have just failed their check -- the thresholds of
+// the re-run come from the row means the failed scan left (make_bin_thresholds_from_means).
+int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr, bool second_pass_only = false, bool own_means = false) {
     const CallCtx &c = sl.call;
     if (launched) *launched = false;
     StftParams sp = make_stft_params(h, sl, c.iq, c.stream_stride, c.n_seg, c.tail_write);
@@ -424,6 +435,10 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     if (mode == RT_MODE_RUNFILTER) {
         // per-bin thresholds from the latest chunk minima (the previous call's; on a re-run this call's own), before they are reset
         const int64_t cells = (int64_t)S * h->N;
+        if (own_means) {
+            hipLaunchKernelGGL(make_bin_thresholds_from_means, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, sl.d_psum, sp.blocks_per_stream,
+                               c.n_seg, h->d_thr_bin, h->d_thr_nat, S, h->R3, h->cfg.snr_threshold);
+        } else {
         if (h->minsum_slot < 0) {
             // the handle's very first call: no chunk minima yet.  A scan of this buffer provides them (its bits, taken with
             // the absolute threshold alone, are overwritten by the scan proper below) -- once per handle.
@@ -434,6 +449,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         const uint32_t *prev = h->slot[h->minsum_slot].d_chunk_min;
         hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, prev, h->d_thr_bin, h->d_thr_nat, S, h->R3,
                            h->L, h->cfg.snr_threshold);
+        }
     }
     if (sl.d_chunk_min && !second_pass_only) {
         RT_HIP(h, hipMemsetAsync(sl.d_chunk_min, 0x7f, (size_t)S * h->N * sizeof(uint32_t), h->s_scan));
@@ -444,12 +460,16 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     } else if (mode == RT_MODE_RUNFILTER) {
         // threshold bits of every cell (+ row sums, tail) -> cells of runs long enough -> only their segments again
         sp.thr_bin = h->d_thr_bin;
+        sp.abs_hot = sl.d_abs_hot;
         launch_scan<6>(h, sp, blocks, c.u8);
         sp.thr_bin = nullptr;
+        sp.abs_hot = nullptr;
+        hipLaunchKernelGGL(max_abs_hot, dim3(1), dim3(256), 0, h->s_scan, sl.d_abs_hot, S, sl.h_abs_hot);
+        sl.call.abs_counted = true;
         {
             const int64_t cells = (int64_t)S * h->N;
             hipLaunchKernelGGL(check_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, h->d_thr_nat, sl.d_psum, S, h->N,
-                               sp.blocks_per_stream, c.n_seg, h->cfg.snr_threshold, sl.h_overflow, sl.d_counters, kFlagHotOverflow);
+                               sp.blocks_per_stream, c.n_seg, h->cfg.snr_threshold, sl.h_overflow, sl.d_counters, kFlagHotOverflow | kFlagThrStale);
         }
         RT_HIP(h, hipMemsetAsync(const_cast<int32_t *>(sp.seg_count), 0, ((size_t)S + 1) * sizeof(int32_t), h->s_scan));
         const int tiles = (c.n_seg + h->plan_tile - 1) / h->plan_tile;
@@ -458,7 +478,13 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         RT_HIP(h, hipMemcpyAsync(sl.h_seg_total, sp.seg_count + S, sizeof(int32_t), hipMemcpyDeviceToHost, h->s_scan));
         launch_scan<7>(h, sp, blocks, c.u8);
     } else if (mode == RT_MODE_PREFILTER) {
-        if (!second_pass_only) launch_scan<4>(h, sp, blocks, c.u8);
+        if (!second_pass_only) {
+            sp.abs_hot = sl.d_abs_hot;
+            launch_scan<4>(h, sp, blocks, c.u8);
+            sp.abs_hot = nullptr;
+            hipLaunchKernelGGL(max_abs_hot, dim3(1), dim3(256), 0, h->s_scan, sl.d_abs_hot, S, sl.h_abs_hot);
+            sl.call.abs_counted = true;
+        }
         hipLaunchKernelGGL(plan_pass_b, dim3(S), dim3(256), sizeof(uint32_t) * ((sp.chunks + 31) / 32), h->s_scan, sp.full, sp.first,
                            sp.item_chunks, sp.item_count, h->LG, sp.segs_per_chunk, c.n_seg, sp.chunks, sp.blocks_per_stream, h->GPW);
         launch_scan<5>(h, sp, blocks, c.u8);
@@ -749,6 +775,8 @@ void rt_destroy(rt_handle *h) {
         (void)hipFree(sl.d_cell_hot);
         (void)hipFree(sl.d_cell_need);
         (void)hipFree(sl.d_chunk_min);
+        (void)hipFree(sl.d_abs_hot);
+        (void)hipHostFree(sl.h_abs_hot);
         (void)hipFree(sl.d_seg_list);
         (void)hipHostFree(sl.h_seg_total);
         (void)hipFree(sl.d_raw);
@@ -1001,6 +1029,12 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             RT_CREATE_HIP(hipHostMalloc(&sl.h_seg_total, sizeof(int32_t)));
             *sl.h_seg_total = 0;
         }
+        if (sl.d_full || sl.d_cell_hot) {
+            RT_CREATE_HIP(hipMalloc(&sl.d_abs_hot, (size_t)S * sizeof(uint32_t)));
+            RT_CREATE_HIP(hipMemset(sl.d_abs_hot, 0, (size_t)S * sizeof(uint32_t)));
+            RT_CREATE_HIP(hipHostMalloc(&sl.h_abs_hot, sizeof(uint32_t)));
+            *sl.h_abs_hot = 0u;
+        }
         RT_CREATE_HIP(hipMalloc(&sl.d_hot, (size_t)S * kBuckets * h->hot_cap * sizeof(uint2)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_count, (size_t)S * kBuckets * sizeof(uint32_t)));
         RT_CREATE_HIP(hipMalloc(&sl.d_hot_seen, (size_t)S * kBuckets * sizeof(uint32_t)));
@@ -1190,6 +1224,9 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
                 --h->dense_sticky;
             } else {
                 c.mode_used = level_down(h, h->auto_level);
+                if (c.mode_used == RT_MODE_SPARSE && h->auto_level != RT_MODE_SPARSE && h->abs_hot_valid &&
+                    (uint64_t)h->abs_hot_seen > (uint64_t)kBuckets * (uint64_t)h->hot_cap)
+                    c.mode_used = h->auto_level;  // (no probe, no back-off: the next call looks again)
                 // one probe at a time: the calls enqueued before this one's verdict is in (the caller may keep a slot's
                 // worth of calls in flight) stay on the handle's level instead of each paying for a failed probe
                 if (c.mode_used != h->auto_level) h->dense_sticky = kSlots;
@@ -1386,6 +1423,21 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
                 sl.h_overflow[s] = 0;
             }
         }
+        // The per-bin thresholds of the exact pre-filter were too high for some streams (their noise floor fell from the
+        // buffer before to this one): not a matter of capacity.  A few streams of many go dense on their own below (AUTO);
+        // otherwise the call is analysed again on the same level, its thresholds now taken from its own row means --
+        // the handle's level does not change, and an explicit RT_MODE_RUNFILTER handle does not fail.
+        const bool stale = (flags & kFlagThrStale) && c.mode_used == RT_MODE_RUNFILTER && !c.thr_rerun;
+        flags &= ~kFlagThrStale;
+        const bool few = n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams && level_up(h, c.mode_used) == RT_MODE_DENSE;
+        if (stale && !(h->cfg.mode == RT_MODE_AUTO && few)) {
+            c.thr_rerun = true;
+            int rc = enqueue_analysis(h, sl, RT_MODE_RUNFILTER, nullptr, false, true);
+            if (rc != RT_OK) return rc;
+            RT_HIP(h, hipEventSynchronize(sl.ev_done));
+            flags = sl.h_counters[2];
+            continue;
+        }
         if (h->cfg.mode != RT_MODE_AUTO) {
             h->err = "candidate-cell capacity exceeded (hot_capacity)";
             if (peek) return kCallFailed;  // the laned rt_fetch drops this call in every lane together
@@ -1396,7 +1448,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             // a few of many: only they go dense, the handle stays on its level
             // (where the pre-filter level is still ahead, the whole batch goes there first: its second pass costs less
             // than the fixed ~1 ms of a dense re-run of a few streams -- one workgroup per stream in detect_dense)
-            if (n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams && level_up(h, c.mode_used) == RT_MODE_DENSE) {
+            if (few) {
                 const unsigned long long other = flags & ~(kFlagHotOverflow | (incons_elsewhere ? 0ull : kFlagInconsistent));
                 int rc = enqueue_partial_dense(h, sl, n_bad, sl.h_counters[0]);
                 if (rc == RT_OK) {
@@ -1490,6 +1542,12 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         (void)hipEventElapsedTime(&h->info.ms_stft, sl.ev_begin, sl.ev_scan);
         (void)hipEventElapsedTime(&h->info.ms_detect, sl.ev_scan, sl.ev_done);
         (void)hipEventElapsedTime(&h->info.ms_total, sl.ev_begin, sl.ev_done);
+    }
+    if (c.abs_counted && sl.h_abs_hot) {
+        h->abs_hot_seen = *sl.h_abs_hot;
+        h->abs_hot_valid = true;
+    } else if (c.mode_used == RT_MODE_DENSE && c.n_dense_streams == 0) {
+        h->abs_hot_valid = false;  // (the dense path keeps no count: what was seen is history by the time it is left)
     }
     h->info.mode_used = c.mode_used;
     h->info.fell_back = c.fell_back ? 1 : 0;

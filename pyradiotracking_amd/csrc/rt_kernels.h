@@ -81,6 +81,8 @@ struct StftParams {
     const uint16_t *cell_need;  // [S][T][LG] the cells the selective pass emits (plan_runs writes, MODE 7 reads)
     const int32_t *seg_list; // [S][T] the segments that hold such cells, in any order; seg_count[s] of them
     const int32_t *seg_count;
+    uint32_t *abs_hot;       // [S] (+ word [S]: their maximum, by the planning kernel), or null: MODE 4 / 6 add the stream's cells at or above the
+                             // absolute threshold -- what the sparse lists would have to hold at least (AUTO skips probes that cannot succeed)
     uint32_t *chunk_min;     // [S][N] float bits, or null: per bin the smallest sum of P over a complete chunk of this call (atomicMin;
                              // the host presets 0x7f7f7f7f) -- the quiet level of the bin, for the next call's thr_bin (make_bin_thresholds)
     const float *thr_bin;    // MODE 6, or null: [S][LG][16] a second, per-bin threshold in lane order; a cell's bit is set only if it passes both
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     int n_steps = L;
 
     uint32_t allhot = 0xFFFFu;  // FLAGS: the chunk's bits so far
+    uint32_t n_abs = 0;         // MODE 4 / 6: this lane's cells at or above the absolute threshold (StftParams::abs_hot)
     uint32_t need = 0xFFFFu;                      // MODE 5: the lane's bins that may emit in every segment of the chunk
     uint32_t first_nxt = 0u;                      // MODE 5, chunk 0: the bins whose run through t = 0 reaches the requested segment
     bool group_need = true;                       // MODE 5: this lane group transforms its chunk
@@ -1035,6 +1038,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                     }
                 }
                 if (active && !halo) {
+                    if constexpr (MODE == 4 || MODE == 6) n_abs += (uint32_t)__builtin_popcount(hot);
                     allhot &= hot;
                     if (chunk == 0 && p.full) {  // (lane index opaque: the address stays out of the loop's registers)
                         int lt_f = lt;
@@ -1134,6 +1138,14 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     }
     if constexpr (FLAGS) {
         if (p.full && chunk_ok) p.full[((int64_t)s * p.chunks + chunk) * LG + lt] = (uint16_t)(allhot & 0xFFFFu);
+    }
+    if constexpr (MODE == 4 || MODE == 6) {
+        if (p.abs_hot) {  // (once per item)
+            uint32_t n = n_abs;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+            if ((threadIdx.x & 63) == 0 && n) atomicAdd(&p.abs_hot[s], n);
+        }
     }
     if constexpr (MODE == 3) {
         if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
@@ -1355,6 +1367,22 @@ __global__ __launch_bounds__(256) void plan_runs(const uint16_t *hot, uint16_t *
     if (mine) atomicAdd(&seg_count[gridDim.y], mine);
 }
 
+// The largest per-stream count of cells at or above the absolute threshold (StftParams::abs_hot, left by a MODE 4 / 6
+// scan) -> pinned host word; the counts are put back to zero for the next call.  One workgroup.
+__global__ __launch_bounds__(256) void max_abs_hot(uint32_t *abs_hot, int n_streams, uint32_t *host_max) {
+    __shared__ uint32_t wave_max[4];
+    uint32_t m = 0;
+    for (int s = threadIdx.x; s < n_streams; s += 256) {
+        m = max(m, abs_hot[s]);
+        abs_hot[s] = 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *host_max = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+}
+
 // bin of result register r in lane lt of a group, R3 at run time (bin_of<R3>)
 __device__ __forceinline__ int bin_of_rt(int R3, int lt, int r) {
     if (R3 == 1) return lt + 16 * r;
@@ -1385,6 +1413,24 @@ __global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk
         const float mn = __uint_as_float(chunk_min_prev[(int64_t)s * N + bin]);
         if (mn < 1.0e38f && mn == mn) th = snr * (mn / (float)L);
     }
+    thr_bin[i] = th;
+    thr_nat[(int64_t)s * N + bin] = th;
+}
+
+// The same table from THIS buffer's row means (a call analysed again after its thresholds failed the check below: the
+// failed scan left the partial row sums): theta = snr * row_mean * (1 - 1e-6), the bound itself -- the check cannot fail.
+__global__ __launch_bounds__(256) void make_bin_thresholds_from_means(const float *psum, int items_per_stream, int n_seg, float *thr_bin, float *thr_nat,
+                                                                     int n_streams, int R3, float snr) {
+    const int N = 256 * R3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [S][LG][16]
+    if (i >= (int64_t)n_streams * N) return;
+    const int s = (int)(i / N), lt = (int)(i % N) / 16, r = (int)(i % 16);
+    const int bin = bin_of_rt(R3, lt, r);
+    double sum = 0.0;
+    for (int c = 0; c < items_per_stream; ++c) sum += (double)psum[((int64_t)s * items_per_stream + c) * N + bin];
+    const float avg = (float)sum / (float)n_seg;
+    float th = snr * avg * (1.0f - 1.0e-6f);
+    if (!(th > 0.f) || !(th < 3.0e38f)) th = 0.f;  // (NaN / overflowing sums: the absolute threshold alone)
     thr_bin[i] = th;
     thr_nat[(int64_t)s * N + bin] = th;
 }
@@ -1470,6 +1516,7 @@ __device__ __forceinline__ DetectParams stream_params(const DetectArgs &a, int s
 constexpr unsigned long long kFlagHotOverflow = 1ull;
 constexpr unsigned long long kFlagRecOverflow = 2ull;
 constexpr unsigned long long kFlagInconsistent = 4ull;
+constexpr unsigned long long kFlagThrStale = 8ull;  // check_bin_thresholds: a stream's per-bin thresholds were too high for this buffer (comes with kFlagHotOverflow)
 
 // sum of one bin's partial row sums in float64, in partial-row order; loads are issued
 // eight at a time so their latency overlaps (the additions keep the sequential order)

@@ -1169,6 +1169,36 @@ def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
         assert len(w8) > n_streams and r8.fetch_records().tobytes() == w8.tobytes()
 
 
+def test_auto_does_not_probe_the_sparse_level_while_the_noise_would_overflow_it():
+    """On a pre-filter level the threshold-bit scan counts, per stream, the cells at or above the absolute threshold.
+    While that count exceeds what the sparse lists hold (16 buckets x hot_capacity) a probe of the sparse level cannot
+    succeed and AUTO does not try (no wasted scan, no re-run); once the input is quiet again the next call is the probe,
+    it goes through, and the handle is back on the sparse path."""
+    _need_gpu()
+    fs, nperseg, n_seg, n_streams = 300000, 256, 1171, 6
+    blen = nperseg * n_seg + 24
+    thr_dbw, floor_db = -90.0, 2.0
+    sigma = float(np.sqrt(10.0 ** ((thr_dbw + floor_db) / 10.0) * fs / 2.0))
+    loud = _noisy_batch(n_streams, blen, fs, nperseg, seed=5, noise_sigma=sigma, peak_dbw=(thr_dbw + floor_db + 20.0, thr_dbw + floor_db + 34.0))
+    calm = _noisy_batch(n_streams, blen, fs, nperseg, seed=6, noise_sigma=sigma / 30.0, peak_dbw=(thr_dbw + 20.0, thr_dbw + 34.0))
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, signal_threshold_dbw=thr_dbw, segs_per_chunk=32)
+    dense = _batch_for(kw, n_streams, blen, "dense")
+    auto = _batch_for(kw, n_streams, blen, "auto")
+    modes, fell = [], []
+    n_loud = 22  # (more than the 16 calls after which a handle without the count would probe)
+    for k in range(n_loud + 3):
+        chunk = np.ascontiguousarray(loud[:, k % 2] if k < n_loud else calm[:, k % 2])
+        dense.enqueue(chunk); auto.enqueue(chunk)
+        want, got = dense.fetch_records(), auto.fetch_records()
+        assert got.tobytes() == want.tobytes(), k
+        info = auto.native.call_info()
+        modes.append(info.mode_used); fell.append(info.fell_back)
+    assert fell == [1] + [0] * (n_loud + 2), fell
+    assert modes[:n_loud] == [_native.RT_MODE_RUNFILTER] * n_loud, modes
+    # the first calm buffer is still analysed on the pre-filter level (its count is what lifts the gate), the next one is the probe
+    assert modes[n_loud] == _native.RT_MODE_RUNFILTER and modes[n_loud + 1:] == [_native.RT_MODE_SPARSE] * 2, modes
+
+
 def test_exact_prefilter_survives_a_noise_floor_that_drops():
     """The per-bin thresholds of the exact pre-filter come from the buffer before (snr * its quietest chunk).  They are
     only valid while they stay below snr * this buffer's row mean -- check_bin_thresholds verifies that behind the scan.
@@ -1197,6 +1227,20 @@ def test_exact_prefilter_survives_a_noise_floor_that_drops():
         assert len(want) > n_streams and got.tobytes() == want.tobytes(), k
         assert info.mode_used == _native.RT_MODE_RUNFILTER, (k, info.mode_used)
         assert info.n_dense_streams == (0 if k == 0 else 2), (k, info.n_dense_streams)
+    # The floor of EVERY stream falls by 6 dB: nothing to single out.  The call is analysed again on the same level with
+    # thresholds from its own row means -- an explicit RT_MODE_RUNFILTER handle (one and two lanes) does not fail, an
+    # AUTO handle neither changes its level nor reports a fall-back.
+    dense = _batch_for(kw, n_streams, blen, "dense")
+    handles = [_batch_for(kw, n_streams, blen, "runfilter"), _batch_for(kw, n_streams, blen, "runfilter", lanes=2), _batch_for(kw, n_streams, blen, "auto")]
+    for k, chunk in enumerate([np.ascontiguousarray(iq[:, 0]), np.ascontiguousarray(quiet[:, 1]), np.ascontiguousarray(quiet[:, 0])]):
+        dense.enqueue(chunk)
+        want = dense.fetch_records()
+        assert len(want) > n_streams
+        for b in handles:
+            b.enqueue(chunk)
+            assert b.fetch_records().tobytes() == want.tobytes(), k
+        info = handles[2].native.call_info()
+        assert info.mode_used == _native.RT_MODE_RUNFILTER and info.n_dense_streams == 0 and info.fell_back == (1 if k == 0 else 0), (k, info.mode_used, info.fell_back)
 
 
 @pytest.mark.parametrize("lanes", [1, 2])
