@@ -54,7 +54,7 @@ typedef enum rt_status {
 /* how the batch is analysed */
 typedef enum rt_mode {
     RT_MODE_AUTO = 0,   /* fused sparse path; a buffer whose candidate lists overflow is re-run one
-                           level up (pre-filter where available, then dense) and the handle stays
+                           level up (RT_MODE_PREFILTER, RT_MODE_RUNFILTER where available, then dense) and the handle stays
                            on that level for the next 16 buffers (32, 64 ... 1024 while the probes of
                            the level below keep overflowing) */
     RT_MODE_DENSE = 1,  /* materialise the power spectrogram (any input)        */
@@ -68,10 +68,13 @@ typedef enum rt_mode {
     RT_MODE_RUNFILTER = 4 /* ABI v5: sparse path behind the EXACT run-length pre-filter: a first scan keeps the
                              threshold bit of every cell, a planning kernel keeps the cells of threshold runs of
                              at least the minimum plateau length (or through t = 0), a second scan transforms only
-                             the segments that hold such cells.  Any segs_per_chunk; the geometry where
-                             RT_MODE_PREFILTER is unavailable (the reference's defaults: 300 kS/s, 8 ms) is where
-                             RT_MODE_AUTO uses it between the sparse and the dense path.  RT_E_UNSUPPORTED where the
-                             minimum plateau length does not fit the planning tiles; overflow -> RT_E_HOT_OVERFLOW. */
+                             the segments that hold such cells.  The bits also ask for snr_threshold x the bin's
+                             quiet level (from the buffer before, verified against this buffer's row means), so the
+                             level stays selective with the noise floor over the absolute threshold.  Any
+                             segs_per_chunk.  RT_MODE_AUTO uses it between the sparse (or RT_MODE_PREFILTER, where
+                             that exists) and the dense path -- at the reference's defaults (300 kS/s, 8 ms) it is
+                             the only level in between.  RT_E_UNSUPPORTED where the minimum plateau length does not
+                             fit the planning tiles; overflow -> RT_E_HOT_OVERFLOW. */
 } rt_mode;
 
 /*

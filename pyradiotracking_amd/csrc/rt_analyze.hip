@@ -385,15 +385,17 @@ int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
     return RT_OK;
 }
 
-// the level above / below `mode` in AUTO's order SPARSE < PREFILTER < DENSE
-// (the middle level is the chunk-bit pre-filter where the geometry allows it, else the exact one)
-int middle_level(const rt_handle *h) { return h->prefilter_ok ? RT_MODE_PREFILTER : h->runfilter_ok ? RT_MODE_RUNFILTER : RT_MODE_DENSE; }
+// the level above / below `mode` in AUTO's order SPARSE < PREFILTER (chunk bits, where the geometry allows it) < RUNFILTER
+// (exact, where its scratch exists) < DENSE
+int level_rank(int mode) { return mode == RT_MODE_SPARSE ? 0 : mode == RT_MODE_PREFILTER ? 1 : mode == RT_MODE_RUNFILTER ? 2 : 3; }
 int level_up(const rt_handle *h, int mode) {
-    if (mode == RT_MODE_SPARSE) return middle_level(h);
+    if (mode == RT_MODE_SPARSE && h->prefilter_ok) return RT_MODE_PREFILTER;
+    if (level_rank(mode) < 2 && h->runfilter_ok) return RT_MODE_RUNFILTER;
     return RT_MODE_DENSE;
 }
 int level_down(const rt_handle *h, int mode) {
-    if (mode == RT_MODE_DENSE && middle_level(h) != RT_MODE_DENSE) return middle_level(h);
+    if (mode == RT_MODE_DENSE && h->runfilter_ok) return RT_MODE_RUNFILTER;
+    if (level_rank(mode) > 1 && h->prefilter_ok) return RT_MODE_PREFILTER;
     return RT_MODE_SPARSE;
 }
 
@@ -879,8 +881,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_PREFILTER needs signal_min_duration >= 2 * segs_per_chunk STFT hops");
         }
         // Exact run-length pre-filter: any chunk length; its planning tiles (kPlanWords words of LDS per buffer, a halo
-        // of r rows either side) must leave room for rows of their own.  Built where it is asked for, and in AUTO mode
-        // where the chunk-bit pre-filter is not available.
+        // of r rows either side) must leave room for rows of their own.  Built where it is asked for, and in AUTO mode.
         h->run_cells = (int)std::max<long long>(1, std::min<long long>(r_min, 1 << 20));
         const int rows_max = kPlanWords / (h->LG / 4);  // rows of 64-bit words (four lanes each) per LDS buffer
         h->plan_tile = std::min(rows_max - 2 * h->run_cells, kPlanWords / 4);
@@ -889,7 +890,15 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             delete h;
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length does not fit the planning tiles at this nperseg");
         }
-        h->runfilter_ok = fits && (cfg->mode == RT_MODE_RUNFILTER || (cfg->mode == RT_MODE_AUTO && !h->prefilter_ok));
+        h->runfilter_ok = fits && (cfg->mode == RT_MODE_RUNFILTER || cfg->mode == RT_MODE_AUTO);
+        if (h->runfilter_ok && cfg->mode == RT_MODE_AUTO && h->prefilter_ok) {
+            // a level between the chunk-bit pre-filter and the dense path (noise far over the absolute threshold: every chunk
+            // bit set, while SNR-aware cell bits stay selective) -- optional: only where its scratch is a small part of
+            // what is free (two slots of threshold bits + kept cells + segment lists + chunk minima)
+            const size_t per_slot = (size_t)cfg->n_streams * std::max(h->max_seg, 1) * (size_t)(h->LG * 4 + 4) + (size_t)cfg->n_streams * h->N * 4;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)kSlots * per_slot > free_b / 8) h->runfilter_ok = false;
+        }
     }
     if (((long long)h->N << key_tbits(std::max(h->max_seg, 2))) > 0x100000000ll) {
         delete h;
@@ -1224,9 +1233,16 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
                 --h->dense_sticky;
             } else {
                 c.mode_used = level_down(h, h->auto_level);
+                // (no probe, no back-off where the last count rules the level below out: the next call looks again)
                 if (c.mode_used == RT_MODE_SPARSE && h->auto_level != RT_MODE_SPARSE && h->abs_hot_valid &&
                     (uint64_t)h->abs_hot_seen > (uint64_t)kBuckets * (uint64_t)h->hot_cap)
-                    c.mode_used = h->auto_level;  // (no probe, no back-off: the next call looks again)
+                    c.mode_used = h->auto_level;
+                // ... and the chunk-bit level needs chunks of L cells that do NOT all pass the absolute threshold: with a
+                // share q of the cells over it a chunk bit is set with probability q^L in each of nperseg bins (q = 3/4,
+                // L = 32, 256 bins: 2.6 % of the chunks), beyond that every chunk is kept
+                if (c.mode_used == RT_MODE_PREFILTER && h->auto_level == RT_MODE_RUNFILTER && h->abs_hot_valid && T > 0 &&
+                    (uint64_t)h->abs_hot_seen * 4u > 3u * (uint64_t)T * (uint64_t)h->N)
+                    c.mode_used = h->auto_level;
                 // one probe at a time: the calls enqueued before this one's verdict is in (the caller may keep a slot's
                 // worth of calls in flight) stay on the handle's level instead of each paying for a failed probe
                 if (c.mode_used != h->auto_level) h->dense_sticky = kSlots;
@@ -1429,7 +1445,8 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         // the handle's level does not change, and an explicit RT_MODE_RUNFILTER handle does not fail.
         const bool stale = (flags & kFlagThrStale) && c.mode_used == RT_MODE_RUNFILTER && !c.thr_rerun;
         flags &= ~kFlagThrStale;
-        const bool few = n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams && level_up(h, c.mode_used) == RT_MODE_DENSE;
+        const bool few = n_bad > 0 && n_bad <= kMaxPartial && 4 * n_bad <= h->cfg.n_streams &&
+                         !(c.mode_used == RT_MODE_SPARSE && level_up(h, RT_MODE_SPARSE) != RT_MODE_DENSE);
         if (stale && !(h->cfg.mode == RT_MODE_AUTO && few)) {
             c.thr_rerun = true;
             int rc = enqueue_analysis(h, sl, RT_MODE_RUNFILTER, nullptr, false, true);
@@ -1505,7 +1522,6 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
   }
     if (c.mode_used != RT_MODE_DENSE && !c.is_extract && c.n_seg > 0)
         for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
-    auto rank = [](int mode) { return mode == RT_MODE_SPARSE ? 0 : (mode == RT_MODE_PREFILTER || mode == RT_MODE_RUNFILTER) ? 1 : 2; };
     // (the exact pre-filter on input where it is not selective: see below)
     bool unselective = h->cfg.mode == RT_MODE_AUTO && c.mode_used == RT_MODE_RUNFILTER && !c.is_extract && c.n_seg > 0 && sl.h_seg_total &&
                        (int64_t)*sl.h_seg_total * 2 > (int64_t)h->cfg.n_streams * c.n_seg;
@@ -1515,7 +1531,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     if (h->cfg.mode == RT_MODE_AUTO && (c.mode_used == RT_MODE_RUNFILTER || c.mode_used == RT_MODE_PREFILTER) && !c.is_extract && c.n_seg > 0 &&
         h->info.n_hot * 32 > (int64_t)h->cfg.n_streams * c.n_seg * h->N)
         unselective = true;
-    if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && rank(c.mode_used) < rank(h->auto_level) && !unselective) {
+    if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && level_rank(c.mode_used) < level_rank(h->auto_level) && !unselective) {
         // a probe of a lower level went through: the handle moves there (and from the pre-filter level it will
         // probe the plain sparse path after the usual interval)
         h->auto_level = c.mode_used;
@@ -1527,7 +1543,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         // is then most of a scan, and the dense path (one scan, 16 B per sample) is faster -- measured at the reference's
         // default geometry with the noise floor 2 dB over the threshold: 213 k against 241 k MS/s.  The handle moves up like
         // after an overflow (without analysing this call again: its result stands) and probes this level later.
-        h->auto_level = RT_MODE_DENSE;
+        h->auto_level = level_up(h, c.mode_used);
         h->dense_sticky = h->sticky_len;
         h->sticky_len = std::min(h->sticky_len * 2, 1024);
     }

@@ -927,8 +927,10 @@ def test_pipelined_uint8_host_buffers_of_growing_length():
     for k, raw in enumerate((raw_short, raw_long, raw_short)):
         serial.enqueue_bytes(raw)
         want.append(serial.fetch_records())
-        # 8-bit noise at this threshold: the first call overflows and re-runs dense, the following ones start dense
-        assert serial.call_info().fell_back == (1 if k == 0 else 0) and serial.call_info().mode_used == _native.RT_MODE_DENSE
+        # 8-bit noise at this threshold: the first call overflows and is analysed again further up (the exact pre-filter;
+        # once it finds itself unselective on this input the handle moves on to the dense path), the following ones start there
+        assert serial.call_info().fell_back == (1 if k == 0 else 0)
+        assert serial.call_info().mode_used in (_native.RT_MODE_RUNFILTER, _native.RT_MODE_DENSE)
     piped = _batch_for(kw, 3, blen, "auto", hot_capacity=256)
     piped.enqueue_bytes(raw_short)
     piped.enqueue_bytes(raw_long)
@@ -1105,6 +1107,35 @@ def test_run_length_prefilter_equals_dense(threshold_dbw):
     d8.enqueue_bytes(raw); p8.enqueue_bytes(raw)
     w8 = d8.fetch_records()
     assert len(w8) > n_streams and p8.fetch_records().tobytes() == w8.tobytes()
+
+
+def test_auto_climbs_from_the_chunk_bit_prefilter_to_the_exact_one_under_a_high_noise_floor():
+    """Noise floor 10 dB OVER the absolute threshold at config-2 geometry (90 % of all cells pass it): nearly every chunk
+    of 32 cells passes throughout, so the chunk-bit pre-filter keeps everything and overflows its lists too; the exact
+    pre-filter, whose bits also need snr x the bin's quiet level, stays selective.  AUTO goes sparse -> chunk bits -> exact
+    on the first buffer, stays there (no probe of a level its count rules out), and returns the dense path's records,
+    one and two lanes."""
+    _need_gpu()
+    fs, nperseg, blen, n_streams = 2048000, 256, 256 * 1500, 6
+    iq = _noisy_batch(n_streams, blen, fs, nperseg, seed=170, n_buffers=2)
+    kw = dict(sample_rate=fs, signal_threshold_dbw=-170.0)
+    dense = _batch_for(kw, n_streams, blen, "dense")
+    auto = _batch_for(kw, n_streams, blen, "auto")
+    lanes = _batch_for(kw, n_streams, blen, "auto", lanes=2)
+    with pytest.raises(_native.NativeError) as ei:  # the chunk-bit level alone cannot hold this input
+        pre = _batch_for(kw, n_streams, blen, "prefilter")
+        pre.enqueue(np.ascontiguousarray(iq[:, 0])); pre.fetch_records()
+    assert ei.value.code == _native.RT_E_HOT_OVERFLOW
+    for k in range(20):  # (past the 16 calls after which a probe of the level below would be due)
+        chunk = np.ascontiguousarray(iq[:, k % 2])
+        for b in (dense, auto, lanes):
+            b.enqueue(chunk)
+        want = dense.fetch_records()
+        assert len(want) > n_streams
+        for b in (auto, lanes):
+            assert b.fetch_records().tobytes() == want.tobytes(), k
+        info = auto.native.call_info()
+        assert info.mode_used == _native.RT_MODE_RUNFILTER and info.fell_back == (1 if k == 0 else 0), (k, info.mode_used, info.fell_back)
 
 
 @pytest.mark.parametrize("fs,nperseg,n_seg,floor_db", [
@@ -1285,7 +1316,12 @@ def test_a_few_noisy_streams_go_dense_on_their_own(lanes):
     b = _batch_for(kw, n_streams, blen, "auto", record_capacity=2048)
     b.enqueue(np.ascontiguousarray(many)); b.fetch_records()
     info = b.native.call_info()
-    assert info.mode_used == _native.RT_MODE_DENSE and info.fell_back == 1 and info.n_dense_streams == 0
+    assert info.mode_used == _native.RT_MODE_RUNFILTER and info.fell_back == 1 and info.n_dense_streams == 0
+    dense = _batch_for(kw, n_streams, blen, "dense", record_capacity=2048)
+    dense.enqueue(np.ascontiguousarray(many))
+    b2 = _batch_for(kw, n_streams, blen, "auto", record_capacity=2048)
+    b2.enqueue(np.ascontiguousarray(many))
+    assert b2.fetch_records().tobytes() == dense.fetch_records().tobytes()
 
 
 def test_prefilter_needs_long_enough_minimum_duration():
