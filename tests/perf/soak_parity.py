@@ -79,9 +79,18 @@ while time.time() < t_end:
             pulses.append(synth.Pulse(max(0, k * blen - ln // 2), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.1))
             pulses.append(synth.Pulse(max(0, k * blen - ln - int(rng.integers(0, 3)) * nperseg), ln, float(rng.uniform(-0.4, 0.4) * fs), amp, 0.3))
         dc = complex(2e-3, -1e-3) if rng.random() < 0.3 else 0j
-        sigma = synth.NOISE_SIGMA if not (noisy or s in noisy_some) else float(np.sqrt(10.0 ** ((thr + rng.uniform(-8.0, 2.0)) / 10.0) * fs / 2.0))
+        # (round 3: up to 10 dB OVER the threshold -- the exact pre-filter's per-bin thresholds, AUTO's four levels)
+        sigma = synth.NOISE_SIGMA if not (noisy or s in noisy_some) else float(np.sqrt(10.0 ** ((thr + rng.uniform(-8.0, 10.0)) / 10.0) * fs / 2.0))
         iq.append(synth.make_stream(synth.StreamSpec(total, fs, pulses, dc=dc, noise_sigma=sigma), 1000 * case + s))
     iq = np.stack(iq)
+    # ... and in a third of the noisy cases the level of some or all streams falls by 6 dB at a buffer boundary (thresholds
+    # taken from the buffer before are then too high: check_bin_thresholds, the re-run on the call's own row means)
+    rng_step = np.random.default_rng([seed0, case, 7])
+    floor_step = noisy and rng_step.random() < 0.33
+    if floor_step:
+        k0 = int(rng_step.integers(1, n_buf))
+        who = np.arange(n_streams) if rng_step.random() < 0.5 else rng_step.choice(n_streams, size=max(1, n_streams // 4), replace=False)
+        iq[who, k0 * blen:] *= np.complex64(0.5)
     poison = os.environ.get("SOAK_POISON") == "1" and not u8 and rng.random() < 0.5
     if poison:
         # NaN samples (SOAK_POISON_KIND=nan, the default): a NaN segment and NaN row means in every bin, the same on both
@@ -237,6 +246,6 @@ while time.time() < t_end:
     n_records += nrec
     n_bad += bad
     print(f"case {case}: N={nperseg} fs={fs} {window} T={n_seg} S={n_streams} bufs={n_buf} min/max={min_ms:.2f}/{max_ms:.1f} ms thr={thr} snr={snr} "
-          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''}{' poisoned' if poison else ''}{' noisy' if noisy else ''}{' noisy-streams=' + str(sorted(noisy_some)) if noisy_some else ''}{' subtract-first' if subtract_first else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
+          f"mode={mode} lanes={lanes} cal={'per-stream' if isinstance(cal, list) else cal}{' pipelined' if pipelined else ''}{' ragged' if vary_len else ''}{' restarts' if resets else ''}{' uint8' if u8 else ''}{' device-tensors' if dev_tensor else ''}{' poisoned' if poison else ''}{' noisy' if noisy else ''}{' floor-step' if floor_step else ''}{' noisy-streams=' + str(sorted(noisy_some)) if noisy_some else ''}{' subtract-first' if subtract_first else ''} chunk={chunking}: {nrec} records, {bad} mismatching stream-buffers", flush=True)
 print(f"SOAK: {n_cases} cases, {n_records} oracle records, {n_bad} mismatching stream-buffers "
       f"({n_unexplained} not explained by a float32 round-off margin, {n_field} with a field beyond 0.1 dB)")
