@@ -161,7 +161,12 @@ class BatchSignalAnalyzer:
         record_pool: int = 0,
         **kwargs,
     ):
-        """``record_pool`` (``rt_config.record_pool``): records the pinned result pool holds at first (0: up to 4 Mi); a
+        """``mode`` (``rt_config.mode``): ``"auto"`` (default) analyses on the fused sparse path and, when an input's noise
+        crosses the thresholds, climbs by itself -- chunk-bit pre-filter, exact SNR-aware pre-filter, dense spectrogram; the
+        records are the same on every level.  ``"sparse"``, ``"prefilter"``, ``"runfilter"`` and
+        ``"dense"`` pin one level (the first three refuse an input they cannot hold with ``RT_E_HOT_OVERFLOW``).
+
+        ``record_pool`` (``rt_config.record_pool``): records the pinned result pool holds at first (0: up to 4 Mi); a
         buffer with more signals grows it -- the reference appends without limit (``analyze.py:449-450``), here only
         ``record_capacity`` per stream bounds a call.
 
