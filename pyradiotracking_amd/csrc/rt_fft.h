@@ -8,28 +8,25 @@
 
 namespace rt {
 
-// Experiment switch RT_PACKED: a complex value as a two-element vector in an aligned VGPR pair, so that the transform's
-// complex additions are one v_pk_add_f32 each and its quarter turns one v_pk_fma_f32 with a constant pair -- the same
-// IEEE operations in the same order as the scalar form (bit-identical spectra), in about half the instructions.
-#ifndef RT_PACKED
-#define RT_PACKED 0
-#endif
-#if RT_PACKED
-typedef float cf __attribute__((ext_vector_type(2)));
-#define RT_FMA2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
-#else
+// Two forms of a complex value, the same IEEE operations in the same order (bit-identical spectra):
+//   cf   a struct of two floats: scalar v_add / v_mul / v_fma_f32 on any two registers;
+//   cfv  a two-element vector in an aligned VGPR pair: complex additions are one v_pk_add_f32 each, quarter turns and the
+//        late 1/sqrt2 one v_pk_fma_f32 with a constant pair, constant twiddles two packed operations -- 16 % fewer vector
+//        instructions in the nperseg-256 step, at the price of ~40 more registers (pairs).  A packed instruction holds
+//        the SIMD ~1.45 x as long as a scalar one, so the step gains 1.7 %, and only where the registers are free: the
+//        complex64 kernels of nperseg 256 use it (stft_scan: PK), every other instantiation keeps the scalar form
+//        (spills at nperseg >= 512, the four-workgroup limit of the uint8 kernels; EXPERIMENTS.md, round 3, entry 20).
 struct cf {
     float x, y;
 };
-#endif
+typedef float cfv __attribute__((ext_vector_type(2)));
+template <class C> __device__ __forceinline__ C make_c(float x, float y);
+template <> __device__ __forceinline__ cf make_c<cf>(float x, float y) { return cf{x, y}; }
+template <> __device__ __forceinline__ cfv make_c<cfv>(float x, float y) { return cfv{x, y}; }
 
-#if RT_PACKED
-__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
-#else
+// ---- scalar form
 __device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
-#endif
 // Contraction is spelled out (the library is built with -ffp-contract=off) so
 // every instantiation of the scan kernel computes bit-identical spectra.
 __device__ __forceinline__ cf cmul(cf a, cf b) {
@@ -37,27 +34,10 @@ __device__ __forceinline__ cf cmul(cf a, cf b) {
 }
 // multiply by -i  (forward-transform quarter turn): (x + iy)(-i) = y - ix
 __device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
-#if RT_PACKED
-__device__ __forceinline__ cf cscale(cf a, float s) { return a * s; }
-__device__ __forceinline__ cf cneg(cf a) { return -a; }
-// a * w for a compile-time w: the partner pair (-w.y, w.x) is a constant too, so the product is two packed operations
-// (a.y * -w.y == -(a.y * w.y) exactly: the same roundings as cmul)
-__device__ __forceinline__ cf cmul_const(cf a, float wx, float wy) {
-    const cf t = a.yy * cf{-wy, wx};
-    return RT_FMA2(a.xx, (cf{wx, wy}), t);
-}
-// b + c (-i) a without forming (-i) a:  (b.x + c a.y, b.y - c a.x) -- one packed fused multiply-add on the swapped pair
-// (c = +-1: the plain sums, exactly)
-template <int SIGN>
-__device__ __forceinline__ cf fma_mi(cf b, cf a, float c) { return RT_FMA2(a.yx, (cf{SIGN * c, -SIGN * c}), b); }
-__device__ __forceinline__ cf add_mi(cf b, cf a) { return fma_mi<1>(b, a, 1.f); }
-__device__ __forceinline__ cf sub_mi(cf b, cf a) { return fma_mi<-1>(b, a, 1.f); }
-// b + c a
-__device__ __forceinline__ cf fma_s(cf b, cf a, float c) { return RT_FMA2(a, (cf{c, c}), b); }
-#else
 __device__ __forceinline__ cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
 __device__ __forceinline__ cf cneg(cf a) { return cf{-a.x, -a.y}; }
 __device__ __forceinline__ cf cmul_const(cf a, float wx, float wy) { return cmul(a, cf{wx, wy}); }
+// b + (-i) a,  b - (-i) a,  b + c (-i) a,  b + c a
 __device__ __forceinline__ cf add_mi(cf b, cf a) { return cadd(b, mul_mi(a)); }
 __device__ __forceinline__ cf sub_mi(cf b, cf a) { return csub(b, mul_mi(a)); }
 template <int SIGN>
@@ -66,20 +46,43 @@ __device__ __forceinline__ cf fma_mi(cf b, cf a, float c) {
     return cf{__builtin_fmaf(r.x, SIGN * c, b.x), __builtin_fmaf(r.y, SIGN * c, b.y)};
 }
 __device__ __forceinline__ cf fma_s(cf b, cf a, float c) { return cf{__builtin_fmaf(a.x, c, b.x), __builtin_fmaf(a.y, c, b.y)}; }
-#endif
+
+// ---- packed form
+__device__ __forceinline__ cfv cadd(cfv a, cfv b) { return a + b; }
+__device__ __forceinline__ cfv csub(cfv a, cfv b) { return a - b; }
+__device__ __forceinline__ cfv cmul(cfv a, cfv b) {  // (a run-time factor: its partner pair would cost two more operations than it saves)
+    return cfv{__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
+}
+__device__ __forceinline__ cfv cscale(cfv a, float s) { return a * s; }
+__device__ __forceinline__ cfv cneg(cfv a) { return -a; }
+// a * w for a compile-time w: the partner pair (-w.y, w.x) is a constant too, so the product is two packed operations
+// (a.y * -w.y == -(a.y * w.y) exactly: the same roundings as cmul)
+__device__ __forceinline__ cfv cmul_const(cfv a, float wx, float wy) {
+    const cfv t = a.yy * cfv{-wy, wx};
+    return __builtin_elementwise_fma(a.xx, (cfv{wx, wy}), t);
+}
+// b + c (-i) a without forming (-i) a:  (b.x + c a.y, b.y - c a.x) -- one packed fused multiply-add on the swapped pair
+// (c = +-1: the plain sums, exactly)
+template <int SIGN>
+__device__ __forceinline__ cfv fma_mi(cfv b, cfv a, float c) { return __builtin_elementwise_fma(a.yx, (cfv{SIGN * c, -SIGN * c}), b); }
+__device__ __forceinline__ cfv add_mi(cfv b, cfv a) { return fma_mi<1>(b, a, 1.f); }
+__device__ __forceinline__ cfv sub_mi(cfv b, cfv a) { return fma_mi<-1>(b, a, 1.f); }
+__device__ __forceinline__ cfv fma_s(cfv b, cfv a, float c) { return __builtin_elementwise_fma(a, (cfv{c, c}), b); }
 
 // 4-point DFT in place, natural order out.
-__device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3) {
-    cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
-    cf s13 = cadd(a1, a3), e13 = csub(a1, a3);
+template <class C>
+__device__ __forceinline__ void dft4(C &a0, C &a1, C &a2, C &a3) {
+    C s02 = cadd(a0, a2), d02 = csub(a0, a2);
+    C s13 = cadd(a1, a3), e13 = csub(a1, a3);
     a0 = cadd(s02, s13);
     a2 = csub(s02, s13);
     a1 = add_mi(d02, e13);
     a3 = sub_mi(d02, e13);
 }
 
-__device__ __forceinline__ void dft2(cf &a0, cf &a1) {
-    cf s = cadd(a0, a1), d = csub(a0, a1);
+template <class C>
+__device__ __forceinline__ void dft2(C &a0, C &a1) {
+    C s = cadd(a0, a1), d = csub(a0, a1);
     a0 = s;
     a1 = d;
 }
@@ -91,23 +94,24 @@ __device__ __forceinline__ void dft2(cf &a0, cf &a1) {
 // multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
 // (a + (-i)a) = (x + y, y - x);  ((-i)a - a) = (y - x, -(x + y)) -- the same sums, then one scale
 // rotations by W8^1 and W8^3 without their factor 1/sqrt2
-__device__ __forceinline__ cf rot_w8_1(cf a) { return add_mi(a, a); }          // (x + y, y - x)
-__device__ __forceinline__ cf rot_w8_3(cf a) { return add_mi(cneg(a), a); }    // (y - x, -(x + y))
-__device__ __forceinline__ cf mul_w8_1(cf a) { return cscale(rot_w8_1(a), RT_SQRT1_2); }
-__device__ __forceinline__ cf mul_w8_3(cf a) { return cscale(rot_w8_3(a), RT_SQRT1_2); }
+template <class C> __device__ __forceinline__ C rot_w8_1(C a) { return add_mi(a, a); }          // (x + y, y - x)
+template <class C> __device__ __forceinline__ C rot_w8_3(C a) { return add_mi(cneg(a), a); }    // (y - x, -(x + y))
+template <class C> __device__ __forceinline__ C mul_w8_1(C a) { return cscale(rot_w8_1(a), RT_SQRT1_2); }
+template <class C> __device__ __forceinline__ C mul_w8_3(C a) { return cscale(rot_w8_3(a), RT_SQRT1_2); }
 
 // 8-point DFT, natural order in and out:  n = n0 + 2*n1, k = ka + 4*kb
 // (4-point DFTs over n1 for each n0, twiddle W8^(n0*ka), 2-point over n0).
-__device__ __forceinline__ void dft8(cf (&v)[8]) {
+template <class C>
+__device__ __forceinline__ void dft8(C (&v)[8]) {
     dft4(v[0], v[2], v[4], v[6]);  // n0 = 0 : Z0[ka] in v[0], v[2], v[4], v[6]
     dft4(v[1], v[3], v[5], v[7]);  // n0 = 1 : Z1[ka]
     v[3] = mul_w8_1(v[3]);         // ka = 1
     v[7] = mul_w8_3(v[7]);         // ka = 3  (ka = 2: W8^2 = -i, folded into y2 / y6)
     // Y[ka + 4*kb] = Z0[ka] + (-1)^kb Z1[ka]
-    cf y0 = cadd(v[0], v[1]), y4 = csub(v[0], v[1]);
-    cf y1 = cadd(v[2], v[3]), y5 = csub(v[2], v[3]);
-    cf y2 = add_mi(v[4], v[5]), y6 = sub_mi(v[4], v[5]);
-    cf y3 = cadd(v[6], v[7]), y7 = csub(v[6], v[7]);
+    C y0 = cadd(v[0], v[1]), y4 = csub(v[0], v[1]);
+    C y1 = cadd(v[2], v[3]), y5 = csub(v[2], v[3]);
+    C y2 = add_mi(v[4], v[5]), y6 = sub_mi(v[4], v[5]);
+    C y3 = cadd(v[6], v[7]), y7 = csub(v[6], v[7]);
     v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
     v[4] = y4; v[5] = y5; v[6] = y6; v[7] = y7;
 }
@@ -117,11 +121,11 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
 // costing multiplications of its own.
 // Both odd inputs carry the factor: (a1 +- a3) unscaled, factor applied in the final level.
 // ROT2: the even input a2 still lacks its quarter turn (-i), which rides on the first level's sums.
-template <bool ROT2>
-__device__ __forceinline__ void dft4_late_odd(cf &a0, cf &a1, cf &a2, cf &a3) {
+template <bool ROT2, class C>
+__device__ __forceinline__ void dft4_late_odd(C &a0, C &a1, C &a2, C &a3) {
     constexpr float c = RT_SQRT1_2;
-    const cf s02 = ROT2 ? add_mi(a0, a2) : cadd(a0, a2), d02 = ROT2 ? sub_mi(a0, a2) : csub(a0, a2);
-    const cf s13 = cadd(a1, a3), e13 = csub(a1, a3);
+    const C s02 = ROT2 ? add_mi(a0, a2) : cadd(a0, a2), d02 = ROT2 ? sub_mi(a0, a2) : csub(a0, a2);
+    const C s13 = cadd(a1, a3), e13 = csub(a1, a3);
     a0 = fma_s(s02, s13, c);
     a2 = fma_s(s02, s13, -c);
     a1 = fma_mi<1>(d02, e13, c);
@@ -129,10 +133,11 @@ __device__ __forceinline__ void dft4_late_odd(cf &a0, cf &a1, cf &a2, cf &a3) {
 }
 
 // 4-point DFT whose input a2 still lacks the factor 1/sqrt2: s02 / d02 become fused multiply-adds.
-__device__ __forceinline__ void dft4_late_even(cf &a0, cf &a1, cf &a2, cf &a3) {
+template <class C>
+__device__ __forceinline__ void dft4_late_even(C &a0, C &a1, C &a2, C &a3) {
     constexpr float c = RT_SQRT1_2;
-    const cf s02 = fma_s(a0, a2, c), d02 = fma_s(a0, a2, -c);
-    const cf s13 = cadd(a1, a3), e13 = csub(a1, a3);
+    const C s02 = fma_s(a0, a2, c), d02 = fma_s(a0, a2, -c);
+    const C s13 = cadd(a1, a3), e13 = csub(a1, a3);
     a0 = cadd(s02, s13);
     a2 = csub(s02, s13);
     a1 = add_mi(d02, e13);
@@ -140,7 +145,8 @@ __device__ __forceinline__ void dft4_late_even(cf &a0, cf &a1, cf &a2, cf &a3) {
 }
 
 // 16-point DFT, natural order in and out:  n = n0 + 4*n1, k = ka + 4*kb.
-__device__ __forceinline__ void dft16(cf (&v)[16]) {
+template <class C>
+__device__ __forceinline__ void dft16(C (&v)[16]) {
     // 4-point DFTs over n1 for each n0: Z[n0][ka] lands in v[n0 + 4*ka]
     dft4(v[0], v[4], v[8], v[12]);
     dft4(v[1], v[5], v[9], v[13]);
@@ -163,7 +169,7 @@ __device__ __forceinline__ void dft16(cf (&v)[16]) {
     dft4_late_odd<true>(v[8], v[9], v[10], v[11]);  // v[9] and v[11] lack 1/sqrt2, v[10] its -i
     dft4_late_even(v[12], v[13], v[14], v[15]);     // v[14] lacks 1/sqrt2
     // transpose to natural order: out[ka + 4*kb] = v[4*ka + kb]
-    cf t;
+    C t;
     t = v[1];  v[1] = v[4];   v[4] = t;
     t = v[2];  v[2] = v[8];   v[8] = t;
     t = v[3];  v[3] = v[12];  v[12] = t;
@@ -174,12 +180,12 @@ __device__ __forceinline__ void dft16(cf (&v)[16]) {
 
 // R-point DFTs over groups of R consecutive registers (R in {2,4,8,16}):
 // 16/R independent transforms, natural order.
-template <int R>
-__device__ __forceinline__ void dft_groups(cf (&v)[16]) {
+template <int R, class C>
+__device__ __forceinline__ void dft_groups(C (&v)[16]) {
     if constexpr (R == 16) {
         dft16(v);
     } else if constexpr (R == 8) {
-        cf a[8], b[8];
+        C a[8], b[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { a[i] = v[i]; b[i] = v[8 + i]; }
         dft8(a);

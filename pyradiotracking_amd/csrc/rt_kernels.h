@@ -405,6 +405,10 @@ template <int R3, int MODE, bool U8 = false, bool LIN = false>
 #ifndef RT_WG4_MAX_R3
 #define RT_WG4_MAX_R3 0
 #endif
+// Packed float32 butterflies (rt_fft.h: cfv) in the complex64 kernels up to this R3 (1 = nperseg 256; 0 = nowhere).
+#ifndef RT_PK_MAX_R3
+#define RT_PK_MAX_R3 1
+#endif
 __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
@@ -441,7 +445,10 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     const int T = p.n_seg;
     const int L = p.segs_per_chunk;
 
-    cf *gx = xch + g * LG * kRowF2;  // this group's exchange rows
+    // the transform's arithmetic form: packed pairs where the registers are free (rt_fft.h), else scalar -- same results
+    constexpr bool PK = (R3 <= RT_PK_MAX_R3) && !U8;
+    using C = typename std::conditional<PK, cfv, cf>::type;
+    C *gx = reinterpret_cast<C *>(xch + g * LG * kRowF2);  // this group's exchange rows
 
     // window and pass twiddles staged in LDS, laid out in the order the lanes
     // read them (16-byte pieces, consecutive lanes -> consecutive pieces), and
@@ -689,9 +696,12 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         const bool halo = LISTED ? false : (BELOW ? (i > L) : (i == 0));  // the step below (above) the chunk: no sums, tail, chunk bits
         const bool active = chunk_ok && seg < T && seg >= 0;
 
-        cf v[16];
+        C v[16];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = to_cf(nxt[m]);
+        for (int m = 0; m < 16; ++m) {
+            const cf x = to_cf(nxt[m]);
+            v[m] = make_c<C>(x.x, x.y);
+        }
         const uint32_t need_seg = need | first_nxt;  // (first_nxt was requested for this step's segment)
         // N = 4096: the window comes from L2.  Vector-memory operations return in order, so these loads must be
         // issued BEFORE the next segment's: waiting for them afterwards (`s_waitcnt vmcnt(0)`) would wait for the
@@ -742,12 +752,13 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         // detrend='constant': subtract the segment mean (scipy _signaltools.py:3926)
         cf sum;
         {
-            cf s8[8], s4[4];
+            C s8[8], s4[4];
 #pragma unroll
             for (int m = 0; m < 8; ++m) s8[m] = cadd(v[m], v[m + 8]);
 #pragma unroll
             for (int m = 0; m < 4; ++m) s4[m] = cadd(s8[m], s8[m + 4]);
-            sum = cadd(cadd(s4[0], s4[2]), cadd(s4[1], s4[3]));
+            const C s1 = cadd(cadd(s4[0], s4[2]), cadd(s4[1], s4[3]));
+            sum = cf{s1.x, s1.y};
         }
         RT_STAMP(2);  // wait for this segment's samples (requested a step ago) + the in-lane sums
         if constexpr (LIN && LG > 64) {
@@ -766,7 +777,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             sum = group_sum<LG>(sum, red);  // (for LG > 64 its barrier also frees the exchange rows)
         }
         RT_STAMP(3);  // group sum (lane shuffles, nperseg >= 2048: workgroup barrier)
-        const cf mean = LIN ? cf{0.f, 0.f} : cscale(sum, 1.0f / (float)N);
+        const cf mean_s = LIN ? cf{0.f, 0.f} : cscale(sum, 1.0f / (float)N);
+        const C mean = make_c<C>(mean_s.x, mean_s.y);
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             float4 w4;
@@ -794,8 +806,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         dft16(v);
         if constexpr (T1_FACTORED) {
             const float4 ta = t1f_lds[lt], tb = t1f_lds[LG + lt];
-            const cf w1{ta.x, ta.y}, w2{ta.z, ta.w}, w4{tb.x, tb.y}, w8{tb.z, tb.w};
-            const cf w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+            const C w1 = make_c<C>(ta.x, ta.y), w2 = make_c<C>(ta.z, ta.w), w4 = make_c<C>(tb.x, tb.y), w8 = make_c<C>(tb.z, tb.w);
+            const C w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
             v[1] = cmul(v[1], w1);
             v[2] = cmul(v[2], w2);
             v[3] = cmul(v[3], w3);
@@ -815,8 +827,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const float4 t = t1_lds[kk * LG + lt];
-                if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
-                v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
+                if (kk) v[2 * kk] = cmul(v[2 * kk], make_c<C>(t.x, t.y));
+                v[2 * kk + 1] = cmul(v[2 * kk + 1], make_c<C>(t.z, t.w));
             }
         }
 
@@ -844,8 +856,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float4 q = row[j];
-                v[2 * j] = cf{q.x, q.y};
-                v[2 * j + 1] = cf{q.z, q.w};
+                v[2 * j] = make_c<C>(q.x, q.y);
+                v[2 * j + 1] = make_c<C>(q.z, q.w);
             }
         }
 
@@ -859,8 +871,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const float4 t = t2_lds[kk * R3 + (lt % R3)];
-                if (kk) v[2 * kk] = cmul(v[2 * kk], cf{t.x, t.y});
-                v[2 * kk + 1] = cmul(v[2 * kk + 1], cf{t.z, t.w});
+                if (kk) v[2 * kk] = cmul(v[2 * kk], make_c<C>(t.x, t.y));
+                v[2 * kk + 1] = cmul(v[2 * kk + 1], make_c<C>(t.z, t.w));
             }
             // Exchange 2 stays inside the R3 lanes that share k1 (R3 consecutive lanes, R3 consecutive
             // rows: the rows those very lanes read in exchange 1), so wave-level ordering is enough.
@@ -877,8 +889,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float4 q = row[j];
-                    v[2 * j] = cf{q.x, q.y};
-                    v[2 * j + 1] = cf{q.z, q.w};
+                    v[2 * j] = make_c<C>(q.x, q.y);
+                    v[2 * j + 1] = make_c<C>(q.z, q.w);
                 }
             }
             RT_ABLATE_STOP(5)  // + pass-2 twiddles and exchange 2
