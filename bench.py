@@ -92,9 +92,11 @@ def parse():
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed steps run once during set-up, before the W warm-up steps: the GPU's clocks need ~10 "
                          "launches after idle to settle (0.85 -> 0.77 ms per scan launch), whatever W the caller picks")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=None,
                     help="stream groups per GPU, each on its own handle / HIP stream (detect of one group overlaps the "
-                         "scan of the other); 1 = one launch sequence per step")
+                         "scan of the other); 1 = one launch sequence per step.  Default: 2 up to nperseg 512, 1 from "
+                         "nperseg 1024 on (those scans are chip-filling grids of persistent workgroups: a second lane's "
+                         "kernels wait behind them -- config 3: 650 k with two lanes, 676 k with one)")
     ap.add_argument("--isolated-steps", type=int, default=50,
                     help="steps of the one-lane pass after the timed region that measures the scan launch alone (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,6 +129,8 @@ def resolve_workload(args, world):
     # name by geometry (the flags of tools/run_configs.sh describe BASELINE configs too)
     by_geometry = {(v["sample_rate"], v["nperseg"], v["window"], v["samples"], v["trains"]): k for k, v in WORKLOADS.items()}
     w["name"] = by_geometry.get((w["sample_rate"], w["nperseg"], w["window"], w["samples"], w["trains"]), "custom")
+    if getattr(args, "lanes", 0) is None:
+        args.lanes = 2 if w["nperseg"] <= 512 else 1
     return w
 
 
