@@ -891,13 +891,15 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length does not fit the planning tiles at this nperseg");
         }
         h->runfilter_ok = fits && (cfg->mode == RT_MODE_RUNFILTER || cfg->mode == RT_MODE_AUTO);
-        if (h->runfilter_ok && cfg->mode == RT_MODE_AUTO && h->prefilter_ok) {
-            // a level between the chunk-bit pre-filter and the dense path (noise far over the absolute threshold: every chunk
-            // bit set, while SNR-aware cell bits stay selective) -- optional: only where its scratch is a small part of
-            // what is free (two slots of threshold bits + kept cells + segment lists + chunk minima)
+        if (h->runfilter_ok && cfg->mode == RT_MODE_AUTO) {
+            // In AUTO mode the level is optional -- the only one between the sparse and the dense path at the reference's
+            // default geometry, the one above the chunk bits elsewhere (noise far over the absolute threshold: every chunk
+            // bit set, while SNR-aware cell bits stay selective): its scratch (two slots of threshold bits + kept cells +
+            // segment lists + chunk minima) is taken where it is a small part of what is free -- at most half where it is
+            // the only middle level, an eighth where the chunk bits exist -- and AUTO does without it otherwise.
             const size_t per_slot = (size_t)cfg->n_streams * std::max(h->max_seg, 1) * (size_t)(h->LG * 4 + 4) + (size_t)cfg->n_streams * h->N * 4;
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)kSlots * per_slot > free_b / 8) h->runfilter_ok = false;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)kSlots * per_slot > free_b / (h->prefilter_ok ? 8 : 2)) h->runfilter_ok = false;
         }
     }
     if (((long long)h->N << key_tbits(std::max(h->max_seg, 2))) > 0x100000000ll) {
