@@ -77,6 +77,14 @@ def test_bench_workloads_follow_baseline_configs():
     assert (w["name"], w["samples"]) == ("config4", 524288)
     w = bench.resolve_workload(ns(nperseg=512), 1)
     assert w["name"] == "custom"
+    # lanes per GPU when the caller does not say: two up to nperseg 512, one where the scans are persistent grids
+    for workload, want in (("config2", 2), ("config4", 2), ("config3", 1), ("config5", 1)):
+        a = ns(workload=workload, lanes=None)
+        bench.resolve_workload(a, 1)
+        assert a.lanes == want, (workload, a.lanes)
+    a = ns(workload="config3", lanes=2)
+    bench.resolve_workload(a, 1)
+    assert a.lanes == 2
 
 
 def test_pmc_traffic_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
