@@ -385,19 +385,11 @@ int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
     return RT_OK;
 }
 
-// the level above / below `mode` in AUTO's order SPARSE < PREFILTER (chunk bits, where the geometry allows it) < RUNFILTER
-// (exact, where its scratch exists) < DENSE
-int level_rank(int mode) { return mode == RT_MODE_SPARSE ? 0 : mode == RT_MODE_PREFILTER ? 1 : mode == RT_MODE_RUNFILTER ? 2 : 3; }
-int level_up(const rt_handle *h, int mode) {
-    if (mode == RT_MODE_SPARSE && h->prefilter_ok) return RT_MODE_PREFILTER;
-    if (level_rank(mode) < 2 && h->runfilter_ok) return RT_MODE_RUNFILTER;
-    return RT_MODE_DENSE;
-}
-int level_down(const rt_handle *h, int mode) {
-    if (mode == RT_MODE_DENSE && h->runfilter_ok) return RT_MODE_RUNFILTER;
-    if (level_rank(mode) > 1 && h->prefilter_ok) return RT_MODE_PREFILTER;
-    return RT_MODE_SPARSE;
-}
+// the level above / below `mode` in AUTO's order (rt_core.h: level_up / level_down / level_rank)
+static_assert(kAutoDense == RT_MODE_DENSE && kAutoSparse == RT_MODE_SPARSE && kAutoPrefilter == RT_MODE_PREFILTER && kAutoRunfilter == RT_MODE_RUNFILTER,
+              "rt_core.h mirrors rt_mode");
+int level_up(const rt_handle *h, int mode) { return level_up(AutoLevels{h->prefilter_ok, h->runfilter_ok}, mode); }
+int level_down(const rt_handle *h, int mode) { return level_down(AutoLevels{h->prefilter_ok, h->runfilter_ok}, mode); }
 
 template <int MODE>
 void launch_scan(rt_handle *h, const StftParams &sp, int blocks, bool u8) {
@@ -1235,15 +1227,10 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
                 --h->dense_sticky;
             } else {
                 c.mode_used = level_down(h, h->auto_level);
-                // (no probe, no back-off where the last count rules the level below out: the next call looks again)
-                if (c.mode_used == RT_MODE_SPARSE && h->auto_level != RT_MODE_SPARSE && h->abs_hot_valid &&
-                    (uint64_t)h->abs_hot_seen > (uint64_t)kBuckets * (uint64_t)h->hot_cap)
-                    c.mode_used = h->auto_level;
-                // ... and the chunk-bit level needs chunks of L cells that do NOT all pass the absolute threshold: with a
-                // share q of the cells over it a chunk bit is set with probability q^L in each of nperseg bins (q = 3/4,
-                // L = 32, 256 bins: 2.6 % of the chunks), beyond that every chunk is kept
-                if (c.mode_used == RT_MODE_PREFILTER && h->auto_level == RT_MODE_RUNFILTER && h->abs_hot_valid && T > 0 &&
-                    (uint64_t)h->abs_hot_seen * 4u > 3u * (uint64_t)T * (uint64_t)h->N)
+                // (no probe, no back-off where the last count rules the level below out -- rt_core.h: probe_ruled_out; the next
+                // call looks again)
+                if (probe_ruled_out(c.mode_used, h->auto_level, h->abs_hot_valid, h->abs_hot_seen, (uint64_t)kBuckets * (uint64_t)h->hot_cap,
+                                    (uint64_t)T * (uint64_t)h->N))
                     c.mode_used = h->auto_level;
                 // one probe at a time: the calls enqueued before this one's verdict is in (the caller may keep a slot's
                 // worth of calls in flight) stay on the handle's level instead of each paying for a failed probe

@@ -41,6 +41,38 @@ struct DetectParams {
     double max_d;         // seconds
 };
 
+// ---- RT_MODE_AUTO's levels (host-side bookkeeping of rt_analyze.hip; here so that the CPU suite can test it) ----
+// Order: sparse < chunk-bit pre-filter (where the geometry allows it) < exact pre-filter (where its scratch exists) < dense.
+// The mode numbers are rt_mode's (include/rt_analyze.h).
+enum : int { kAutoDense = 1, kAutoSparse = 2, kAutoPrefilter = 3, kAutoRunfilter = 4 };
+struct AutoLevels {
+    bool prefilter_ok;  // the chunk-bit pre-filter exists at this geometry
+    bool runfilter_ok;  // the exact pre-filter exists (and its scratch is allocated)
+};
+RT_HD int level_rank(int mode) { return mode == kAutoSparse ? 0 : mode == kAutoPrefilter ? 1 : mode == kAutoRunfilter ? 2 : 3; }
+RT_HD int level_up(AutoLevels a, int mode) {
+    if (mode == kAutoSparse && a.prefilter_ok) return kAutoPrefilter;
+    if (level_rank(mode) < 2 && a.runfilter_ok) return kAutoRunfilter;
+    return kAutoDense;
+}
+RT_HD int level_down(AutoLevels a, int mode) {
+    if (mode == kAutoDense && a.runfilter_ok) return kAutoRunfilter;
+    if (level_rank(mode) > 1 && a.prefilter_ok) return kAutoPrefilter;
+    return kAutoSparse;
+}
+// Is a probe of `target` (= level_down of the handle's level) pointless?  `abs_hot` = the most cells at or above the
+// absolute threshold any stream had in the last call a pre-filter level analysed (valid: there was one):
+//   * the sparse lists hold `list_cells` (16 buckets x hot_capacity) cells per stream -- more than that cannot fit;
+//   * the chunk-bit level needs chunks of L cells that do NOT all pass the absolute threshold: with a share q of the cells
+//     over it a chunk bit is set with probability q^L in each of nperseg bins (q = 3/4, L = 32, 256 bins: 2.6 % of the
+//     chunks), beyond that every chunk is kept.
+RT_HD bool probe_ruled_out(int target, int level, bool valid, uint64_t abs_hot, uint64_t list_cells, uint64_t cells_per_stream) {
+    if (!valid || target == level) return false;
+    if (target == kAutoSparse) return abs_hot > list_cells;
+    if (target == kAutoPrefilter && level == kAutoRunfilter) return cells_per_stream > 0 && abs_hot * 4u > 3u * cells_per_stream;
+    return false;
+}
+
 // times[k] of scipy: arange(N/2, B - N/2 + 1, N) / float(fs)
 RT_HD double seg_time(int32_t k, int32_t nperseg, double fs) {
     return ((double)nperseg * 0.5 + (double)k * (double)nperseg) / fs;

@@ -85,4 +85,12 @@ int hc_extract(const float *spec, int n_seg, int n_bins, const float *last, int 
     return n;
 }
 
+// RT_MODE_AUTO's level bookkeeping (rt_core.h)
+int hc_level_up(int prefilter_ok, int runfilter_ok, int mode) { return level_up(AutoLevels{prefilter_ok != 0, runfilter_ok != 0}, mode); }
+int hc_level_down(int prefilter_ok, int runfilter_ok, int mode) { return level_down(AutoLevels{prefilter_ok != 0, runfilter_ok != 0}, mode); }
+int hc_level_rank(int mode) { return level_rank(mode); }
+int hc_probe_ruled_out(int target, int level, int valid, unsigned long long abs_hot, unsigned long long list_cells, unsigned long long cells_per_stream) {
+    return probe_ruled_out(target, level, valid != 0, abs_hot, list_cells, cells_per_stream) ? 1 : 0;
+}
+
 }  // extern "C"

@@ -119,3 +119,39 @@ def test_bounded_tail_is_exact(hc, i):
     k = hc.hc_tail_cols(256, float(c["kwargs"]["sample_rate"]), p.signal_max_duration)
     cut, _ = _run_hostcheck(hc, c, tail_cols=k)
     assert full.tobytes() == cut.tobytes()
+
+
+def test_auto_levels_form_a_ladder(hc):
+    """RT_MODE_AUTO's level bookkeeping (rt_core.h: level_up / level_down / level_rank): sparse < chunk bits < exact <
+    dense, the middle levels only where they exist; up and down are inverse on the levels that exist."""
+    D, S, P, R = _native.RT_MODE_DENSE, _native.RT_MODE_SPARSE, _native.RT_MODE_PREFILTER, _native.RT_MODE_RUNFILTER
+    assert [hc.hc_level_rank(m) for m in (S, P, R, D)] == [0, 1, 2, 3]
+    for pre in (0, 1):
+        for run in (0, 1):
+            ladder = [S] + ([P] if pre else []) + ([R] if run else []) + [D]
+            for lo, hi in zip(ladder, ladder[1:]):
+                assert hc.hc_level_up(pre, run, lo) == hi, (pre, run, lo)
+                assert hc.hc_level_down(pre, run, hi) == lo, (pre, run, hi)
+            assert hc.hc_level_up(pre, run, D) == D and hc.hc_level_down(pre, run, S) == S
+            # a level that does not exist at this geometry is never proposed
+            for m in (S, P, R, D):
+                assert hc.hc_level_up(pre, run, m) in ladder and hc.hc_level_down(pre, run, m) in ladder
+
+
+def test_probes_that_cannot_succeed_are_ruled_out(hc):
+    """rt_core.h: probe_ruled_out -- the sparse level while a stream has more cells over the absolute threshold than
+    its lists hold; the chunk-bit level from the exact one while more than 3/4 of a stream's cells pass that threshold;
+    nothing without a count, nothing for other moves."""
+    D, S, P, R = _native.RT_MODE_DENSE, _native.RT_MODE_SPARSE, _native.RT_MODE_PREFILTER, _native.RT_MODE_RUNFILTER
+    hc.hc_probe_ruled_out.argtypes = [C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]
+    lists, cells = 16 * 1024, 1171 * 256
+    assert hc.hc_probe_ruled_out(S, R, 1, lists + 1, lists, cells) == 1
+    assert hc.hc_probe_ruled_out(S, P, 1, lists + 1, lists, cells) == 1
+    assert hc.hc_probe_ruled_out(S, R, 1, lists, lists, cells) == 0       # exactly full still fits
+    assert hc.hc_probe_ruled_out(S, R, 0, 10 * lists, lists, cells) == 0  # no count yet
+    assert hc.hc_probe_ruled_out(S, S, 1, 10 * lists, lists, cells) == 0  # not a probe
+    assert hc.hc_probe_ruled_out(P, R, 1, 3 * cells // 4 + 1, lists, cells) == 1
+    assert hc.hc_probe_ruled_out(P, R, 1, 3 * cells // 4, lists, cells) == 0
+    assert hc.hc_probe_ruled_out(P, R, 1, cells, lists, 0) == 0           # an empty call
+    assert hc.hc_probe_ruled_out(R, D, 1, cells, lists, cells) == 0       # the dense level keeps no count: always probes
+    assert hc.hc_probe_ruled_out(P, D, 1, cells, lists, cells) == 0
