@@ -442,7 +442,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         }
         const uint32_t *prev = h->slot[h->minsum_slot].d_chunk_min;
         hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, prev, h->d_thr_bin, h->d_thr_nat, S, h->R3,
-                           h->L, h->cfg.snr_threshold);
+                           h->L * minsum_group(h->L, h->GPW), h->cfg.snr_threshold);
         }
     }
     if (sl.d_chunk_min && !second_pass_only) {

@@ -73,6 +73,16 @@ RT_HD bool probe_ruled_out(int target, int level, bool valid, uint64_t abs_hot, 
     return false;
 }
 
+// Chunks per "quiet level" sample of the exact pre-filter's per-bin thresholds (make_bin_thresholds): the quietest sum
+// over `g` consecutive complete chunks of a workgroup's item, g the smallest power of two with g * L >= 32 segments (at
+// most the item's gpw chunks) -- a small batch runs chunks of 4 segments, and the minimum over hundreds of 4-segment
+// sums of exponentially distributed noise lies at a tenth of the mean, where the minimum over 32-segment sums lies at 0.55.
+RT_HD int minsum_group(int L, int gpw) {
+    int g = 1;
+    while (g * L < 32 && g * 2 <= gpw) g *= 2;
+    return g;
+}
+
 // times[k] of scipy: arange(N/2, B - N/2 + 1, N) / float(fs)
 RT_HD double seg_time(int32_t k, int32_t nperseg, double fs) {
     return ((double)nperseg * 0.5 + (double)k * (double)nperseg) / fs;

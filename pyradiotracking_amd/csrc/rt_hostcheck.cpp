@@ -93,4 +93,6 @@ int hc_probe_ruled_out(int target, int level, int valid, unsigned long long abs_
     return probe_ruled_out(target, level, valid != 0, abs_hot, list_cells, cells_per_stream) ? 1 : 0;
 }
 
+int hc_minsum_group(int L, int gpw) { return minsum_group(L, gpw); }
+
 }  // extern "C"

@@ -83,7 +83,7 @@ struct StftParams {
     const int32_t *seg_count;
     uint32_t *abs_hot;       // [S] (+ word [S]: their maximum, by the planning kernel), or null: MODE 4 / 6 add the stream's cells at or above the
                              // absolute threshold -- what the sparse lists would have to hold at least (AUTO skips probes that cannot succeed)
-    uint32_t *chunk_min;     // [S][N] float bits, or null: per bin the smallest sum of P over a complete chunk of this call (atomicMin;
+    uint32_t *chunk_min;     // [S][N] float bits, or null: per bin the smallest sum of P over a complete chunk (group of chunks: minsum_group) of this call (atomicMin;
                              // the host presets 0x7f7f7f7f) -- the quiet level of the bin, for the next call's thr_bin (make_bin_thresholds)
     const float *thr_bin;    // MODE 6, or null: [S][LG][16] a second, per-bin threshold in lane order; a cell's bit is set only if it passes both
 #ifdef RT_STAMPS
@@ -1178,12 +1178,21 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             for (int gg = 0; gg < GPW; ++gg) sum += part[gg * N + bin];
             dst[bin] = sum;
             if (p.chunk_min) {
-                // the quietest complete chunk of the bin so far (positive floats order like their bits)
-                float mn = 3.0e38f;
+                // the quietest complete run of >= 32 segments of the bin so far: a chunk, or a group of consecutive chunks
+                // where chunks are shorter (rt_core.h: minsum_group; positive floats order like their bits)
+                const int grp = minsum_group(L, GPW);
+                float mn = 3.0e38f, run = 0.f;
+                bool whole = true;
 #pragma unroll
                 for (int gg = 0; gg < GPW; ++gg) {
                     const int ch = cb * GPW + gg;
-                    if (ch < p.chunks && (ch + 1) * L <= T) mn = fminf(mn, part[gg * N + bin]);
+                    whole = whole && (ch < p.chunks && (ch + 1) * L <= T);
+                    run += part[gg * N + bin];
+                    if (((gg + 1) & (grp - 1)) == 0) {
+                        if (whole) mn = fminf(mn, run);
+                        run = 0.f;
+                        whole = true;
+                    }
                 }
                 if (mn < 3.0e38f) atomicMin(&p.chunk_min[(int64_t)s * N + bin], __float_as_uint(mn));
             }
@@ -1407,12 +1416,13 @@ __device__ __forceinline__ int bin_of_rt(int R3, int lt, int r) {
 // Per-bin thresholds for the exact pre-filter's bits (MODE 6), from the PREVIOUS call's chunk minima.  The reference's
 // predicate is `!(P < thr) && !(P / row_mean < snr)` (analyze.py:370, 378); with the noise floor over the absolute
 // threshold the first test says nothing and the second decides -- but the row mean of a buffer is known only after its
-// scan.  The quietest complete chunk of the previous buffer gives a lower bound that survives tags coming and going
-// (a pulse sits in one or two chunks of dozens): theta = snr * (smallest chunk sum / L) is about 0.55 * snr * (noise mean)
-// for stationary noise.  A cell passes the full predicate only if it passes `P >= theta` -- PROVIDED theta <= snr * (this
+// scan.  The quietest complete chunk of the previous buffer (where chunks are shorter than 32 segments: the quietest group
+// of consecutive chunks that makes up 32, rt_core.h: minsum_group; `L` below is that length) gives a lower bound that
+// survives tags coming and going (a pulse sits in one or two chunks of dozens): theta = snr * (smallest sum / L) is about
+// 0.55 * snr * (noise mean) for stationary noise.  A cell passes the full predicate only if it passes `P >= theta` -- PROVIDED theta <= snr * (this
 // buffer's row mean), which check_bin_thresholds verifies after the scan; a stream that fails it (its floor dropped by
-// more than ~2.5 dB from one buffer to the next) is analysed again on the dense path.  No estimate (first call, buffers
-// shorter than a chunk): theta = 0, the bits are the absolute threshold's alone.
+// more than ~2.5 dB from one buffer to the next) is analysed again (rt_fetch: a few streams dense, else the call on its own
+// row means).  No estimate (first call, buffers shorter than a chunk): theta = 0, the bits are the absolute threshold's alone.
 __global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk_min_prev, float *thr_bin /* lane order */, float *thr_nat /* [S][N] */,
                                                           int n_streams, int R3, int L, float snr) {
     const int N = 256 * R3, LG = 16 * R3;

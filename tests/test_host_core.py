@@ -155,3 +155,12 @@ def test_probes_that_cannot_succeed_are_ruled_out(hc):
     assert hc.hc_probe_ruled_out(P, R, 1, cells, lists, 0) == 0           # an empty call
     assert hc.hc_probe_ruled_out(R, D, 1, cells, lists, cells) == 0       # the dense level keeps no count: always probes
     assert hc.hc_probe_ruled_out(P, D, 1, cells, lists, cells) == 0
+
+
+def test_quiet_level_samples_cover_at_least_32_segments(hc):
+    """rt_core.h: minsum_group -- chunks per sample of the exact pre-filter's quiet-level estimate: the smallest power of
+    two that makes 32 segments, at most the chunks of a workgroup's item."""
+    hc.hc_minsum_group.argtypes = [C.c_int, C.c_int]
+    assert [hc.hc_minsum_group(L, 16) for L in (4, 8, 16, 32, 71)] == [8, 4, 2, 1, 1]
+    assert [hc.hc_minsum_group(L, 4) for L in (4, 8, 24, 37)] == [4, 4, 2, 1]
+    assert hc.hc_minsum_group(4, 1) == 1
