@@ -90,9 +90,13 @@ __global__ __launch_bounds__(256, WPS) void ksq(const cf *iq, const float *windo
     constexpr int kSegRows = PPL * kRow + (SPW > 1 ? 32 : 0);  // (the second segment's rows start 32 banks off the first's)
     __shared__ __attribute__((aligned(16))) float xch[4][SPW * kSegRows];
     __shared__ __attribute__((aligned(16))) cf ta[16 * PPL];
+    constexpr bool WIN_LDS = (PPL == 32);  // (at 4096 points the table needs the 8-wave workgroup of k4096w)
+    __shared__ __attribute__((aligned(16))) float win[WIN_LDS ? N : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = lane % PPL, sw = lane / PPL;
     for (int i = threadIdx.x; i < 16 * PPL; i += 256) ta[i] = tw_a[i];
+    if constexpr (WIN_LDS)
+        for (int i = threadIdx.x; i < N; i += 256) win[i] = window_t[i];
     __syncthreads();
     cf tb[C];
 #pragma unroll
@@ -109,18 +113,37 @@ __global__ __launch_bounds__(256, WPS) void ksq(const cf *iq, const float *windo
         if (seg >= n_seg_total) seg = n_seg_total - 1;  // (wave-uniform control flow: the last wave re-reads the last segment)
         const cf *src = iq + seg * N + l;
         cf v[PPL];
+        if constexpr (WIN_LDS) {
+            // loads in the order the first pass consumes them (m = n0 + 2 j), window from LDS: the first 16-point transform
+            // runs while the second half of the segment is still arriving
 #pragma unroll
-        for (int m = 0; m < PPL; ++m) {
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            const f2 q = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(src + PPL * m));
-            v[m] = cf{q.x, q.y};
-        }
-        const f4 *wt = reinterpret_cast<const f4 *>(window_t + l * PPL);
+            for (int n0 = 0; n0 < 2; ++n0)
 #pragma unroll
-        for (int q = 0; q < PPL / 4; ++q) {
-            const f4 w4 = wt[q];
-            v[4 * q] = cscale(v[4 * q], w4.x); v[4 * q + 1] = cscale(v[4 * q + 1], w4.y);
-            v[4 * q + 2] = cscale(v[4 * q + 2], w4.z); v[4 * q + 3] = cscale(v[4 * q + 3], w4.w);
+                for (int j = 0; j < 16; ++j) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const int m = n0 + 2 * j;
+                    const f2 q = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(src + PPL * m));
+                    v[m] = cf{q.x, q.y};
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n0 = 0; n0 < 2; ++n0)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[n0 + 2 * j] = cscale(v[n0 + 2 * j], win[l * PPL + n0 + 2 * j]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < PPL; ++m) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 q = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(src + PPL * m));
+                v[m] = cf{q.x, q.y};
+            }
+            const f4 *wt = reinterpret_cast<const f4 *>(window_t + l * PPL);
+#pragma unroll
+            for (int q = 0; q < PPL / 4; ++q) {
+                const f4 w4 = wt[q];
+                v[4 * q] = cscale(v[4 * q], w4.x); v[4 * q + 1] = cscale(v[4 * q + 1], w4.y);
+                v[4 * q + 2] = cscale(v[4 * q + 2], w4.z); v[4 * q + 3] = cscale(v[4 * q + 3], w4.w);
+            }
         }
         dft_lane<PPL>(v);  // over m: lane n1 = l now holds A[n1][ka], ka = register index
         // exchange inside the segment's PPL lanes: lane ka gets A[n1][ka] for all n1 -- real parts, then imaginary parts
@@ -172,6 +195,125 @@ __global__ __launch_bounds__(256, WPS) void ksq(const cf *iq, const float *windo
 #pragma unroll
     for (int kb = 0; kb < PPL; ++kb) dst[l + PPL * kb] = acc[kb];
     if (n_hot) atomicAdd(hits, n_hot);
+}
+
+// Variant for 4096 points: ONE workgroup of eight waves per CU (2 per SIMD) so that the window table (16 KiB) fits LDS next to
+// the eight exchange areas: the window multiply then does not queue behind the segment's own loads (vector-memory loads
+// return in order), and with the loads issued in the order the first pass consumes them (m = n0 + 4 j, n0 = 0..3) the
+// first 16-point transforms run while the rest of the segment is still arriving.
+__global__ __launch_bounds__(512, 1) void k4096w(const cf *iq, const float *window_t /* [lane][64] */, const cf *tw_a, const cf *tw_b, float *psum,
+                                                 unsigned *hits, int steps_per_wave, long n_seg_total, float thr) {
+    constexpr int PPL = 64, N = 4096, C = 4, kRow = 68;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *const xch = lds;                                   // [8][64 * kRow]
+    cf *const ta = reinterpret_cast<cf *>(lds + 8 * 64 * kRow);  // [16][64]
+    float *const win = lds + 8 * 64 * kRow + 2 * 16 * 64;     // [64 lanes][64]: lane-major, read as float4
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 16 * 64; i += 512) ta[i] = tw_a[i];
+    for (int i = threadIdx.x; i < 4096; i += 512) win[i] = window_t[i];
+    __syncthreads();
+    cf tb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) tb[c] = tw_b[lane * C + c];
+    float *const rows = xch + wave * 64 * kRow;
+    const long wave_id = (long)blockIdx.x * 8 + wave;
+    float acc[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) acc[i] = 0.f;
+    unsigned n_hot = 0;
+    const long seg0 = wave_id * steps_per_wave;
+    for (int it = 0; it < steps_per_wave; ++it) {
+        long seg = seg0 + it;
+        if (seg >= n_seg_total) seg = n_seg_total - 1;
+        const cf *src = iq + seg * N + lane;
+        cf v[PPL];
+#pragma unroll
+        for (int n0 = 0; n0 < 4; ++n0)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const int m = n0 + 4 * j;
+                const f2 q = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(src + PPL * m));
+                v[m] = cf{q.x, q.y};
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        const f4 *wt = reinterpret_cast<const f4 *>(win + lane * 64);
+#pragma unroll
+        for (int n0 = 0; n0 < 4; ++n0) {
+            // window of this quarter (w[lane + 64 (n0 + 4 j)]: table order [lane][n0][j] would be nicer; scalar reads here)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = n0 + 4 * j;
+                v[m] = cscale(v[m], win[lane * 64 + m]);
+            }
+        }
+        (void)wt;
+        dft_lane<PPL>(v);
+        float re[PPL];
+#pragma unroll
+        for (int ka = 0; ka < PPL; ++ka) rows[ka * kRow + lane] = v[ka].x;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < PPL / 4; ++q) {
+            const f4 r4 = reinterpret_cast<const f4 *>(rows + lane * kRow)[q];
+            re[4 * q] = r4.x; re[4 * q + 1] = r4.y; re[4 * q + 2] = r4.z; re[4 * q + 3] = r4.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ka = 0; ka < PPL; ++ka) rows[ka * kRow + lane] = v[ka].y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < PPL / 4; ++q) {
+            const f4 r4 = reinterpret_cast<const f4 *>(rows + lane * kRow)[q];
+            v[4 * q] = cf{re[4 * q], r4.x}; v[4 * q + 1] = cf{re[4 * q + 1], r4.y};
+            v[4 * q + 2] = cf{re[4 * q + 2], r4.z}; v[4 * q + 3] = cf{re[4 * q + 3], r4.w};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const cf wa = ta[d * PPL + lane];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (c == 0 && d == 0) continue;
+                cf x = v[c + C * d];
+                if (d) x = cmul(x, wa);
+                if (c) x = cmul(x, tb[c]);
+                v[c + C * d] = x;
+            }
+        }
+        dft_lane<PPL>(v);
+        float mx = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < PPL; ++kb) {
+            const float P = __builtin_fmaf(v[kb].x, v[kb].x, v[kb].y * v[kb].y);
+            acc[kb] += P;
+            mx = __builtin_fmaxf(mx, P);
+        }
+        if (!(mx < thr)) ++n_hot;
+    }
+    float *dst = psum + wave_id * N;
+#pragma unroll
+    for (int kb = 0; kb < PPL; ++kb) dst[lane + PPL * kb] = acc[kb];
+    if (n_hot) atomicAdd(hits, n_hot);
+}
+
+static void run_w(const cf *iq, const float *wt, const cf *ta, const cf *tb, float *psum, unsigned *hits, long n_seg, int spw) {
+    const size_t lds_bytes = (size_t)(8 * 64 * 68 + 2 * 16 * 64 + 4096) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k4096w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        printf("k4096w: %zu bytes of LDS refused\n", lds_bytes);
+        return;
+    }
+    const long waves = (n_seg + spw - 1) / spw;
+    const int blocks = (int)((waves + 7) / 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) k4096w<<<blocks, 512, lds_bytes>>>(iq, wt, ta, tb, psum, hits, spw, n_seg, 1e30f);
+    hipEventRecord(e0);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) k4096w<<<blocks, 512, lds_bytes>>>(iq, wt, ta, tb, psum, hits, spw, n_seg, 1e30f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("nperseg 4096, window in LDS, loads in first-pass order, one 8-wave workgroup per CU, %3d segments per wave (%d workgroups): %.3f ms  %.2f TB/s  (%s)\n", spw, blocks, ms,
+           (double)n_seg * 4096 * 8 / (ms * 1e-3) * 1e-12, hipGetErrorString(hipGetLastError()));
 }
 
 // reference: one segment on the host in double precision
@@ -248,6 +390,18 @@ static void shape(long S, long T, const char *what) {
     if constexpr (PPL == 64) {
         for (int spw : {16, 32, 64}) run<PPL, 2>(iq, wt, ta, tb, psum, hits, n_seg, spw);
         run<PPL, 1>(iq, wt, ta, tb, psum, hits, n_seg, 32);
+        // correctness of the variant, then its timing
+        hipMemset(psum, 0, N * 4);
+        {
+            const size_t lds_bytes = (size_t)(8 * 64 * 68 + 2 * 16 * 64 + 4096) * sizeof(float);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k4096w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            k4096w<<<1, 512, lds_bytes>>>(iq, wt, ta, tb, psum, hits, 1, 1, 1e30f);
+            hipMemcpy(got.data(), psum, N * 4, hipMemcpyDeviceToHost);
+            double worst2 = 0;
+            for (int k = 0; k < N; ++k) worst2 = std::max(worst2, fabs(got[k] - P[k]) / (P[k] + 1e-3));
+            printf("variant, one segment against a float64 DFT: worst relative power difference %.2e (%s)\n", worst2, hipGetErrorString(hipGetLastError()));
+        }
+        for (int spw : {16, 32, 64}) run_w(iq, wt, ta, tb, psum, hits, n_seg, spw);
     } else {
         for (int spw : {16, 32, 64}) run<PPL, 3>(iq, wt, ta, tb, psum, hits, n_seg, spw);
         for (int spw : {32}) run<PPL, 2>(iq, wt, ta, tb, psum, hits, n_seg, spw);
