@@ -65,6 +65,66 @@ __global__ __launch_bounds__(256, 3) void k(const float *src, float *out, int st
     if (t == 123.456f) out[wave * 64 + lane] = t + pad[lane];
 }
 
+// the scan's address pattern at nperseg 256: the four 16-lane groups of a wave walk four different chunks (32 segments of 2 KiB =
+// 64 KiB apart), so a wave's 8 KiB per step are four 2 KiB pieces; 16 loads of 8 B per lane, each instruction = one 128-byte
+// line per group
+template <int V>
+__global__ __launch_bounds__(256, 3) void k_scanlike(const float *src, float *out, int steps) {
+    extern __shared__ float pad[];
+    constexpr int NF = 32;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave w owns four chunks: chunk c = 4 w + grp, each `steps` segments of 2 KiB
+    const char *base = reinterpret_cast<const char *>(src) + ((size_t)wave * 4 + grp) * steps * 2048 + l16 * 8;
+    float cur[NF], nxt[NF];
+    auto request = [&](int step) {
+        const char *p = base + (size_t)step * 2048;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p + m * 128));
+            nxt[2 * m] = v.x; nxt[2 * m + 1] = v.y;
+        }
+    };
+    request(steps - 1);  // (the scan walks a chunk down from its latest segment)
+    float acc[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[i] = 0.f;
+    for (int s = steps - 1; s >= 0; --s) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) cur[i] = nxt[i];
+        request(s > 0 ? s - 1 : 0);
+#pragma unroll
+        for (int r = 0; r < V / NF; ++r)
+#pragma unroll
+            for (int i = 0; i < NF; ++i) acc[i] = __builtin_fmaf(acc[i], 0.999f, cur[i]);
+        if constexpr (V == 0) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) acc[i] += cur[i];
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) t += acc[i];
+    if (t == 123.456f) out[wave * 64 + lane] = t + pad[lane];
+}
+
+template <int V>
+void run_scanlike(const float *src, float *out, size_t bytes, int steps) {
+    const int waves = (int)(bytes / ((size_t)steps * 8192));
+    const int blocks = waves / 4;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_scanlike<V>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) k_scanlike<V><<<blocks, 256, 48 * 1024>>>(src, out, steps);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) k_scanlike<V><<<blocks, 256, 48 * 1024>>>(src, out, steps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const double moved = (double)blocks * 4 * steps * 8192;
+    printf("scan-like addresses (4 x 2 KiB pieces per wave and step, %d KiB apart, walked downwards), %3d FMAs per step, %2d steps per workgroup: %.3f ms  %.2f TB/s\n",
+           steps * 2, V, steps, ms, moved / (ms * 1e-3) * 1e-12);
+}
+
 template <int WIDTH, int V, int SPLIT>
 void run(const float *src, float *out, size_t bytes) {
     const int steps = 64;
@@ -96,6 +156,9 @@ int main() {
     run<8, 1024, 1>(src, out, bytes); run<16, 1024, 1>(src, out, bytes);
     run<8, 768, 4>(src, out, bytes);  run<16, 768, 4>(src, out, bytes);
     run<8, 1024, 4>(src, out, bytes); run<16, 1024, 4>(src, out, bytes);
+    run_scanlike<0>(src, out, bytes, 32);   run_scanlike<768>(src, out, bytes, 32);
+    run_scanlike<0>(src, out, bytes, 64);   run_scanlike<768>(src, out, bytes, 64);
+    run_scanlike<0>(src, out, bytes, 128);  run_scanlike<768>(src, out, bytes, 128);
     hipFree(src); hipFree(out);
     return 0;
 }
