@@ -83,6 +83,16 @@ RT_HD int minsum_group(int L, int gpw) {
     return g;
 }
 
+// Factor on the quiet-level estimate when its samples are longer than 32 segments (chunks of 37 .. 71 segments at nperseg >= 1024).
+// The minimum over n samples of the mean of m exponentially distributed powers lies about 2 / sqrt(m) under the mean; the
+// thresholds must stay under snr x the NEXT buffer's row mean, and with long samples (few of them, each close to the mean) that
+// margin shrinks: 14 % at m = 128, where one bin in fifty failed the check in an experiment.  The factor puts every sample
+// length on the footing of m = 32 (0.55 - 0.65 x the mean, measured safe).
+RT_HD float minsum_margin(int m) {
+    if (m <= 32) return 1.0f;
+    return (1.0f - 2.0f / sqrtf(32.0f)) / (1.0f - 2.0f / sqrtf((float)m));
+}
+
 // times[k] of scipy: arange(N/2, B - N/2 + 1, N) / float(fs)
 RT_HD double seg_time(int32_t k, int32_t nperseg, double fs) {
     return ((double)nperseg * 0.5 + (double)k * (double)nperseg) / fs;

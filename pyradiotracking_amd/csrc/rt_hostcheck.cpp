@@ -94,5 +94,6 @@ int hc_probe_ruled_out(int target, int level, int valid, unsigned long long abs_
 }
 
 int hc_minsum_group(int L, int gpw) { return minsum_group(L, gpw); }
+double hc_minsum_margin(int m) { return (double)minsum_margin(m); }
 
 }  // extern "C"

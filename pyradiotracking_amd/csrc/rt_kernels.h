@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk
     float th = 0.f;
     if (chunk_min_prev) {
         const float mn = __uint_as_float(chunk_min_prev[(int64_t)s * N + bin]);
-        if (mn < 1.0e38f && mn == mn) th = snr * (mn / (float)L);
+        if (mn < 1.0e38f && mn == mn) th = snr * minsum_margin(L) * (mn / (float)L);
     }
     thr_bin[i] = th;
     thr_nat[(int64_t)s * N + bin] = th;

@@ -164,3 +164,13 @@ def test_quiet_level_samples_cover_at_least_32_segments(hc):
     assert [hc.hc_minsum_group(L, 16) for L in (4, 8, 16, 32, 71)] == [8, 4, 2, 1, 1]
     assert [hc.hc_minsum_group(L, 4) for L in (4, 8, 24, 37)] == [4, 4, 2, 1]
     assert hc.hc_minsum_group(4, 1) == 1
+
+
+def test_quiet_level_margin_normalises_long_samples(hc):
+    """rt_core.h: minsum_margin -- 1 up to 32 segments per sample, then the ratio that puts the expected minimum of longer
+    samples (chunks of 37 .. 71 segments at nperseg >= 1024) where that of 32-segment samples lies."""
+    hc.hc_minsum_margin.argtypes = [C.c_int]
+    hc.hc_minsum_margin.restype = C.c_double
+    assert hc.hc_minsum_margin(4) == 1.0 and hc.hc_minsum_margin(32) == 1.0
+    for m, want in ((37, 0.963), (71, 0.847), (128, 0.785)):
+        assert abs(hc.hc_minsum_margin(m) - want) < 2e-3, (m, hc.hc_minsum_margin(m))

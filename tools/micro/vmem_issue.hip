@@ -68,17 +68,21 @@ __global__ __launch_bounds__(256, 3) void k(const float *src, float *out, int st
 // the scan's address pattern at nperseg 256: the four 16-lane groups of a wave walk four different chunks (32 segments of 2 KiB =
 // 64 KiB apart), so a wave's 8 KiB per step are four 2 KiB pieces; 16 loads of 8 B per lane, each instruction = one 128-byte
 // line per group
-template <int V>
+// SEQ: the four groups take four CONSECUTIVE 2 KiB segments of one run instead (a wave's 8 KiB per step are contiguous, but every
+// load instruction still touches four lines 2 KiB apart) -- the pattern of an experiment with the scan kernel (EXPERIMENTS.md)
+template <int V, bool SEQ = false>
 __global__ __launch_bounds__(256, 3) void k_scanlike(const float *src, float *out, int steps) {
     extern __shared__ float pad[];
     constexpr int NF = 32;
     const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     // wave w owns four chunks: chunk c = 4 w + grp, each `steps` segments of 2 KiB
-    const char *base = reinterpret_cast<const char *>(src) + ((size_t)wave * 4 + grp) * steps * 2048 + l16 * 8;
+    const char *base = SEQ ? reinterpret_cast<const char *>(src) + (size_t)wave * steps * 8192 + (3 - grp) * 2048 + l16 * 8
+                           : reinterpret_cast<const char *>(src) + ((size_t)wave * 4 + grp) * steps * 2048 + l16 * 8;
+    const size_t step_bytes = SEQ ? 8192 : 2048;
     float cur[NF], nxt[NF];
     auto request = [&](int step) {
-        const char *p = base + (size_t)step * 2048;
+        const char *p = base + (size_t)step * step_bytes;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p + m * 128));
@@ -108,26 +112,29 @@ __global__ __launch_bounds__(256, 3) void k_scanlike(const float *src, float *ou
     if (t == 123.456f) out[wave * 64 + lane] = t + pad[lane];
 }
 
-template <int V>
+template <int V, bool SEQ = false>
 void run_scanlike(const float *src, float *out, size_t bytes, int steps) {
     const int waves = (int)(bytes / ((size_t)steps * 8192));
     const int blocks = waves / 4;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_scanlike<V>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_scanlike<V, SEQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) k_scanlike<V><<<blocks, 256, 48 * 1024>>>(src, out, steps);
+    for (int i = 0; i < 3; ++i) k_scanlike<V, SEQ><<<blocks, 256, 48 * 1024>>>(src, out, steps);
     hipEventRecord(e0);
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) k_scanlike<V><<<blocks, 256, 48 * 1024>>>(src, out, steps);
+    for (int i = 0; i < reps; ++i) k_scanlike<V, SEQ><<<blocks, 256, 48 * 1024>>>(src, out, steps);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     const double moved = (double)blocks * 4 * steps * 8192;
-    printf("scan-like addresses (4 x 2 KiB pieces per wave and step, %d KiB apart, walked downwards), %3d FMAs per step, %2d steps per workgroup: %.3f ms  %.2f TB/s\n",
-           steps * 2, V, steps, ms, moved / (ms * 1e-3) * 1e-12);
+    if (SEQ)
+        printf("four consecutive 2 KiB segments per wave and step (8 KiB contiguous, each instruction four lines 2 KiB apart), %3d FMAs per step, %2d steps per workgroup: %.3f ms  %.2f TB/s\n",
+               V, steps, ms, moved / (ms * 1e-3) * 1e-12);
+    else
+        printf("scan-like addresses (4 x 2 KiB pieces per wave and step, %d KiB apart, walked downwards), %3d FMAs per step, %2d steps per workgroup: %.3f ms  %.2f TB/s\n",
+               steps * 2, V, steps, ms, moved / (ms * 1e-3) * 1e-12);
 }
 
 template <int WIDTH, int V, int SPLIT>
-void run(const float *src, float *out, size_t bytes) {
-    const int steps = 64;
+void run(const float *src, float *out, size_t bytes, int steps = 64) {
     const int waves = (int)(bytes / ((size_t)steps * 8192));
     const int blocks = waves / 4;
     hipFuncSetAttribute(reinterpret_cast<const void *>(k<WIDTH, V, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
@@ -139,8 +146,8 @@ void run(const float *src, float *out, size_t bytes) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     const double moved = (double)blocks * 4 * steps * 8192;
-    printf("load width %2d B x %2d per step, %3d FMAs per step%s: %.3f ms  %.2f TB/s\n", WIDTH, 8192 / 64 / WIDTH, V,
-           SPLIT > 1 ? ", requests spread over the step in 4 parts" : "", ms, moved / (ms * 1e-3) * 1e-12);
+    printf("load width %2d B x %2d per step, %3d FMAs per step%s, %3d steps per workgroup: %.3f ms  %.2f TB/s\n", WIDTH, 8192 / 64 / WIDTH, V,
+           SPLIT > 1 ? ", requests spread over the step in 4 parts" : "", steps, ms, moved / (ms * 1e-3) * 1e-12);
 }
 
 int main() {
@@ -156,7 +163,9 @@ int main() {
     run<8, 1024, 1>(src, out, bytes); run<16, 1024, 1>(src, out, bytes);
     run<8, 768, 4>(src, out, bytes);  run<16, 768, 4>(src, out, bytes);
     run<8, 1024, 4>(src, out, bytes); run<16, 1024, 4>(src, out, bytes);
+    run<8, 768, 1>(src, out, bytes, 32);    run<8, 768, 1>(src, out, bytes, 128);  // contiguous, the workgroup lives of the rows below
     run_scanlike<0>(src, out, bytes, 32);   run_scanlike<768>(src, out, bytes, 32);
+    run_scanlike<0, true>(src, out, bytes, 32);   run_scanlike<768, true>(src, out, bytes, 32);
     run_scanlike<0>(src, out, bytes, 64);   run_scanlike<768>(src, out, bytes, 64);
     run_scanlike<0>(src, out, bytes, 128);  run_scanlike<768>(src, out, bytes, 128);
     hipFree(src); hipFree(out);
