@@ -196,6 +196,12 @@ int next_pow2(int v) {
 // queue in the dispatcher and find the counter exhausted.
 template <int MODE, bool U8, bool LIN>
 void launch_stft_lin(rt_handle *h, const StftParams &p, int items) {
+    if (scan_wave64(h->R3)) {
+        // nperseg 4096: one wave per segment, items drawn per wave; one 8-wave workgroup (all of a CU's LDS) per CU
+        const int wgs = std::min((items + kW64Waves - 1) / kW64Waves, h->n_cu);
+        hipLaunchKernelGGL((stft_scan64<MODE, U8, LIN>), dim3(wgs), dim3(kW64Block), 0, h->s_scan, p);
+        return;
+    }
     const int blk = scan_block(h->R3);
     // workgroups a CU holds: three waves per SIMD by registers (four for the leaner uint8 / RT_WG4 instantiations), and at
     // nperseg 256 twelve one-wave workgroups by LDS whatever the registers allow
@@ -208,7 +214,11 @@ void launch_stft_lin(rt_handle *h, const StftParams &p, int items) {
         case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
         case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
         case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+#if !RT_WAVE64_4096
         default: hipLaunchKernelGGL((stft_scan<16, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+#else
+        default: break;  // (nperseg 4096 is stft_scan64's, above)
+#endif
     }
 }
 
@@ -946,6 +956,16 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             const double ang = -two_pi * (double)((a * k1) % N) / (double)N;
             tw1[(size_t)a * 16 + k1] = cf{(float)std::cos(ang), (float)std::sin(ang)};
         }
+    if (scan_wave64(R3)) {
+        // stft_scan64: W_N^(ka n1) with n1 = c + 8 d as W^(8 ka d) (rows 0..6, d = 1..7) times W^(ka c) (rows 7..13, c = 1..7), lane ka
+        tw1.assign((size_t)kW64TwRows * 64, cf{1.f, 0.f});
+        for (int row = 0; row < 14; ++row)
+            for (int ka = 0; ka < 64; ++ka) {
+                const int e = row < 7 ? 8 * ka * (row + 1) : ka * (row - 6);
+                const double ang = -two_pi * (double)(e % N) / (double)N;
+                tw1[(size_t)row * 64 + ka] = cf{(float)std::cos(ang), (float)std::sin(ang)};
+            }
+    }
     for (int b = 0; b < R3; ++b)
         for (int q1 = 0; q1 < 16; ++q1) {
             // W_LG^(b q1), times the phase W16^(-s q1) that undoes the column rotation s = x1_rotation(b) of exchange 1
@@ -976,6 +996,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             std::vector<float> wt((size_t)N);
             for (int l = 0; l < LG; ++l)
                 for (int m = 0; m < 16; ++m) wt[(size_t)l * 16 + m] = ws[(size_t)l + (size_t)LG * m];
+            if (scan_wave64(R3)) {
+                // the order stft_scan64's lanes read it: 16-byte pieces [n0][jq][lane] holding the elements m = n0 + 4 (4 jq + e)
+                for (int n0 = 0; n0 < 4; ++n0)
+                    for (int jq = 0; jq < 4; ++jq)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e2 = 0; e2 < 4; ++e2)
+                                wt[(((size_t)n0 * 4 + jq) * 64 + l) * 4 + e2] = ws[(size_t)l + 64 * (size_t)(n0 + 4 * (4 * jq + e2))];
+            }
             RT_CREATE_HIP(hipMalloc(&h->d_window_t, sizeof(float) * N));
             RT_CREATE_HIP(hipMemcpy(h->d_window_t, wt.data(), sizeof(float) * N, hipMemcpyHostToDevice));
         }

@@ -203,5 +203,42 @@ __device__ __forceinline__ void dft_groups(C (&v)[16]) {
     }
 }
 
+// W64^k = exp(-2 pi i k / 64), k = 0 .. 47 (the exponents n0 * k' of the 64-point transform below), rounded once from double
+constexpr float kW64Re[48] = {1.0f, 0.99518472f, 0.980785251f, 0.956940353f, 0.923879504f, 0.881921291f, 0.831469595f, 0.773010433f, 0.707106769f, 0.634393275f, 0.555570245f, 0.471396744f, 0.382683426f, 0.290284663f, 0.195090324f, 0.0980171412f, 0.0f, -0.0980171412f, -0.195090324f, -0.290284663f, -0.382683426f, -0.471396744f, -0.555570245f, -0.634393275f, -0.707106769f, -0.773010433f, -0.831469595f, -0.881921291f, -0.923879504f, -0.956940353f, -0.980785251f, -0.99518472f, -1.0f, -0.99518472f, -0.980785251f, -0.956940353f, -0.923879504f, -0.881921291f, -0.831469595f, -0.773010433f, -0.707106769f, -0.634393275f, -0.555570245f, -0.471396744f, -0.382683426f, -0.290284663f, -0.195090324f, -0.0980171412f};
+constexpr float kW64Im[48] = {0.0f, -0.0980171412f, -0.195090324f, -0.290284663f, -0.382683426f, -0.471396744f, -0.555570245f, -0.634393275f, -0.707106769f, -0.773010433f, -0.831469595f, -0.881921291f, -0.923879504f, -0.956940353f, -0.980785251f, -0.99518472f, -1.0f, -0.99518472f, -0.980785251f, -0.956940353f, -0.923879504f, -0.881921291f, -0.831469595f, -0.773010433f, -0.707106769f, -0.634393275f, -0.555570245f, -0.471396744f, -0.382683426f, -0.290284663f, -0.195090324f, -0.0980171412f, 0.0f, 0.0980171412f, 0.195090324f, 0.290284663f, 0.382683426f, 0.471396744f, 0.555570245f, 0.634393275f, 0.707106769f, 0.773010433f, 0.831469595f, 0.881921291f, 0.923879504f, 0.956940353f, 0.980785251f, 0.99518472f};
+
+// 64-point DFT in place, natural order in and out:  n = n0 + 4*n', k = k' + 16*k0.
+// Four 16-point transforms over n' (inputs v[n0 + 4 j]: the quarter n0 of the registers -- a caller whose quarters arrive one
+// after the other transforms each as it comes and calls dft64_finish), twiddles W64^(n0 k'), sixteen 4-point transforms over n0.
+// dft64_finish: v[n0 + 4 k'] holds A[n0][k'], the 16-point transform of quarter n0.
+__device__ __forceinline__ void dft64_finish(cf (&v)[64]) {
+    cf t[64];
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+        cf a0 = v[4 * kp], a1 = v[1 + 4 * kp], a2 = v[2 + 4 * kp], a3 = v[3 + 4 * kp];
+        if (kp) {
+            a1 = (kp == 8) ? mul_w8_1(a1) : cmul_const(a1, kW64Re[kp], kW64Im[kp]);
+            a2 = (kp == 8) ? mul_mi(a2) : (kp == 4) ? mul_w8_1(a2) : (kp == 12) ? mul_w8_3(a2) : cmul_const(a2, kW64Re[2 * kp], kW64Im[2 * kp]);
+            a3 = (kp == 8) ? mul_w8_3(a3) : cmul_const(a3, kW64Re[3 * kp], kW64Im[3 * kp]);
+        }
+        dft4(a0, a1, a2, a3);
+        t[kp] = a0;  t[kp + 16] = a1;  t[kp + 32] = a2;  t[kp + 48] = a3;  // X[k' + 16 k0]
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = t[i];
+}
+__device__ __forceinline__ void dft64(cf (&v)[64]) {
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) {
+        cf a[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = v[n0 + 4 * j];
+        dft16(a);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[n0 + 4 * j] = a[j];  // A[n0][k' = j]
+    }
+    dft64_finish(v);
+}
+
 }  // namespace rt
 #endif

@@ -51,8 +51,9 @@ struct StftParams {
     int32_t blocks_per_stream;
     int32_t tail_cols;       // K
     const float *window;     // [N] window coefficients times sqrt(scale)
-    const float *window_t;   // nperseg 4096: the same in lane order, [LG][16]: element [lane][m] = window[lane + LG * m]
-    const cf *tw1;           // [LG][16]   W_N^(a*k1)
+    const float *window_t;   // nperseg 4096: the same in the order the lanes read it.  stft_scan64: [n0][jq][lane][e] = window[lane + 64 m],
+                             // m = n0 + 4 (4 jq + e) (16-byte pieces of the quarter n0 of a lane's 64 elements); stft_scan<16>: [lane][m] = window[lane + 256 m]
+    const cf *tw1;           // [LG][16]   W_N^(a*k1); stft_scan64: [16][64] rows 0..6 W_N^(8 l d), d = 1..7, rows 7..13 W_N^(l c), c = 1..7
     const cf *tw2;           // [R3][16]   W_LG^(b*q1)
     float scale;
     float thr;
@@ -1404,6 +1405,13 @@ __global__ __launch_bounds__(256) void max_abs_hot(uint32_t *abs_hot, int n_stre
     if (threadIdx.x == 0) *host_max = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
 }
 
+// Which kernel serves nperseg 4096: stft_scan64 (rt_scan64.h: one wave per segment, 64 bins per lane) -- the default -- or,
+// with -DRT_WAVE64_4096=0, the four-waves-per-segment instantiation stft_scan<16, ...> it replaced (kept for A/B runs).
+#ifndef RT_WAVE64_4096
+#define RT_WAVE64_4096 1
+#endif
+__host__ __device__ constexpr bool scan_wave64(int R3) { return RT_WAVE64_4096 && R3 == 16; }
+
 // bin of result register r in lane lt of a group, R3 at run time (bin_of<R3>)
 __device__ __forceinline__ int bin_of_rt(int R3, int lt, int r) {
     if (R3 == 1) return lt + 16 * r;
@@ -1411,6 +1419,13 @@ __device__ __forceinline__ int bin_of_rt(int R3, int lt, int r) {
     const int k1 = lt / R3, qg = lt % R3;
     const int u = (r / R3 - ((k1 * R3 / 8) & (G - 1))) & (G - 1), q2 = r % R3;
     return k1 + 16 * (qg * G + u) + 256 * q2;
+}
+
+// the bin whose threshold sits at position j of a stream's table in lane order (StftParams::thr_bin): [lane][16 registers] of the
+// 16-points-per-lane scans, [lane][64 registers] of stft_scan64 (bin = lane + 64 register)
+__device__ __forceinline__ int lane_order_bin(int R3, int j) {
+    if (scan_wave64(R3)) return j / 64 + 64 * (j % 64);
+    return bin_of_rt(R3, j / 16, j % 16);
 }
 
 // Per-bin thresholds for the exact pre-filter's bits (MODE 6), from the PREVIOUS call's chunk minima.  The reference's
@@ -1428,8 +1443,8 @@ __global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk
     const int N = 256 * R3, LG = 16 * R3;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [S][LG][16]
     if (i >= (int64_t)n_streams * N) return;
-    const int s = (int)(i / N), lt = (int)(i % N) / 16, r = (int)(i % 16);
-    const int bin = bin_of_rt(R3, lt, r);
+    const int s = (int)(i / N);
+    const int bin = lane_order_bin(R3, (int)(i % N));
     float th = 0.f;
     if (chunk_min_prev) {
         const float mn = __uint_as_float(chunk_min_prev[(int64_t)s * N + bin]);
@@ -1446,8 +1461,8 @@ __global__ __launch_bounds__(256) void make_bin_thresholds_from_means(const floa
     const int N = 256 * R3;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [S][LG][16]
     if (i >= (int64_t)n_streams * N) return;
-    const int s = (int)(i / N), lt = (int)(i % N) / 16, r = (int)(i % 16);
-    const int bin = bin_of_rt(R3, lt, r);
+    const int s = (int)(i / N);
+    const int bin = lane_order_bin(R3, (int)(i % N));
     double sum = 0.0;
     for (int c = 0; c < items_per_stream; ++c) sum += (double)psum[((int64_t)s * items_per_stream + c) * N + bin];
     const float avg = (float)sum / (float)n_seg;
@@ -2447,4 +2462,6 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
 }
 
 }  // namespace rt
+
+#include "rt_scan64.h"  // the nperseg-4096 scan (one wave per segment)
 #endif

@@ -21,6 +21,21 @@ pytestmark = pytest.mark.gpu
 POWER_TOL_DB = 0.01  # north_star allows 0.1
 STD_TOL_DB = 0.01
 SPEC_REL_TOL = 2e-4  # linear power, per cell, against the oracle's float32 spectrogram
+ROUND_OFF_LEVEL_DB = 80.0
+
+
+def _std_tolerance(x, spec, spec_prev=None):
+    """Tolerance for `std` (np.std(dB(data)), analyze.py:445) of the oracle record x on the oracle's spectrogram [F, T].
+    A plateau's cells start on the sub-threshold cell before the run (:382-398); where such a cell lies >= 80 dB under the
+    strongest bin of its OWN segment it is float32 round-off of whatever FFT computes it -- SciPy's float32 transform and
+    the kernels' each stray 1e-2 .. 4e-2 dB from a float64 transform there (3e-4 .. 8e-4 dB rms; measured,
+    profiles/r04_b_fft_round_off_by_level.txt), and `std` over two dozen cells moves by a fifth of that cell's error.
+    north_star's bar of 0.1 dB applies to `std` in that case, the tests' tighter STD_TOL_DB everywhere else."""
+    for t in range(x.start, x.end):
+        col = spec[:, t] if t >= 0 else spec_prev[:, t]
+        if col[x.fi] * 10.0 ** (ROUND_OFF_LEVEL_DB / 10.0) <= col.max():
+            return 0.1
+    return STD_TOL_DB
 
 
 def _need_gpu():
@@ -377,6 +392,7 @@ def test_look_back_over_several_chunks(nperseg, fs, mode):
         b.enqueue(chunk)
         rec = b.fetch_records()
         for s in range(n_streams):
+            spec_prev = oas[s].spec_last
             want_all, want_kept = oas[s].process(chunk[s], gu.TS0)
             mine = rec[rec["stream"] == s]
             assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want_all], f"buffer {k} stream {s}"
@@ -384,8 +400,10 @@ def test_look_back_over_several_chunks(nperseg, fs, mode):
             assert [bool(r["shadowed"]) for r in mine] == [id(x) not in kept_ids for x in want_all]
             sigs = b._decoder.signals(mine, [str(s)] * n_streams, [gu.TS0] * n_streams)
             for g, x in zip(sigs, want_all):
-                for name in ("max", "avg", "noise", "snr", "std"):
+                for name in ("max", "avg", "noise", "snr"):
                     assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB, (name, getattr(g, name), getattr(x, name))
+                # (these runs start on a noise cell 90 dB under the tones of its segment)
+                assert abs(g.std - x.std) < _std_tolerance(x, oas[s].spec_last, spec_prev), ("std", g.std, x.std)
             starts += [int(r["start"]) for r in mine]
     assert min(starts) <= -100, sorted(starts)[:40]
     if mode != "prefilter":  # (its minimum duration of 64 hops rejects the shorter runs on both sides)

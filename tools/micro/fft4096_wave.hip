@@ -19,7 +19,7 @@ using namespace rt;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // 64-point DFT in place, natural order in and out: n = n0 + 4 n', k = k' + 16 k0
-__device__ __forceinline__ void dft64(cf (&v)[64]) {
+__device__ __forceinline__ void micro_dft64(cf (&v)[64]) {
     // four 16-point DFTs over n' (stride 4)
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ void dft32(cf (&v)[32]) {
     for (int i = 0; i < 32; ++i) v[i] = t[i];
 }
 template <int PPL> __device__ __forceinline__ void dft_lane(cf (&v)[PPL]) {
-    if constexpr (PPL == 64) dft64(v); else dft32(v);
+    if constexpr (PPL == 64) micro_dft64(v); else dft32(v);
 }
 
 // N = PPL x PPL points per segment, PPL lanes per segment (a wave holds 64 / PPL segments), PPL points per lane
