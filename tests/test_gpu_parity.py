@@ -1360,6 +1360,95 @@ def test_a_few_noisy_streams_go_dense_on_their_own(lanes):
     assert b2.fetch_records().tobytes() == dense.fetch_records().tobytes()
 
 
+def test_nperseg_4096_every_mode_of_the_one_wave_per_segment_scan():
+    """fft_nperseg = 4096 is served by a kernel of its own (csrc/rt_scan64.h: one wave per segment, 64 bins per lane, 64-bit
+    per-lane bit words, wave-level work items).  The cases with 4096 in their parameters reach its sparse, dense, spectrogram
+    and exact-pre-filter instantiations on complex64; this one reaches the rest: the chunk-bit pre-filter (MODE 4 / 5), a few
+    noisy streams re-run dense from a stream list, the uint8 wire format (subtract-first detrend) through sparse, dense and
+    both pre-filters -- each byte-identical to the dense path, the dense path against the oracle."""
+    _need_gpu()
+    fs, nperseg, n_streams, n_buf = 3200000, 4096, 6, 2
+    hop_ms = 1000.0 * nperseg / fs
+    blen = nperseg * 260 + 123
+    w = oracle.window_coefficients("hamming", nperseg)
+    # noise floor -160 dBW (sigma 1.27e-5 at 3.2 MS/s); plateaus of >= 8 hops, so that chunks of 4 segments qualify for the chunk bits
+    # (and the exact pre-filter's planning tiles, 32 rows at this nperseg, still hold a plateau's length either side)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window="hamming", signal_min_duration_ms=8 * hop_ms, signal_max_duration_ms=80 * hop_ms, signal_threshold_dbw=-158.0)
+    sigma = float(np.sqrt(10 ** (-160.0 / 10) * fs / 2))  # (a fifth of all cells passes the absolute threshold: the sparse lists overflow, the chunk bits of 4 segments stay selective)
+    iq = []
+    for s in range(n_streams):
+        rng = np.random.default_rng([4096, s])
+        pulses = synth.random_pulses(rng, n_buf * blen, fs, w, 6 * n_buf, dur_ms=(22, 60), peak_dbw=(-140.0, -126.0))
+        pulses.append(synth.Pulse(blen - int(0.020 * fs) - 11 * s, int(0.040 * fs), (0.05 + 0.04 * s) * fs, synth.amp_for_peak_dbw(-128.0, w, fs)))  # across the buffers
+        pulses.append(synth.Pulse(0, int(0.030 * fs), (-0.3 + 0.03 * s) * fs, synth.amp_for_peak_dbw(-128.0, w, fs)))  # a run that starts at t = 0
+        iq.append(synth.make_stream(synth.StreamSpec(n_buf * blen, fs, pulses, noise_sigma=sigma), seed=4100 + s).reshape(n_buf, blen))
+    iq = np.stack(iq)
+    common = dict(segs_per_chunk=4)
+    dense = _batch_for(kw, n_streams, blen, "dense", **common)
+    others = {m: _batch_for(kw, n_streams, blen, m, **common) for m in ("prefilter", "runfilter", "auto")}
+    others["auto, two lanes"] = _batch_for(kw, n_streams, blen, "auto", lanes=2, **common)
+    oas = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(n_streams)]
+    total = 0
+    for k in range(n_buf):
+        chunk = np.ascontiguousarray(iq[:, k])
+        dense.enqueue(chunk)
+        want = dense.fetch_records()
+        for name, b in others.items():
+            b.enqueue(chunk)
+            assert b.fetch_records().tobytes() == want.tobytes(), (name, k)
+        assert others["prefilter"].native.call_info().mode_used == _native.RT_MODE_PREFILTER
+        assert others["runfilter"].native.call_info().mode_used == _native.RT_MODE_RUNFILTER
+        assert others["auto"].native.call_info().mode_used != _native.RT_MODE_SPARSE  # (the sparse lists overflow)
+        # the dense path against the oracle: indices exact; decisions on the noise itself (floor = threshold) may flip within an ulp, so
+        # streams are compared where the record lists agree and most must
+        agree = 0
+        for s in range(n_streams):
+            want_all, _ = oas[s].process(chunk[s], gu.TS0)
+            mine = want[want["stream"] == s]
+            if [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] != [(x.fi, x.start, x.end) for x in want_all]:
+                continue
+            agree += 1
+            sigs = dense._decoder.signals(mine, [str(s)] * n_streams, [gu.TS0] * n_streams)
+            for g, x in zip(sigs, want_all):
+                for name in ("max", "avg", "noise", "snr"):
+                    assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB, (name, s)
+            total += len(mine)
+        assert agree >= n_streams - 1, (k, agree)
+    assert total > 2 * n_streams
+    # one noisy SDR among quiet ones: it alone is re-run dense (a scan over a stream list)
+    quiet_kw = dict(kw, signal_threshold_dbw=-150.0)
+    mixed = iq[:, 0].copy()
+    mixed[2] = (mixed[2] * 4.0).astype(np.complex64)  # + 12 dB: this stream's floor is over the threshold now
+    d2 = _batch_for(quiet_kw, n_streams, blen, "dense")
+    a2 = _batch_for(quiet_kw, n_streams, blen, "auto")
+    d2.enqueue(np.ascontiguousarray(mixed)); a2.enqueue(np.ascontiguousarray(mixed))
+    w2 = d2.fetch_records()
+    assert a2.fetch_records().tobytes() == w2.tobytes()
+    info = a2.native.call_info()
+    assert info.n_dense_streams == 1 and info.fell_back == 1, (info.mode_used, info.n_dense_streams)
+    # the RTL-SDR wire format: quantised bytes through every level, byte-identical to the dense path and to the complex64 path
+    # fed with the same conversion (subtract-first detrend on both sides, DESIGN 4.5)
+    raw = synth.quantize_u8(iq[:, 0], gain=2000.0)
+    kw8 = dict(kw, signal_threshold_dbw=-158.0 + 66.0)  # the gain of 2000 is 66 dB
+    d8 = _batch_for(kw8, n_streams, blen, "dense", **common)
+    d8.enqueue_bytes(raw)
+    w8 = d8.fetch_records()
+    assert len(w8) > n_streams
+    for m in ("prefilter", "runfilter", "auto"):
+        b8 = _batch_for(kw8, n_streams, blen, m, **common)
+        b8.enqueue_bytes(raw)
+        assert b8.fetch_records().tobytes() == w8.tobytes(), m
+    c8 = _batch_for(kw8, n_streams, blen, "dense", subtract_first=True, **common)
+    c8.enqueue(synth.u8_to_complex64_like_kernel(raw))
+    assert c8.fetch_records().tobytes() == w8.tobytes()
+    # ... and on clean input the sparse path (uint8) equals the dense one
+    kw8s = dict(kw8, signal_threshold_dbw=-150.0 + 66.0)
+    s8, ds8 = _batch_for(kw8s, n_streams, blen, "sparse"), _batch_for(kw8s, n_streams, blen, "dense")
+    s8.enqueue_bytes(raw); ds8.enqueue_bytes(raw)
+    got = s8.fetch_records()
+    assert len(got) > n_streams and got.tobytes() == ds8.fetch_records().tobytes()
+
+
 def test_prefilter_needs_long_enough_minimum_duration():
     """chunks of L segments need signal_min_duration >= 2 L hops (L >= 4); otherwise the mode is refused and AUTO goes
     from the sparse path straight to the dense one"""
