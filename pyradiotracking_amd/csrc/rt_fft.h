@@ -55,6 +55,7 @@ __device__ __forceinline__ cfv cmul(cfv a, cfv b) {  // (a run-time factor: its 
 }
 __device__ __forceinline__ cfv cscale(cfv a, float s) { return a * s; }
 __device__ __forceinline__ cfv cneg(cfv a) { return -a; }
+__device__ __forceinline__ cfv mul_mi(cfv a) { return cfv{a.y, -a.x}; }
 // a * w for a compile-time w: the partner pair (-w.y, w.x) is a constant too, so the product is two packed operations
 // (a.y * -w.y == -(a.y * w.y) exactly: the same roundings as cmul)
 __device__ __forceinline__ cfv cmul_const(cfv a, float wx, float wy) {
@@ -211,11 +212,12 @@ constexpr float kW64Im[48] = {0.0f, -0.0980171412f, -0.195090324f, -0.290284663f
 // Four 16-point transforms over n' (inputs v[n0 + 4 j]: the quarter n0 of the registers -- a caller whose quarters arrive one
 // after the other transforms each as it comes and calls dft64_finish), twiddles W64^(n0 k'), sixteen 4-point transforms over n0.
 // dft64_finish: v[n0 + 4 k'] holds A[n0][k'], the 16-point transform of quarter n0.
-__device__ __forceinline__ void dft64_finish(cf (&v)[64]) {
-    cf t[64];
+template <class C>
+__device__ __forceinline__ void dft64_finish(C (&v)[64]) {
+    C t[64];
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
-        cf a0 = v[4 * kp], a1 = v[1 + 4 * kp], a2 = v[2 + 4 * kp], a3 = v[3 + 4 * kp];
+        C a0 = v[4 * kp], a1 = v[1 + 4 * kp], a2 = v[2 + 4 * kp], a3 = v[3 + 4 * kp];
         if (kp) {
             a1 = (kp == 8) ? mul_w8_1(a1) : cmul_const(a1, kW64Re[kp], kW64Im[kp]);
             a2 = (kp == 8) ? mul_mi(a2) : (kp == 4) ? mul_w8_1(a2) : (kp == 12) ? mul_w8_3(a2) : cmul_const(a2, kW64Re[2 * kp], kW64Im[2 * kp]);
@@ -227,10 +229,11 @@ __device__ __forceinline__ void dft64_finish(cf (&v)[64]) {
 #pragma unroll
     for (int i = 0; i < 64; ++i) v[i] = t[i];
 }
-__device__ __forceinline__ void dft64(cf (&v)[64]) {
+template <class C>
+__device__ __forceinline__ void dft64(C (&v)[64]) {
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) {
-        cf a[16];
+        C a[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = v[n0 + 4 * j];
         dft16(a);
