@@ -259,6 +259,16 @@ int choose_chunk(const rt_config &cfg, int R3, int n_streams, int n_seg) {
         if (blocks >= 2048) break;
         L >>= 1;
     }
+    if (L == 32 && R3 < 4 && n_seg > 32) {
+        // nperseg <= 512, a batch that fills the chip: a workgroup holds GPW chunks and its lane groups walk in step, so the chunks
+        // of a stream cost (workgroups) x L steps whatever the last workgroup holds.  The shortest L with the same number of
+        // workgroups: 1 171 segments (the reference's default geometry, 300 kS/s) = 37 chunks of 32 in three workgroups of 16, eleven
+        // lane groups idle -- or 47 chunks of 25 in the same three, one idle: 22 % fewer steps.  Config 2 (8 000 segments) and
+        // config 4 (2 048) keep 32.  (Not a function of the number of streams, like the rules below.)
+        const int wgs = (n_seg + GPW * 32 - 1) / (GPW * 32);
+        const int lb = (n_seg + GPW * wgs - 1) / (GPW * wgs);
+        if (lb >= 16) L = lb;
+    }
     if (L == 32 && !keep_long && R3 >= 4) {
         // nperseg >= 1024, a batch that fills the chip: the chunk length is chosen by what a workgroup costs.  All lane
         // groups of a workgroup take L steps (a last chunk that is short leaves its group idle), and a workgroup pays
@@ -477,7 +487,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         }
         RT_HIP(h, hipMemsetAsync(const_cast<int32_t *>(sp.seg_count), 0, ((size_t)S + 1) * sizeof(int32_t), h->s_scan));
         const int tiles = (c.n_seg + h->plan_tile - 1) / h->plan_tile;
-        hipLaunchKernelGGL(plan_runs, dim3(tiles, S), dim3(256), 0, h->s_scan, sp.cell_hot, sl.d_cell_need,
+        const size_t plan_lds = 3 * sizeof(unsigned long long) * (size_t)plan_rows_padded(h->plan_tile, h->run_cells) * (h->LG / 4) + sizeof(uint32_t) * (size_t)h->plan_tile;
+        hipLaunchKernelGGL(plan_runs, dim3(tiles, S), dim3(64), plan_lds, h->s_scan, sp.cell_hot, sl.d_cell_need,
                            sl.d_seg_list, const_cast<int32_t *>(sp.seg_count), c.n_seg, h->LG, h->run_cells, h->plan_tile);
         RT_HIP(h, hipMemcpyAsync(sl.h_seg_total, sp.seg_count + S, sizeof(int32_t), hipMemcpyDeviceToHost, h->s_scan));
         launch_scan<7>(h, sp, blocks, c.u8);
@@ -886,7 +897,9 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         // of r rows either side) must leave room for rows of their own.  Built where it is asked for, and in AUTO mode.
         h->run_cells = (int)std::max<long long>(1, std::min<long long>(r_min, 1 << 20));
         const int rows_max = kPlanWords / (h->LG / 4);  // rows of 64-bit words (four lanes each) per LDS buffer
-        h->plan_tile = std::min(rows_max - 2 * h->run_cells, kPlanWords / 4);
+        // tiles a few halos long (one wave each, rt_kernels.h: plan_runs): 14 r rows -- sixteen blocks of r with the halo, a lane
+        // per block and word of a row -- at least 32, within what a buffer holds (the rows are padded to whole blocks: 3 r off)
+        h->plan_tile = std::min(rows_max / h->run_cells * h->run_cells - 2 * h->run_cells, std::max(32, std::min(14 * h->run_cells, kPlanWords / 4)));
         const bool fits = h->plan_tile >= 8 && h->max_seg >= 2;
         if (cfg->mode == RT_MODE_RUNFILTER && !fits) {
             delete h;
@@ -1103,6 +1116,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_runs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(3 * sizeof(unsigned long long) * kPlanWords + sizeof(uint32_t) * (kPlanWords / 4))));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dense));
 #undef RT_CREATE_HIP

@@ -435,7 +435,14 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     constexpr size_t kT1B = T1_IN_LDS ? sizeof(float4) * 8 * LG : 0;
     constexpr size_t kT2B = (R3 > 1) ? sizeof(float4) * 8 * R3 : 0;
     constexpr size_t kStageB = (MODE == 0 || MODE == 5 || MODE == 7) ? sizeof(uint2) * (BLK / 64) * kStage : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB];
+    // MODE 6: the stream's per-bin second thresholds, staged per item in the order the lanes read them ([q][lane] float4 = the lane's
+    // registers 4 q .. 4 q + 3).  Read from L2 in every step they queued behind the next segment's loads (vector-memory operations
+    // return in order): the threshold test of a step waited for the prefetch of the next -- 2.11 ms for a scan whose bytes take 1.7
+    // (profiles/r04_a_*).  Up to nperseg 1024, where the table fits beside the rest at three workgroups per CU.
+    constexpr bool THR_LDS = (MODE == 6) && R3 <= 4;
+    constexpr size_t kThrB = THR_LDS ? sizeof(float) * N : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB];
+    float4 *const thr_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB);
     cf *const xch = reinterpret_cast<cf *>(lds_block);
     cf *const red = reinterpret_cast<cf *>(lds_block + kXchB);
     uint32_t *const tail_any = reinterpret_cast<uint32_t *>(lds_block + kXchB + sizeof(cf) * (BLK / 64));  // LG > 64, see the tail columns below
@@ -534,18 +541,44 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         if (pb >= p.item_count[s]) return;
         chunk = p.item_chunks[((int64_t)s * p.blocks_per_stream + pb) * GPW + g];
     }
-    // MODE 7: the item is GPW * L entries of the stream's segment list; this lane group takes L consecutive ones
-    int e0 = 0, n_mine = 0;
+    // MODE 7: the item is (up to) GPW * L entries of the stream's segment list, dealt to the workgroup's lane groups in equal
+    // runs of `per7` consecutive entries, and the step loop ends after per7 steps.  (L entries to a lane group and L steps whatever
+    // the list held -- the first version -- left 12 of 16 lane groups idle at the reference's default geometry, where a stream
+    // lists 137 of its 1 171 segments, and walked 32 steps for 9: 0.58 ms for an eighth of the samples, profiles/r04_a_*.)
+    int e0 = 0, n_mine = 0, per7 = 0;
     if constexpr (MODE == 7) {
         const int pb = item / p.n_streams;
         const int cnt = p.seg_count[s];
-        if (pb * GPW * p.segs_per_chunk >= cnt) return;  // (workgroup-uniform)
-        e0 = (pb * GPW + g) * p.segs_per_chunk;
-        n_mine = cnt - e0;
-        n_mine = n_mine < 0 ? 0 : (n_mine > p.segs_per_chunk ? p.segs_per_chunk : n_mine);
+        const int first = pb * GPW * p.segs_per_chunk;
+        if (first >= cnt) return;  // (workgroup-uniform)
+        const int n_item = cnt - first < GPW * p.segs_per_chunk ? cnt - first : GPW * p.segs_per_chunk;
+        per7 = (n_item + GPW - 1) / GPW;
+        e0 = first + g * per7;
+        n_mine = n_item - g * per7;
+        n_mine = n_mine < 0 ? 0 : (n_mine > per7 ? per7 : n_mine);
     }
     const bool chunk_ok = (MODE == 7) ? (n_mine > 0) : (chunk < p.chunks);
     const int c0 = chunk * p.segs_per_chunk;
+    if constexpr (THR_LDS) {
+        if (p.thr_bin) {  // (the previous item's readers are behind the barrier that ended it; this item's first step is behind the next one)
+            // max(absolute threshold, the bin's own): `!(P < a) && !(P < b)` is `!(P < max(a, b))`, one test per cell instead of two
+            const float thr_abs = p.thr_s ? p.thr_s[s] : p.thr;
+            const float4 *src = reinterpret_cast<const float4 *>(p.thr_bin + (int64_t)s * N);  // [lane][q]
+            for (int idx = tid; idx < 4 * LG; idx += BLK) {
+                const float4 t4 = src[(idx % LG) * 4 + idx / LG];
+                thr_lds[idx] = make_float4(fmaxf(t4.x, thr_abs), fmaxf(t4.y, thr_abs), fmaxf(t4.z, thr_abs), fmaxf(t4.w, thr_abs));
+            }
+        }
+        __syncthreads();
+    }
+    // MODE 6 with staged thresholds: the bits of the absolute threshold alone (`hot`) are only built where something reads them --
+    // the chunk bits (p.full), the sparse tail's masks (items that reach into the last tail_cols segments) -- and the count for
+    // AUTO's probes (abs_hot) comes from every eighth segment elsewhere: 48 of ~630 vector instructions of every step at the
+    // reference's default geometry, where the noise passes the absolute threshold in nearly every lane.
+    bool item_hot = true;  // wave-uniform
+    if constexpr (THR_LDS) {
+        if (p.thr_bin) item_hot = __builtin_amdgcn_ballot_w64(p.full != nullptr || c0 + p.segs_per_chunk > p.n_seg - p.tail_cols) != 0ull;
+    }
     if constexpr (LG > 64) {
         // (behind the barrier that ended the previous item, ahead of this item's first one: group_sum / the rows barrier)
         if (tid < 3) tail_any[tid] = (tid == 1) ? 1u : 0u;  // the first step (i = 1) writes its whole column
@@ -594,7 +627,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #endif
     constexpr bool BELOW = (R3 <= RT_BELOW_MAX_R3);
     const int i_first = (!BELOW && EMIT && !LISTED) ? 0 : 1;
-    int n_steps = L;
+    int n_steps = LISTED ? per7 : L;
 
     uint32_t allhot = 0xFFFFu;  // FLAGS: the chunk's bits so far
     uint32_t n_abs = 0;         // MODE 4 / 6: this lane's cells at or above the absolute threshold (StftParams::abs_hot)
@@ -1018,7 +1051,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, P[r]), P[r + 1]);
             mx = __builtin_fmaxf(mx, P[15]);
             uint32_t hot = 0;
-            if (active && !(mx < thr)) {
+            const bool sampled_abs = THR_LDS && !item_hot && p.abs_hot && (seg & 7) == 0 && !halo;  // (see item_hot)
+            if (active && !(mx < thr) && (item_hot || sampled_abs)) {
                 // bit r = !(P[r] < thr), built by shifting (v_lshl_or_b32): `hot |= 1u << r` made hipcc keep the nine
                 // literals 128 .. 32768 in VGPRs across the whole step loop (a select cannot take a literal on gfx9)
 #pragma unroll
@@ -1032,14 +1066,27 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                         int lt_b = lt;
                         asm volatile("" : "+v"(lt_b));
                         uint32_t bits = hot;
-                        if (p.thr_bin && bits) {
+                        if (THR_LDS && p.thr_bin) {
+                            // (the staged table holds max(absolute threshold, the bin's own): the one test)
+                            bits = 0;
+                            if (!(mx < thr)) {
+#pragma unroll
+                                for (int q = 3; q >= 0; --q) {
+                                    const float4 t4 = thr_lds[q * LG + lt_b];
+                                    bits = (bits << 1) | ((P[4 * q + 3] < t4.w) ? 0u : 1u);
+                                    bits = (bits << 1) | ((P[4 * q + 2] < t4.z) ? 0u : 1u);
+                                    bits = (bits << 1) | ((P[4 * q + 1] < t4.y) ? 0u : 1u);
+                                    bits = (bits << 1) | ((P[4 * q + 0] < t4.x) ? 0u : 1u);
+                                }
+                            }
+                        } else if (p.thr_bin && bits) {
                             // the bin's own second threshold (a lower bound of snr * row mean, see make_bin_thresholds):
                             // only cells that pass it too can be part of a plateau.  Sixteen floats per lane from L2.
                             const float4 *tb = reinterpret_cast<const float4 *>(p.thr_bin + ((int64_t)s * LG + lt_b) * 16);
                             uint32_t ok = 0;
 #pragma unroll
                             for (int q = 3; q >= 0; --q) {
-                                const float4 t4 = tb[q];
+                                const float4 t4 = THR_LDS ? thr_lds[q * LG + lt_b] : tb[q];
                                 ok = (ok << 1) | ((P[4 * q + 3] < t4.w) ? 0u : 1u);
                                 ok = (ok << 1) | ((P[4 * q + 2] < t4.z) ? 0u : 1u);
                                 ok = (ok << 1) | ((P[4 * q + 1] < t4.y) ? 0u : 1u);
@@ -1051,7 +1098,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                     }
                 }
                 if (active && !halo) {
-                    if constexpr (MODE == 4 || MODE == 6) n_abs += (uint32_t)__builtin_popcount(hot);
+                    if constexpr (MODE == 4 || MODE == 6) n_abs += (uint32_t)__builtin_popcount(hot) << ((THR_LDS && !item_hot) ? 3 : 0);
                     allhot &= hot;
                     if (chunk == 0 && p.full) {  // (lane index opaque: the address stays out of the loop's registers)
                         int lt_f = lt;
@@ -1291,72 +1338,98 @@ __global__ __launch_bounds__(256) void plan_pass_b(const uint16_t *full, uint16_
 // 16), tiles are short (a few halos long), so that several workgroups share a CU: the first version -- 16-bit words, tiles
 // of 1 000 rows, one workgroup of 100 KiB of LDS per CU -- took 3.3 ms per call at 4 096 streams of the reference's
 // default geometry, twice the scan it serves.
-constexpr int kPlanWords = 2048;  // 64-bit words per LDS buffer (16 KiB; three buffers)
-__global__ __launch_bounds__(256) void plan_runs(const uint16_t *hot, uint16_t *need, int32_t *seg_list, int32_t *seg_count,
-                                                 int n_seg, int lg, int r, int tile_rows) {
-    __shared__ unsigned long long plan_buf[3 * kPlanWords];
-    __shared__ uint32_t row_any[kPlanWords / 4];  // (tile_rows <= kPlanWords / (lg / 4) <= kPlanWords / 4)
-    unsigned long long *A = plan_buf, *B = plan_buf + kPlanWords, *Cb = plan_buf + 2 * kPlanWords;
+constexpr int kPlanWords = 4096;  // 64-bit words per LDS buffer at most (32 KiB; three buffers)
+// ONE WAVE per tile, no workgroup barrier; the window operations in a constant number of passes: rows in blocks of r, a running
+// AND (OR) down and up each block, and a window of r rows is the tail of one block's run and the head of the next one's
+// (van Herk / Gil-Werman).  Doubling (P_2k[t] = P_k[t] & P_k[t + k], ten passes for r = 9) made the kernel 0.28 - 0.39 ms for
+// the 157 MB of bits of 4 096 streams at the reference's default geometry, twice what its bytes take (profiles/r04_a_*).
+// Dynamic LDS: three buffers of rows_p x lg / 4 words, rows_p = tile_rows + 2 r rounded up to whole blocks, + tile_rows words.
+__host__ __device__ inline int plan_rows_padded(int tile_rows, int r) { return (tile_rows + 2 * r + r - 1) / r * r; }
+__global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *need, int32_t *seg_list, int32_t *seg_count,
+                                                int n_seg, int lg, int r, int tile_rows) {
+    extern __shared__ unsigned long long plan_buf[];
     const int s = blockIdx.y, tid = threadIdx.x;
     const int w = lg / 4;                                  // 64-bit words per row
     const int t0 = blockIdx.x * tile_rows;                 // first row of the tile
     const int rows = tile_rows + 2 * r;                    // with the halo
-    const int words = rows * w;
+    const int rows_p = plan_rows_padded(tile_rows, r);     // ... in whole blocks of r (the rows beyond `rows` are zero)
+    const int words = rows_p * w;
+    unsigned long long *A = plan_buf, *Up = plan_buf + words, *Dn = plan_buf + 2 * words;
+    uint32_t *row_any = reinterpret_cast<uint32_t *>(plan_buf + 3 * words);  // [tile_rows]
     const unsigned long long *H = reinterpret_cast<const unsigned long long *>(hot + (int64_t)s * n_seg * lg);
-    // A = H on rows t0 - r .. t0 + tile_rows + r - 1 (zero outside the buffer)
-    for (int i = tid; i < words; i += 256) {
-        const int t = t0 - r + i / w;
-        A[i] = (t >= 0 && t < n_seg) ? H[(int64_t)t * w + i % w] : 0ull;
+    // A = H on rows t0 - r .. t0 + tile_rows + r - 1 (zero outside the buffer and in the padding); eight loads in flight per lane
+    // (one at a time -- a loop the compiler cannot unroll -- every lane paid a memory round trip per word: most of the kernel's time)
+    for (int i0 = tid; i0 < words; i0 += 64 * 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            const int row = i / w, t = t0 - r + row;
+            v[u] = (i < words && row < rows && t >= 0 && t < n_seg) ? H[(int64_t)t * w + i % w] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 64 * u < words) A[i0 + 64 * u] = v[u];
     }
-    for (int i = tid; i < tile_rows; i += 256) row_any[i] = 0u;
-    __syncthreads();
-    auto at = [&](const unsigned long long *X, int i, int shift_rows) -> unsigned long long {  // X[row + shift], zero outside the staged rows
-        const int j = i + shift_rows * w;
-        return (j >= 0 && j < words) ? X[j] : 0ull;
-    };
-    // E = AND over r rows starting at t: binary decomposition of r over the doubled windows P (span k)
-    {
-        unsigned long long *P = A, *Q = B;
-        bool first = true;
-        int off = 0;
-        for (int k = 1; k <= r; k <<= 1) {
-            if (r & k) {
-                for (int i = tid; i < words; i += 256) Cb[i] = first ? at(P, i, off) : (Cb[i] & at(P, i, off));
-                first = false;
-                off += k;
-            }
-            if ((k << 1) <= r) {
-                __syncthreads();
-                for (int i = tid; i < words; i += 256) Q[i] = P[i] & at(P, i, k);
-                unsigned long long *tmp = P; P = Q; Q = tmp;
-            }
-            __syncthreads();
+    for (int i = tid; i < tile_rows; i += 64) row_any[i] = 0u;
+    wave_sync();
+    const int n_blk = rows_p / r;
+    // E[t] = AND of the r rows from t on = (block's rows t .. end) & (next rows up to t + r - 1): Dn[t] & Up[t + r - 1]
+    for (int i = tid; i < n_blk * w; i += 64) {
+        const int base = (i / w) * r * w + i % w;
+        unsigned long long run = ~0ull;
+        for (int k0 = 0; k0 < r; k0 += 4) {  // rows block start .. t (four LDS reads in flight)
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k0 + u < r) ? A[base + (k0 + u) * w] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { run &= v[u]; if (k0 + u < r) Up[base + (k0 + u) * w] = run; }
+        }
+        run = ~0ull;
+        for (int k0 = r - 1; k0 >= 0; k0 -= 4) {  // rows t .. block end
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k0 - u >= 0) ? A[base + (k0 - u) * w] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { run &= v[u]; if (k0 - u >= 0) Dn[base + (k0 - u) * w] = run; }
         }
     }
-    // C = OR over the r rows ending at t of E (now in Cb): same scheme, negative offsets
-    unsigned long long *Cres;
-    {
-        unsigned long long *P = Cb, *Q = A, *R = B;
-        bool first = true;
-        int off = 0;
-        for (int k = 1; k <= r; k <<= 1) {
-            if (r & k) {
-                for (int i = tid; i < words; i += 256) R[i] = first ? at(P, i, -off) : (R[i] | at(P, i, -off));
-                first = false;
-                off += k;
-            }
-            if ((k << 1) <= r) {
-                __syncthreads();
-                for (int i = tid; i < words; i += 256) Q[i] = P[i] | at(P, i, -k);
-                unsigned long long *tmp = P; P = Q; Q = tmp;
-            }
-            __syncthreads();
-        }
-        Cres = R;
+    wave_sync();
+    for (int i = tid; i < words; i += 64) {
+        const int j = i + (r - 1) * w;
+        A[i] = Dn[i] & (j < words ? Up[j] : 0ull);  // (r = 1: Dn[i] & Up[i] = H[i])
     }
+    wave_sync();
+    // C[t] = OR of E over the r rows up to t = (block's rows start .. t) | (rows t - r + 1 .. end of the block before)
+    for (int i = tid; i < n_blk * w; i += 64) {
+        const int base = (i / w) * r * w + i % w;
+        unsigned long long run = 0ull;
+        for (int k0 = 0; k0 < r; k0 += 4) {
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k0 + u < r) ? A[base + (k0 + u) * w] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { run |= v[u]; if (k0 + u < r) Up[base + (k0 + u) * w] = run; }
+        }
+        run = 0ull;
+        for (int k0 = r - 1; k0 >= 0; k0 -= 4) {
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k0 - u >= 0) ? A[base + (k0 - u) * w] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { run |= v[u]; if (k0 - u >= 0) Dn[base + (k0 - u) * w] = run; }
+        }
+    }
+    wave_sync();
+    unsigned long long *Cres = A;
+    for (int i = tid; i < words; i += 64) {
+        const int j = i - (r - 1) * w;
+        Cres[i] = Up[i] | (j >= 0 ? Dn[j] : 0ull);
+    }
+    wave_sync();
     // the run through t = 0, whatever its length (first tile only): and the rows up from t = 0 until nothing is left
     if (t0 == 0) {
-        for (int l = tid; l < w; l += 256) {
+        for (int l = tid; l < w; l += 64) {
             unsigned long long z = ~0ull;
             for (int t = 0; t < tile_rows + r && t < n_seg && z; ++t) {
                 z &= H[(int64_t)t * w + l];
@@ -1364,10 +1437,10 @@ __global__ __launch_bounds__(256) void plan_runs(const uint16_t *hot, uint16_t *
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     // need[t] = C[t] | C[t + 1] (the cell before a run), rows of this tile only; remember which rows hold anything
     unsigned long long *Nd = reinterpret_cast<unsigned long long *>(need + (int64_t)s * n_seg * lg);
-    for (int i = tid; i < tile_rows * w; i += 256) {
+    for (int i = tid; i < tile_rows * w; i += 64) {
         const int row = i / w, t = t0 + row;
         if (t >= n_seg) break;
         const int j = (row + r) * w + i % w;
@@ -1376,17 +1449,24 @@ __global__ __launch_bounds__(256) void plan_runs(const uint16_t *hot, uint16_t *
         Nd[(int64_t)t * w + i % w] = v;
         if (v) row_any[row] = 1u;  // (benign race: every writer stores 1)
     }
-    __syncthreads();
-    int mine = 0;
-    for (int row = tid; row < tile_rows; row += 256) {
-        if (row_any[row] && t0 + row < n_seg) {
-            const int idx = atomicAdd(&seg_count[s], 1);
-            seg_list[(int64_t)s * n_seg + idx] = t0 + row;
-            ++mine;
+    wave_sync();
+    // The tile's rows that hold anything go to the stream's list: one returned atomic per 64 rows reserves their places (an atomic
+    // per row, and one per thread on the batch's total -- a single word for every workgroup of the launch -- was the first version)
+    for (int row0 = 0; row0 < tile_rows; row0 += 64) {  // (wave-uniform bounds)
+        const int row = row0 + tid;
+        const bool has = row < tile_rows && row_any[row] && t0 + row < n_seg;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+        if (m == 0ull) continue;
+        const int total = __builtin_popcountll(m);
+        int base = 0;
+        if (tid == 0) {
+            base = atomicAdd(&seg_count[s], total);
+            // the batch's total (word [S] of the counts) tells the host how selective the level is on this input
+            atomicAdd(&seg_count[gridDim.y], total);
         }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (has) seg_list[(int64_t)s * n_seg + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t0 + row;
     }
-    // the batch's total (word [S] of the counts) tells the host how selective the level is on this input
-    if (mine) atomicAdd(&seg_count[gridDim.y], mine);
 }
 
 // The largest per-stream count of cells at or above the absolute threshold (StftParams::abs_hot, left by a MODE 4 / 6

@@ -123,6 +123,10 @@ __device__ __forceinline__ bool bit_of(uint32_t lo, uint32_t hi, int r) { return
 #ifndef RT_W64_PREFETCH
 #define RT_W64_PREFETCH 1
 #endif
+// (Tried and dropped: spreading a step's vector-memory instructions over its arithmetic -- quarter 3's loads behind quarter 0's
+// transform, the prefetch pieces two at a time between the twiddle rows -- because a wave that issues them in one run waits for
+// queue slots in between (38 cycles per load, 76 per LDS-DMA piece, profiles/r04_c_stage_stamps_*).  Either placement sends hipcc's
+// register allocation from 2 spilled registers outside the step to 53 / 152 inside it.)
 
 
 template <int MODE, bool U8, bool LIN>

@@ -2,9 +2,9 @@
 """Round-off of the scan's transform under a strong tone: the GPU spectrogram (rt_spectrogram_device) and SciPy's float32
 spectrogram, each against a float64 transform of the same complex64 samples.  Cells are binned by how far they lie under the
 strongest bin of their segment; printed: rms and worst |dB error| per bin of 10 dB.
-usage: RT_ANALYZE_LIB=<lib> python tools/r4/fft_accuracy.py [nperseg]"""
+usage: RT_ANALYZE_LIB=<lib> python tests/perf/fft_round_off.py [nperseg]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # the repo root
 import numpy as np
 from oracle import analyze_oracle as oracle
 from pyradiotracking_amd import _native, synth
