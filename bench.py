@@ -159,42 +159,89 @@ def pmc_traffic(default_workload, lanes):
     return int(doc["bytes_per_launch_256_streams"]) // lanes, "bytes/launch: PMC FETCH_SIZE (calibrated on the kernel's own load stream) + WRITE_SIZE on one 256-stream launch; " + doc.get("source", "profiles/pmc_traffic.json")
 
 
+def _tail(path, n=25):
+    try:
+        with open(path, errors="replace") as f:
+            return "".join(f.readlines()[-n:])
+    except OSError:
+        return ""
+
+
 def spawn_ranks(args):
     """``--gpus N`` started by hand (no launcher): run the N ranks as N fresh child processes of this script, one per
-    GPU, rendezvous on 127.0.0.1.  This process has not imported torch and never touches a GPU; it relays rank 0's
-    output and exits non-zero if any rank does (the others are then stopped by their exact PIDs)."""
+    GPU, rendezvous on 127.0.0.1.  This process has not imported torch and never touches a GPU (every GPU question is
+    asked in a child); it relays rank 0's output.  It cannot hang on a rank that dies: all children are polled, the
+    first non-zero exit stops the others by their exact PIDs and is reported with that rank's stderr tail (the
+    reference's supervisor does the same for its analyzer processes, __main__.py:152-190)."""
     import socket
     import subprocess
+    import tempfile
+    import threading
+    import time
 
+    share = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
+    # the lease has N GPUs?  Asked in a child (HIP runtime only, no torch), answered in a second or two
+    try:
+        probe = subprocess.run([sys.executable, "-c", "from pyradiotracking_amd import _native; print(_native.device_count())"],
+                               env=dict(os.environ, RT_NO_TORCH="1"), cwd=REPO, capture_output=True, text=True, timeout=120)
+        n_dev = int(probe.stdout.strip().splitlines()[-1]) if probe.returncode == 0 and probe.stdout.strip() else -1
+    except (subprocess.TimeoutExpired, ValueError):
+        n_dev, probe = -1, None
+    if n_dev < 0:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: could not count the GPUs: {(probe.stderr if probe else 'timed out')[-500:]}")
+    if n_dev < (1 if share else args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {n_dev} GPU(s)")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    procs = []
+    procs, errs = [], []
+    tmp = tempfile.mkdtemp(prefix="rt_bench_ranks_")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(os.path.join(tmp, f"rank{r}.err"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].stdout.read()
-    rcs = []
-    failed = False
-    for pr in procs:
-        try:
-            rcs.append(pr.wait(timeout=None if not failed else 30))
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            rcs.append(pr.wait())
-        if rcs[-1] != 0 and not failed:
-            failed = True
-            for other in procs:
-                if other.poll() is None:
-                    other.terminate()
-    sys.stdout.write(out0)
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=open(errs[-1], "w"), text=True))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("RT_BENCH_RANKS_TIMEOUT_S", "1500"))
+    failed = None  # (rank, exit code) of the first rank that failed
+    while failed is None and any(pr.poll() is None for pr in procs):
+        for r, pr in enumerate(procs):
+            rc = pr.poll()
+            if rc is not None and rc != 0:
+                failed = (r, rc)
+                break
+        if failed is None and time.monotonic() > deadline:
+            failed = (-1, "timeout")
+        if failed is None:
+            time.sleep(0.2)
+    if failed is None:
+        bad = [(r, pr.returncode) for r, pr in enumerate(procs) if pr.returncode != 0]
+        failed = bad[0] if bad else None
+    if failed is not None:
+        for pr in procs:  # the others: by their exact PIDs, politely, then not
+            if pr.poll() is None:
+                pr.terminate()
+        t_end = time.monotonic() + 20
+        for pr in procs:
+            try:
+                pr.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+    reader.join(timeout=10)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit(f"bench.py --gpus {args.gpus}: rank(s) failed (rank, exit code): {bad}")
+    for r, path in enumerate(errs):  # rank 0's stderr is the run's own; the others' only matter when something failed
+        if r == 0 or failed is not None:
+            text = _tail(path, 40 if failed is not None else 1000)
+            if text:
+                sys.stderr.write(text if r == 0 and failed is None else f"---- rank {r} stderr (tail) ----\n{text}")
+    if failed is not None:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: rank {failed[0]} failed (exit code {failed[1]}); the other ranks were stopped")
 
 
 def device_identity(torch, local_rank):
@@ -220,6 +267,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RT_BENCH_FAIL_RANK") == str(rank) and launched:
+        raise SystemExit(3)  # test hook: this rank dies before the rendezvous (tests/test_multigpu.py)
     # test hook (1-GPU box): all ranks on GPU 0 -- exercises the N > 1 code path (rendezvous, sharding, barrier,
     # max-over-ranks, rank-0 print) where only one GPU exists
     share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
@@ -235,7 +284,9 @@ def main():
     if world > 1:
         # control plane only (a barrier, one double, record counts): gloo at every N; the data path has no collective
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))  # a rank that never arrives: minutes, not half an hour
 
     from pyradiotracking_amd import shard, synth
     from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
@@ -456,6 +507,8 @@ def main():
             "records_per_step": n_records_total,
             "candidate_cells_per_step": n_hot_total,
             "sharding": "contiguous stream blocks per GPU (shard.stream_range), no collective; control plane on gloo",
+            "scaling_curves": "this line: " + ("one population sharded over the GPUs (strong)" if wl["scaling"] == "strong" else "256 streams per GPU (weak: the driver's bare command)")
+                              + "; north_star's sharded curve (config 4: 32 768 streams x 524 288 samples over N GPUs, strong): python bench.py --gpus N --workload config4; config 5: --workload config5",
             "lanes_per_gpu": args.lanes,
             "settle_steps": args.settle,
             "population_seed": seed,

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -99,3 +101,20 @@ def test_pmc_traffic_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path,
     f.write_text(json.dumps({"sources_sha256": bench.sources_sha256(), "bytes_per_launch_256_streams": 4456600000}))
     assert bench.pmc_traffic(True, 2)[0] == 2228300000
     assert bench.pmc_traffic(False, 2)[0] is None  # another workload
+
+
+def test_bench_refuses_more_gpus_than_the_box_has_within_seconds():
+    """`python bench.py --gpus N` asks a child process how many GPUs there are before it starts any rank (the parent stays
+    GPU-free) and says so instead of leaving ranks to wait for one another; here: none."""
+    import subprocess
+    import time
+
+    from pyradiotracking_amd import _native
+
+    if _native.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "RT_BENCH_SHARE_GPU")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env, cwd=REPO)
+    assert r.returncode != 0 and time.monotonic() - t0 < 60
+    assert "GPU(s)" in r.stderr and not r.stdout.strip()

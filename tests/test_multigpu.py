@@ -167,6 +167,25 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert all(x["name"] for x in devs)
 
 
+def test_bench_fails_fast_when_a_rank_dies_before_the_rendezvous():
+    """A rank that exits before it has joined (bad device ordinal, out of memory while generating IQ, an import error):
+    `python bench.py --gpus 2` stops the other rank by its PID and returns non-zero with the failed rank named, within
+    seconds -- not after the rendezvous store's time-out (reference: the supervisor loop that ends all analyzers when one
+    dies, __main__.py:152-190)."""
+    import time
+
+    env = dict(os.environ, RT_BENCH_SHARE_GPU="1", RT_BENCH_FAIL_RANK="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--settle", "2", "--streams", "32"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    took = time.monotonic() - t0
+    assert r.returncode != 0 and took < 60, (r.returncode, took, r.stderr[-2000:])
+    assert "rank 1 failed (exit code 3)" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # no result line of a run that did not happen
+
+
 def test_bench_line_prices_the_isolated_launch():
     """`roofline.frac` / `kernel_ms` describe the scan launch alone (one lane); the per-launch figures of the two-lane
     timed region sit beside them; the host sinks are reported outside `value`"""
