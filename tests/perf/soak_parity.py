@@ -21,7 +21,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 n_cases = n_records = n_bad = n_unexplained = n_field = 0
-case = 0
+case = int(os.environ.get("SOAK_FIRST_CASE", "1")) - 1  # (SOAK_FIRST_CASE=n: start at case n of the seed -- a case depends on (seed, case number) only)
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng([seed0, case])
@@ -240,6 +240,13 @@ while time.time() < t_end:
                     bad += 1
                     n_field += 1
                     print(f"  FIELD MISMATCH case {case} buf {k} stream {s}: gpu max/avg/std/noise/snr {g.max} {g.avg} {g.std} {g.noise} {g.snr} vs {x}")
+                    if os.environ.get("SOAK_DUMP_CELLS"):
+                        spec = oas[s].spec_last
+                        cells = spec[x.fi, max(x.start, 0):x.end]
+                        print(f"    oracle cells of the record (this buffer's part) {cells.tolist()}; strongest bin of the head segment {float(spec[:, max(x.start, 0)].max())}")
+                        # the samples of the record's segments (complex64 as the oracle saw them), for a fixture
+                        np.save(os.path.join(os.environ["SOAK_DUMP_CELLS"], f"case{case}_buf{k}_stream{s}_fi{x.fi}_seg{max(x.start, 0)}_{x.end}.npy"),
+                                chunk[s][max(x.start, 0) * nperseg:x.end * nperseg])
                     break
     b.close()
     n_cases += 1
