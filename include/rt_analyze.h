@@ -219,8 +219,8 @@ int rt_process_u8_host(rt_handle *h, const void *iq_u8_host, int64_t n_samples, 
  * a call that finds more records than the pool holds grows the pool and is analysed
  * again inside this function -- only rt_extract (whose spectrogram the library does
  * not keep) or a host without memory for the larger pool end in RT_E_CAPACITY for
- * that reason, and then every stream still delivers the first records, in emission
- * order, that fit (never an empty list).  RT_E_HOT_OVERFLOW (RT_MODE_SPARSE): no
+ * that reason, and then every stream still delivers the first records, in (bin, start)
+ * order -- the reference's append order -- that fit (never an empty list).  RT_E_HOT_OVERFLOW (RT_MODE_SPARSE): no
  * result, the call is consumed.
  * If an rt_process fails, nothing stays enqueued for it (with lanes: in no lane),
  * and the look-back state is the one before the call.

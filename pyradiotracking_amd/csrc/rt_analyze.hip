@@ -60,8 +60,11 @@ struct CallCtx {
     bool pool_grown = false;  // the record pool was enlarged for this call and the call analysed again (fetch_one)
     bool thr_rerun = false;   // analysed again on RT_MODE_RUNFILTER with thresholds from its own row means (once per call)
     bool abs_counted = false; // a MODE 4 / 6 scan of this call left the slot's h_abs_hot
+    bool level_settled = false;  // AUTO's level bookkeeping for this call is done (fetch_one passes over a call twice: size query / peek, then delivery)
+    bool ran_lin = false;     // its scans detrended by linearity (fetch_one: analysed again if the guard marks a stream)
+    uint64_t sub_epoch = 0;   // rt_handle::sub_epoch when its kernels were enqueued
     // handle state before this call (restored when the call is rolled back: a later lane failed to enqueue)
-    int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0;
+    int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0, prev_minsum_slot = -1;
 };
 
 struct Slot {
@@ -90,6 +93,7 @@ struct Slot {
     int32_t *h_no_last = nullptr;                              // pinned, [S]: streams without a previous buffer in this call
     int32_t *h_overflow = nullptr;                             // pinned, [S]: set by detect_bucket for a stream whose candidate lists overflowed
     int32_t *h_incons = nullptr;                               // pinned, [S]: ... and for one in which a run lacked its preceding cell
+    int32_t *h_dc_flag = nullptr;                              // pinned, [S]: set by a LIN scan for a stream whose constant offset is too large for that form (StftParams::dc_flag)
     int32_t *h_list = nullptr;                                 // pinned, [kMaxPartial]: the streams of a partial dense re-run (read by the kernels)
     unsigned long long *h_total = nullptr;                     // pinned: records allocated so far, uploaded before a partial re-run
     hipEvent_t ev_begin = nullptr, ev_scan = nullptr, ev_done = nullptr;
@@ -130,6 +134,13 @@ struct rt_handle {
     size_t lds_large = 0, lds_small = 0, lds_dense = 0;
 
     bool lin = false;      // constant detrend by linearity (cosine-sum window of order <= 1; rt_kernels.h: LIN)
+    // ... except for the streams its guard has marked (StftParams::dc_flag / sub_first): per stream, for good (an SDR's offset is a
+    // property of its hardware), so that a stream's results never depend on which other streams share its batch
+    int32_t *d_sub_first = nullptr;        // [S] non-zero = marked
+    std::vector<int32_t> h_sub_first;      // host copy
+    int32_t *h_sub_list = nullptr;         // pinned, device-visible: the marked streams, ascending (n_sub of them)
+    int n_sub = 0;
+    uint64_t sub_epoch = 0;                // changes of the set so far (a call analysed under an older one is analysed again)
     float lin_c[3] = {0.f, 0.f, 0.f};
 
     // AUTO mode: three ways to analyse a buffer, cheapest first -- RT_MODE_SPARSE (candidates emitted by the scan itself),
@@ -150,7 +161,8 @@ struct rt_handle {
     bool abs_hot_valid = false;
     int sticky_len = 16;
     uint64_t n_calls = 0;  // calls enqueued so far
-    uint64_t test_enqueues = 0;  // laned handle: rt_process calls seen (RT_TEST_FAIL_LANE)
+    uint64_t test_enqueues = 0;  // laned handle: rt_process calls seen (fault injection, read once at rt_create: RT_TEST_FAIL_LANE=<lane>:<n>)
+    int test_fail_lane = -1, test_fail_nth = 0;
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
     std::vector<uint8_t> reset_pending;  // [S] streams whose look-back is dropped at the next rt_process
@@ -228,10 +240,28 @@ void launch_stft_lin(rt_handle *h, const StftParams &p, int items) {
 // one; the linearity form leaves a residue 140 dB under the offset there -- found by the round-2 soak)
 template <int MODE, bool U8 = false>
 void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
-    if (h->lin && MODE != 3 && !U8)
-        launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, p, blocks);
-    else
+    if (h->lin && MODE != 3 && !U8) {
+        if (p.stream_list || h->n_sub == 0 || !p.sub_first) {
+            // (a launch over a list of its own -- AUTO's dense re-run of a few streams -- keeps the linearity form for all of them: its
+            // dense spectrogram is indexed by position in that list, which a second launch over a sub-list cannot address)
+            StftParams q = p;
+            if (p.stream_list) q.sub_first = nullptr;
+            launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, q, blocks);
+        } else {
+            // the streams the guard of that form has marked (StftParams::dc_flag): the first launch leaves them alone, the
+            // subtract-first instantiation takes them, by list
+            launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, p, blocks);
+            StftParams q = p;
+            q.sub_first = nullptr;
+            q.dc_flag = nullptr;
+            q.spec_by_stream = 1;
+            q.stream_list = h->h_sub_list;
+            q.n_streams = h->n_sub;
+            launch_stft_lin<MODE, U8, false>(h, q, h->n_sub * p.blocks_per_stream);
+        }
+    } else {
         launch_stft_lin<MODE, U8, false>(h, p, blocks);
+    }
 }
 
 // cells a run must have to pass the duration gate unless it runs through t = 0 (see rt_create)
@@ -342,6 +372,10 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.cell_need = sl.d_cell_need;
     p.seg_list = sl.d_seg_list;
     p.seg_count = sl.d_seg_list ? sl.d_seg_list + (size_t)h->cfg.n_streams * h->max_seg : nullptr;
+    p.dc_flag = h->lin ? sl.h_dc_flag : nullptr;
+    p.sub_first = h->lin ? h->d_sub_first : nullptr;
+    p.dc_limit = 1.0e6f * (float)h->N * (float)h->N * (float)h->cfg.sample_rate;  // 60 dB over the quietest bin's per-sample power
+    p.dc_limit2 = 100.0f * (float)h->N * (float)h->cfg.sample_rate;               // ... and 20 dB over everything else in those segments
     return p;
 }
 
@@ -445,6 +479,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     }
     if (!second_pass_only) RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
     if (launched) *launched = true;
+    sl.call.ran_lin = h->lin && !c.u8;
+    sl.call.sub_epoch = h->sub_epoch;
     const int slot_index = (int)(&sl - h->slot);
     if (mode == RT_MODE_RUNFILTER) {
         // per-bin thresholds from the latest chunk minima (the previous call's; on a re-run this call's own), before they are reset
@@ -467,7 +503,9 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     }
     if (sl.d_chunk_min && !second_pass_only) {
         RT_HIP(h, hipMemsetAsync(sl.d_chunk_min, 0x7f, (size_t)S * h->N * sizeof(uint32_t), h->s_scan));
-        h->minsum_slot = slot_index;
+        // the LATEST buffer's minima set the next call's thresholds: a call analysed again from rt_fetch (level-up, stale
+        // thresholds, pool growth, the detrend guard) while a later one is in flight must not take that place back
+        if (h->minsum_slot < 0 || sl.call.seq >= h->slot[h->minsum_slot].call.seq) h->minsum_slot = slot_index;
     }
     if (dense) {
         launch_scan<1>(h, sp, blocks, c.u8);
@@ -571,7 +609,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     } else {
         const int waves = S * kBuckets;
         hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
-        // always launched: it is also the pass that re-zeroes the per-bucket counters
+        // (the large instantiation returns at once for a stream without a bucket over kSmallBucket cells; the per-bucket counters
+        // are put back to zero by finalize_records)
         hipLaunchKernelGGL(detect_bucket<true>, dim3(S), dim3(256), h->lds_large, sd, a);  // one workgroup per stream: its 16 buckets in turn
         hipLaunchKernelGGL(finalize_records, dim3(S), dim3(256), 0, sd, a);
     }
@@ -673,6 +712,7 @@ void rollback_newest(rt_handle *h) {
         h->tail_cur = c.prev_tail_cur;
         h->n_seg_last = c.prev_n_seg_last;
         h->dense_sticky = c.prev_dense_sticky;
+        h->minsum_slot = c.prev_minsum_slot;  // (the chunk minima of the dropped buffer must not set the next call's thresholds)
         if (c.no_last) {
             for (int s = 0; s < h->cfg.n_streams; ++s)
                 if (best->h_no_last[s]) h->reset_pending[(size_t)s] = 1;
@@ -709,15 +749,11 @@ int for_each_lane(rt_handle *h, F call, bool enqueues = false) {
             }
         }
     }
-    // test hook (tests/test_gpu_parity.py, fault injection): RT_TEST_FAIL_LANE=<k>:<n> makes lane k refuse the n-th
-    // enqueue seen while the variable is set, as a device allocation failure inside that lane would
+    // test hook (tests/test_gpu_parity.py, fault injection): a handle created under RT_TEST_FAIL_LANE=<k>:<n> has its lane k
+    // refuse the handle's n-th enqueue, as a device allocation failure inside that lane would (the variable is read once,
+    // at rt_create; nothing looks at the environment on this path)
     int fail_lane = -1;
-    if (enqueues) {
-        if (const char *spec = std::getenv("RT_TEST_FAIL_LANE")) {
-            int lane = -1, nth = 0;
-            if (std::sscanf(spec, "%d:%d", &lane, &nth) == 2 && ++h->test_enqueues == (uint64_t)nth) fail_lane = lane;
-        }
-    }
+    if (enqueues && h->test_fail_lane >= 0 && ++h->test_enqueues == (uint64_t)h->test_fail_nth) fail_lane = h->test_fail_lane;
     for (size_t k = 0; k < h->kids.size(); ++k) {
         int rc;
         if ((int)k == fail_lane) {
@@ -771,6 +807,8 @@ void rt_destroy(rt_handle *h) {
     (void)hipFree(h->d_thr_nat);
     (void)hipFree(h->d_window);
     (void)hipFree(h->d_window_t);
+    (void)hipFree(h->d_sub_first);
+    (void)hipHostFree(h->h_sub_list);
     (void)hipFree(h->d_tw1);
     (void)hipFree(h->d_tw2);
     for (auto &t : h->d_tail) (void)hipFree(t);
@@ -804,6 +842,7 @@ void rt_destroy(rt_handle *h) {
         (void)hipHostFree(sl.h_no_last);
         (void)hipHostFree(sl.h_overflow);
         (void)hipHostFree(sl.h_incons);
+        (void)hipHostFree(sl.h_dc_flag);
         (void)hipHostFree(sl.h_list);
         (void)hipHostFree(sl.h_total);
         if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
@@ -834,6 +873,13 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         rt_handle *p = new (std::nothrow) rt_handle();
         if (!p) return fail_create(RT_E_NOMEM, "out of host memory");
         p->cfg = *cfg;
+        if (const char *spec = std::getenv("RT_TEST_FAIL_LANE")) {
+            int lane = -1, nth = 0;
+            if (std::sscanf(spec, "%d:%d", &lane, &nth) == 2 && lane >= 0 && nth > 0) {
+                p->test_fail_lane = lane;
+                p->test_fail_nth = nth;
+            }
+        }
         for (int k = 0; k <= lanes; ++k) p->kid_base.push_back((int)((int64_t)cfg->n_streams * k / lanes));
         for (int k = 0; k < lanes; ++k) {
             rt_config kc = *cfg;
@@ -993,6 +1039,10 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
         if (cus > 0) h->n_cu = cus;
     }
+    h->h_sub_first.assign((size_t)cfg->n_streams, 0);
+    RT_CREATE_HIP(hipMalloc(&h->d_sub_first, (size_t)cfg->n_streams * sizeof(int32_t)));
+    RT_CREATE_HIP(hipMemset(h->d_sub_first, 0, (size_t)cfg->n_streams * sizeof(int32_t)));
+    RT_CREATE_HIP(hipHostMalloc(&h->h_sub_list, (size_t)cfg->n_streams * sizeof(int32_t)));
     RT_CREATE_HIP(hipMalloc(&h->d_work, 2 * sizeof(uint32_t)));
     RT_CREATE_HIP(hipMemset(h->d_work, 0, 2 * sizeof(uint32_t)));
     RT_CREATE_HIP(hipMalloc(&h->d_window, sizeof(float) * N));
@@ -1101,6 +1151,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         std::memset(sl.h_overflow, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_incons, (size_t)S * sizeof(int32_t)));
         std::memset(sl.h_incons, 0, (size_t)S * sizeof(int32_t));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_dc_flag, (size_t)S * sizeof(int32_t)));
+        std::memset(sl.h_dc_flag, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_list, (size_t)kMaxPartial * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_total, sizeof(unsigned long long)));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_begin));
@@ -1241,6 +1293,7 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
     c.prev_tail_cur = h->tail_cur;
     c.prev_n_seg_last = h->n_seg_last;
     c.prev_dense_sticky = h->dense_sticky;
+    c.prev_minsum_slot = h->minsum_slot;
     c.iq = iq_dev;
     c.u8 = u8;
     c.n_samples = n_samples;
@@ -1299,6 +1352,7 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
     rc = enqueue();
     if (rc != RT_OK) {
         h->dense_sticky = c.prev_dense_sticky;
+        h->minsum_slot = c.prev_minsum_slot;
         if (c.no_last) {
             for (int s = 0; s < h->cfg.n_streams; ++s)
                 if (sl.h_no_last[s]) h->reset_pending[(size_t)s] = 1;
@@ -1455,6 +1509,39 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     h->info = rt_call_info{};
     h->info.n_seg = c.n_seg;
     h->info.n_hot = 0;
+    // Guard of the detrend by linearity (rt_kernels.h: StftParams::dc_flag).  The form carries a stream's constant offset through
+    // the transform: harmless while the offset is <= 60 dB over the per-sample noise (any <= 16-bit front end; <= 0.02 dB against
+    // the oracle), 0.06 - 0.17 dB at 80 dB.  A scan that meets such a stream marks it; from then on that stream -- and only that
+    // stream -- is detrended in SciPy's order (_spectral_py.py:2191-2194), and every call whose kernels were enqueued before the
+    // mark (this one, and any in flight) is analysed again.
+    if (c.ran_lin && !c.is_extract && c.n_seg > 0) {
+        bool newly = false;
+        for (int s = 0; s < h->cfg.n_streams; ++s) {
+            if (sl.h_dc_flag[s] != 0 && !h->h_sub_first[(size_t)s]) {
+                h->h_sub_first[(size_t)s] = 1;
+                newly = true;
+            }
+            sl.h_dc_flag[s] = 0;
+        }
+        if (newly) {
+            // (everything of this handle runs on s_scan: drained first, so that no kernel in flight reads the list while it changes)
+            RT_HIP(h, hipStreamSynchronize(h->s_scan));
+            h->n_sub = 0;
+            for (int s = 0; s < h->cfg.n_streams; ++s)
+                if (h->h_sub_first[(size_t)s]) h->h_sub_list[h->n_sub++] = s;
+            RT_HIP(h, hipMemcpy(h->d_sub_first, h->h_sub_first.data(), h->h_sub_first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            ++h->sub_epoch;
+        }
+        if (c.sub_epoch != h->sub_epoch) {
+            for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
+            c.n_dense_streams = 0;
+            int rc = enqueue_analysis(h, sl, c.mode_used);  // (takes the current epoch)
+            if (rc != RT_OK) return rc;
+            RT_HIP(h, hipEventSynchronize(sl.ev_done));
+            flags = sl.h_counters[2];
+            for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_dc_flag[s] = 0;  // (marked streams mark themselves again: nothing new)
+        }
+    }
   for (;;) {  // (a second round only after the record pool had to grow)
     while ((flags & kFlagHotOverflow) && !c.is_extract && c.mode_used != RT_MODE_DENSE) {
         // which streams overflowed?  (the flags are consumed here, whatever happens next)  The scan stops emitting for a
@@ -1563,7 +1650,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     if (h->cfg.mode == RT_MODE_AUTO && (c.mode_used == RT_MODE_RUNFILTER || c.mode_used == RT_MODE_PREFILTER) && !c.is_extract && c.n_seg > 0 &&
         h->info.n_hot * 32 > (int64_t)h->cfg.n_streams * c.n_seg * h->N)
         unselective = true;
-    if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && level_rank(c.mode_used) < level_rank(h->auto_level) && !unselective) {
+    if (c.level_settled) {
+        unselective = false;  // (settled on the first pass: the probe interval doubles once per call, not once per pass)
+    } else if (h->cfg.mode == RT_MODE_AUTO && !c.is_extract && !c.fell_back && c.n_seg > 0 && level_rank(c.mode_used) < level_rank(h->auto_level) && !unselective) {
         // a probe of a lower level went through: the handle moves there (and from the pre-filter level it will
         // probe the plain sparse path after the usual interval)
         h->auto_level = c.mode_used;
@@ -1579,6 +1668,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         h->dense_sticky = h->sticky_len;
         h->sticky_len = std::min(h->sticky_len * 2, 1024);
     }
+    c.level_settled = true;
     if (flags & kFlagInconsistent) {
         std::memset(sl.h_incons, 0, (size_t)h->cfg.n_streams * sizeof(int32_t));
         h->err = "internal: candidate list lacks the cell preceding a run";

@@ -87,6 +87,19 @@ struct StftParams {
     uint32_t *chunk_min;     // [S][N] float bits, or null: per bin the smallest sum of P over a complete chunk (group of chunks: minsum_group) of this call (atomicMin;
                              // the host presets 0x7f7f7f7f) -- the quiet level of the bin, for the next call's thr_bin (make_bin_thresholds)
     const float *thr_bin;    // MODE 6, or null: [S][LG][16] a second, per-bin threshold in lane order; a cell's bit is set only if it passes both
+    // LIN instantiations, guard of the detrend by linearity: a stream whose constant offset lies more than 60 dB over its quietest
+    // bin's per-sample power is marked (host-visible word); the host analyses the call again with that stream -- and only that
+    // stream, from then on -- on the subtract-first kernels (rt_fetch).  With D = the sum over an item's segments of
+    // |sum of the samples|^2 (N^2 x the power the mean subtraction removes), an item marks its stream when
+    // D > dc_limit x (smallest of its row sums, the bins 0 and +-1 aside)  [dc_limit = 1e6 N^2 fs: the offset 60 dB over the noise]
+    // and  D > dc_limit2 x (sum of its row sums)  [dc_limit2 = 100 N fs: the offset holds 20 dB more power than everything else in
+    // those segments -- a tag a fraction of a bin from the centre frequency also has a large segment mean, but what the mean
+    // subtraction leaves of it is as strong as what it takes, and the round-off of a strong tone is in every bin in either form].
+    int32_t *dc_flag;        // [S], or null: no guard
+    float dc_limit, dc_limit2;
+    const int32_t *sub_first;  // LIN instantiations, or null: [S] non-zero = a marked stream: this launch leaves it alone (its items end at
+                             // once), a second launch of the subtract-first instantiation over `stream_list` = the marked streams takes it
+    int32_t spec_by_stream;  // MODE 1 with a stream list: the dense spectrogram is indexed by stream, not by position in the list
 #ifdef RT_STAMPS
     uint32_t *dbg;           // [workgroups][4 waves][kStamps] cycles per stage, [kStamps - 1] = steps taken
 #endif
@@ -533,6 +546,19 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     }
     const int s_pos = item % p.n_streams;
     const int s = p.stream_list ? p.stream_list[s_pos] : s_pos;
+    if constexpr (LIN) {
+        if (p.sub_first && p.sub_first[s] != 0) {  // a stream the guard has marked: the subtract-first launch behind this one analyses it
+            if constexpr (!PERSIST) {
+                return;
+            } else {
+                __syncthreads();
+                if (tid == 0) *item_word = ticket;
+                __syncthreads();
+                item = (int)gridDim.x + (int)*item_word;
+                continue;
+            }
+        }
+    }
     const int cb = p.blocks_per_stream - 1 - item / p.n_streams;
     int chunk = cb * GPW + g;
     if constexpr (MODE == 5) {
@@ -596,6 +622,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     constexpr int kLinRegs = kLinIdx2 > kLinIdx1 ? kLinIdx2 + 1 : kLinIdx1 + 1;
     constexpr int kLinReg[3] = {kS0.reg, kLinIdx1 == 1 ? kS1.reg : kS2.reg, kS2.reg};
     float lin_k[3] = {0.f, 0.f, 0.f};
+    float dc_acc = 0.f;  // LIN: sum over the item's segments of |sum of the segment's samples|^2 (the same in every lane of a group)
     if constexpr (LIN) {
         if (lt == kS0.lane) lin_k[0] += p.lin_c[0];
         if (lt == kS1.lane) lin_k[kLinIdx1] += p.lin_c[1];
@@ -938,6 +965,9 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         RT_ABLATE_STOP(6)  // + pass 3
 
         if constexpr (LIN) {
+            if constexpr (SUMS) {
+                if (active && !halo) dc_acc = __builtin_fmaf(sum.x, sum.x, __builtin_fmaf(sum.y, sum.y, dc_acc));  // (guard of this form: StftParams::dc_flag)
+            }
             // X[k] -= (sum x) * W[k]/N for k in {0, 1, N-1}: the constant detrend, applied to the transform
 #pragma unroll
             for (int j = 0; j < kLinRegs; ++j) {
@@ -962,7 +992,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             const int col = seg - (T - p.tail_cols);
             const bool to_spec = (MODE == 1 || MODE == 2) && active && !halo;
             const bool to_tail = SUMS && active && !halo && col >= 0;
-            float *spec_dst = p.spec + ((int64_t)s_pos * T + seg) * N;
+            float *spec_dst = p.spec + ((int64_t)(p.spec_by_stream ? s : s_pos) * T + seg) * N;
             float *tail_dst = p.tail + ((int64_t)s * p.tail_cols + col) * N;
             // Sparse tail (the scans that keep threshold bits, MODE 0 / 4): the next buffer's look-back walks down from
             // the last segment while the cells pass the absolute threshold and stops ON the first that does not
@@ -1210,6 +1240,30 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     if constexpr (MODE == 3) {
         if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
     } else if constexpr (SUMS) {
+        if constexpr (LIN) {
+            if (p.dc_flag) {
+                // the quietest bin of this lane (bins 0 and +-1 carry what the detrend left) and the lane's total, then the wave's
+                // (wave-wide figures: at nperseg <= 512 a wave holds several chunks of the stream, from nperseg 2048 on a part of the bins)
+                float mn = 3.0e38f, tot = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool dc_bin = (r == kS0.reg && lt == kS0.lane) || (r == kS1.reg && lt == kS1.lane) || (r == kS2.reg && lt == kS2.lane);
+                    mn = fminf(mn, (dc_bin || !chunk_ok) ? 3.0e38f : acc[r]);
+                    tot += chunk_ok ? acc[r] : 0.f;
+                }
+                float dsum = chunk_ok ? dc_acc : 0.f;  // (the same in the LG lanes of a group)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mn = fminf(mn, __shfl_xor(mn, o));
+                    tot += __shfl_xor(tot, o);
+                    dsum += __shfl_xor(dsum, o);
+                }
+                constexpr int kLanesPerGroup = LG < 64 ? LG : 64;
+                const float groups = (float)__builtin_popcountll(__builtin_amdgcn_ballot_w64(chunk_ok)) / (float)kLanesPerGroup;
+                const float d = dsum / (float)kLanesPerGroup;  // D summed over the wave's groups
+                if (d > p.dc_limit * mn * groups && d > p.dc_limit2 * tot && (threadIdx.x & 63) == 0) p.dc_flag[s] = 1;
+            }
+        }
         // deterministic workgroup reduction of the lane groups' row sums: one
         // partial row per workgroup (fixed summation order, no float atomics)
         __syncthreads();
@@ -1766,7 +1820,7 @@ __device__ void publish_records(const DetectArgs &a, RecLds &l, int s, int n) {
     int *lds_base = l.count + 1;
     if (threadIdx.x == 0) {
         long long base = (long long)atomicAdd(&a.counters[0], (unsigned long long)n);
-        // a pool too short for this stream: the first records (in emission order) that still fit are delivered, the
+        // a pool too short for this stream: the first records (in (bin, start) order) that still fit are delivered, the
         // call is flagged, and counters[0] tells the host how large a pool the call wants (rt_fetch grows it)
         long long fit = a.pool_cap - base;
         fit = fit < 0 ? 0 : (fit > n ? n : fit);
@@ -2327,7 +2381,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
         const unsigned long long v = atomicAdd(&a.counters[0], (unsigned long long)n | (1ull << kTicketShift));
         const unsigned long long mask = (1ull << kTicketShift) - 1ull;
         const long long base = (long long)(v & mask);
-        // a pool too short for this stream: its first records (in emission order) that still fit are delivered; the
+        // a pool too short for this stream: its first records (in (bin, start) order) that still fit are delivered; the
         // call's total below tells the host how large a pool the call wants (rt_fetch grows it and runs the call again)
         long long fit = a.pool_cap - base;
         fit = fit < 0 ? 0 : (fit > n ? n : fit);

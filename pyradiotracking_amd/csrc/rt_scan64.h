@@ -168,6 +168,7 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
         do {  // one item (break = nothing (more) to do for it)
             const int s_pos = item % p.n_streams;
             const int s = p.stream_list ? p.stream_list[s_pos] : s_pos;
+            if (LIN && p.sub_first && p.sub_first[s] != 0) break;  // a stream the guard of this form has marked: the subtract-first launch behind this one analyses it
             const int pb = item / p.n_streams;
             int chunk = p.blocks_per_stream - 1 - pb;  // latest chunks first: the ones that also write the tail run longest
             if constexpr (MODE == 5) {
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
             bits64 allhot{~0u, ~0u};            // FLAGS: the chunk's bits so far
             bits64 need{~0u, ~0u};              // MODE 5: the lane's bins that may emit in every segment of the chunk
             uint32_t n_abs = 0;                 // MODE 4 / 6: this lane's cells at or above the absolute threshold
+            float dc_acc = 0.f;                 // LIN: sum over the item's segments of |sum of the segment's samples|^2 (wave-uniform)
             int stg_n = 0;                      // wave-uniform fill level of the staging area
             bool gave_up = false;               // wave-uniform: a candidate list of this stream has overflowed
             if constexpr (MODE == 5) {
@@ -434,6 +436,9 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                 dft64(u);
                 RT_STAMP(8);  // pass 2
                 if constexpr (LIN) {
+                    if constexpr (SUMS) {
+                        if (!halo) dc_acc = __builtin_fmaf(sum.x, sum.x, __builtin_fmaf(sum.y, sum.y, dc_acc));  // (guard of this form: StftParams::dc_flag)
+                    }
                     // X[k] -= (sum x) W[k] / N for k in {0, 1, N - 1}: the constant detrend, applied to the transform
                     // (FFT(w (x - m)) = FFT(w x) - m W, W real and confined to those bins for a cosine-sum window of order <= 1)
                     const float k0 = lane == 0 ? p.lin_c[0] : lane == 1 ? p.lin_c[1] : 0.f;
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                 }
                 // spectrogram row (dense modes) and look-back tail column (the last K segments): bin = lane + 64 r
                 if constexpr (MODE == 1 || MODE == 2) {
-                    const rsrc_t rs = make_rsrc(p.spec + ((int64_t)s_pos * T + seg) * N, (uint32_t)(N * sizeof(float)));
+                    const rsrc_t rs = make_rsrc(p.spec + ((int64_t)(p.spec_by_stream ? s : s_pos) * T + seg) * N, (uint32_t)(N * sizeof(float)));
 #pragma unroll
                     for (int r = 0; r < 64; ++r) raw_buffer_store_f1(P[r], rs, lane * 4, 256 * r, 0);
                 }
@@ -638,6 +643,23 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
             if constexpr (MODE == 3) {
                 if (acc[0] == 12345.678f) p.psum[0] = acc[0];  // keeps the loads alive, never true in practice
             } else if constexpr (SUMS) {
+                if constexpr (LIN) {
+                    if (p.dc_flag) {  // guard of the detrend by linearity (StftParams::dc_flag): the quietest bin (the bins 0 and +-1 aside), the total
+                        float mn = 3.0e38f, tot = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 64; ++r) {
+                            const bool dc_bin = (r == 0 && lane <= 1) || (r == 63 && lane == 63);
+                            mn = fminf(mn, dc_bin ? 3.0e38f : acc[r]);
+                            tot += acc[r];
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            mn = fminf(mn, __shfl_xor(mn, o));
+                            tot += __shfl_xor(tot, o);
+                        }
+                        if (dc_acc > p.dc_limit * mn && dc_acc > p.dc_limit2 * tot && lane == 0) p.dc_flag[s] = 1;
+                    }
+                }
                 // one partial row of sums per item (= chunk): the detection adds a stream's rows in chunk order, float64
                 const rsrc_t rp = make_rsrc(p.psum + ((int64_t)s * p.blocks_per_stream + chunk) * N, (uint32_t)(N * sizeof(float)));
 #pragma unroll

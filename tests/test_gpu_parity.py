@@ -626,13 +626,16 @@ def test_detrend_by_linearity_equals_subtract_first(nperseg, window):
 def test_detrend_by_linearity_under_a_large_dc_offset(nperseg, noise_sigma):
     """An RTL-SDR's DC spike is 0.05 .. 0.1 of full scale.  The linearity form carries the whole offset through the
     window multiply and every butterfly (the subtract-first form removes it first): float32 round-off of the offset,
-    ~eps * |DC| * (butterfly growth), lands in every bin.  Pinned here, offset 0.1 - 0.07j, every bin but 0 and +-1, cells at
-    the noise level or above, against the oracle:
+    ~eps * |DC| * (butterfly growth), lands in every bin.  Offset 0.1 - 0.07j, every bin but 0 and +-1, cells at the noise
+    level or above, against the oracle:
       * offset 60 dB over the noise (sigma 1e-4; a 16-bit front end cannot show more): both forms within 0.03 dB
         (measured 0.011 .. 0.019 for the linearity form, 0.005 .. 0.02 for subtract-first);
-      * offset 80 dB over the noise (sigma 1e-5): subtract-first within 0.05 dB; the linearity form 0.06 dB at
-        nperseg 256, 0.11 dB at 1024 and 0.17 dB at nperseg 4096 -- beyond the +-0.1 dB bar there, which is why such input wants
-        `subtract_first=True`; asserted: < 0.25 dB, and the records still the oracle's."""
+      * offset 80 dB over the noise (sigma 1e-5): subtract-first within 0.05 dB; the linearity form on its own 0.06 dB at
+        nperseg 256, 0.11 dB at 1024 and 0.17 dB at nperseg 4096 -- beyond the +-0.1 dB bar there.  The scans guard the form
+        (StftParams::dc_flag): a stream whose offset lies > 60 dB over its quietest bin marks the call, rt_fetch analyses it
+        again subtract-first and the handle stays there.  Asserted: a DEFAULT handle is within the subtract-first bound at
+        both offsets once it has analysed a buffer (and its records are the oracle's); the unguarded form (a handle that has
+        only served rt_spectrogram) shows what the guard avoids."""
     _need_gpu()
     fs, n = 2048000, 48 * 4096
     n_seg = n // nperseg
@@ -647,28 +650,34 @@ def test_detrend_by_linearity_under_a_large_dc_offset(nperseg, noise_sigma):
     others = np.ones(nperseg, bool)
     others[[0, 1, nperseg - 1]] = False
     worst = {}
-    for first in (False, True):
+    for name, first, analyse in (("default (guarded)", False, True), ("subtract-first", True, True), ("linearity, unguarded", False, False)):
         b = _batch_for(kw, 2, n, "sparse", subtract_first=first)
         d_iq = _native.DeviceBuffer(0, iq.nbytes)
         d_iq.upload(iq)
         d_out = _native.DeviceBuffer(0, 2 * n_seg * nperseg * 4)
-        b.native.spectrogram_device(d_iq.ptr, n, n, d_out.ptr)
+        rec = None
+        if analyse:
+            b.enqueue(iq)
+            rec = b.fetch_records()
+        b.native.spectrogram_device(d_iq.ptr, n, n, d_out.ptr)  # (the form the handle uses from here on)
         spec = d_out.download(np.float32, 2 * n_seg * nperseg).reshape(2, n_seg, nperseg)
-        b.enqueue(iq)
-        rec = b.fetch_records()
-        bound = 0.03 if noise_sigma > 5e-5 else (0.05 if first else 0.25)
+        bound = 0.03 if noise_sigma > 5e-5 else (0.05 if analyse else 0.25)
         for s in range(2):
             _, _, want = oracle.stft_power(iq[s], fs, window, nperseg)
             o = want.T[:, others].astype(np.float64)  # [T, bins]
             g = spec[s][:, others].astype(np.float64)
             sel = o > 0.5 * np.median(o)
             dev = np.abs(10 * np.log10(g[sel] / o[sel]))
-            worst[("subtract-first" if first else "linearity", s)] = round(float(dev.max()), 5)
-            assert dev.max() < bound, (nperseg, noise_sigma, "subtract-first" if first else "linearity", s, float(dev.max()))
-            sigs, kept = oracle.OracleAnalyzer(device=str(s), **kw).process(iq[s], gu.TS0)
-            mine = rec[rec["stream"] == s]
-            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(v.fi, v.start, v.end) for v in sigs], (nperseg, first, s)
-            assert len(sigs) > 0
+            worst[(name, s)] = round(float(dev.max()), 5)
+            assert dev.max() < bound, (nperseg, noise_sigma, name, s, float(dev.max()))
+            if rec is not None:
+                sigs, kept = oracle.OracleAnalyzer(device=str(s), **kw).process(iq[s], gu.TS0)
+                mine = rec[rec["stream"] == s]
+                assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(v.fi, v.start, v.end) for v in sigs], (nperseg, name, s)
+                assert len(sigs) > 0
+                for g_, v in zip(b._decoder.signals(mine, ["0", "1"], [gu.TS0] * 2), sigs):
+                    for fld in ("max", "avg", "noise", "snr"):
+                        assert abs(getattr(g_, fld) - getattr(v, fld)) < (0.03 if noise_sigma > 5e-5 else 0.05), (nperseg, name, fld)
         b.close()
     print(f"nperseg {nperseg} sigma {noise_sigma}: worst dB deviation {worst}")
 
@@ -1666,14 +1675,14 @@ def test_lanes_stay_in_step_when_a_later_lane_refuses_an_enqueue(monkeypatch):
     for k in (0, 1, 3):  # the refused call (buffer 2) never happened
         ref.enqueue(bufs[k])
         want[k] = ref.fetch_records()
+    monkeypatch.setenv("RT_TEST_FAIL_LANE", "1:3")  # (read once, when the handle is created: its lane 1 refuses its third enqueue)
     b = _batch_for(kw, S, blen, "sparse", lanes=2)
+    monkeypatch.delenv("RT_TEST_FAIL_LANE")
     b.enqueue(bufs[0])
     b.enqueue(bufs[1])
-    monkeypatch.setenv("RT_TEST_FAIL_LANE", "1:1")
     with pytest.raises(_native.NativeError) as e:
         b.enqueue(bufs[2])
     assert e.value.code == _native.RT_E_NOMEM
-    monkeypatch.delenv("RT_TEST_FAIL_LANE")
     assert b.fetch_records().tobytes() == want[1].tobytes()  # the one call both lanes still hold
     with pytest.raises(_native.NativeError):
         b.fetch_records()  # nothing else is pending, in either lane
