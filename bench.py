@@ -134,14 +134,51 @@ def resolve_workload(args, world):
     return w
 
 
-def sources_sha256():
-    """Hash of the kernel sources this run was built from (ties profiles/pmc_traffic.json to them)."""
-    h = hashlib.sha256()
-    csrc = os.path.join(REPO, "pyradiotracking_amd", "csrc")
-    for name in ("rt_kernels.h", "rt_analyze.hip", "rt_fft.h", "rt_core.h"):
-        with open(os.path.join(csrc, name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()
+SCAN_KERNEL_SYMBOL = "_ZN2rt9stft_scanILi1ELi0ELb0ELb1EEEvNS_10StftParamsE"  # rt::stft_scan<1, 0, false, true>: the default workload's scan
+
+
+def scan_kernel_sha256(lib_path=None, symbol=SCAN_KERNEL_SYMBOL):
+    """sha256 of the MACHINE CODE of the default workload's scan kernel inside the built library (the gfx950 code object of
+    the offload bundle, the symbol's bytes in .text).  It ties profiles/pmc_traffic.json to the kernel that was measured:
+    edits that cannot change that kernel's traffic (host code, other kernels, comments) leave it alone, anything that
+    changes its instructions changes it.  None if the library or the symbol cannot be read."""
+    import struct
+
+    path = lib_path or os.environ.get("RT_ANALYZE_LIB") or os.path.join(REPO, "pyradiotracking_amd", "librt_analyze.so")
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+        if i < 0:
+            return None
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        off, elf = i + 32, None
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl]
+            off += tl
+            if b"gfx950" in triple and sz:
+                elf = data[i + o:i + o + sz]
+        if elf is None or elf[:4] != b"\x7fELF":
+            return None
+        shoff, = struct.unpack_from("<Q", elf, 0x28)
+        shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + k * shentsize) for k in range(shnum)]  # name, type, flags, addr, offset, size, link, info, align, entsize
+        for sec in secs:
+            if sec[1] not in (2, 11):  # SHT_SYMTAB, SHT_DYNSYM
+                continue
+            strtab = secs[sec[6]]
+            for k in range(sec[5] // 24):
+                st_name, _info, _other, shndx, value, size = struct.unpack_from("<IBBHQQ", elf, sec[4] + 24 * k)
+                end = elf.index(b"\0", strtab[4] + st_name)
+                if elf[strtab[4] + st_name:end].decode(errors="replace") == symbol and size and 0 < shndx < shnum:
+                    text = secs[shndx]
+                    start = text[4] + (value - text[3])
+                    return hashlib.sha256(elf[start:start + size]).hexdigest()
+    except (OSError, struct.error, ValueError, IndexError):
+        return None
+    return None
 
 
 def pmc_traffic(default_workload, lanes):
@@ -154,8 +191,9 @@ def pmc_traffic(default_workload, lanes):
             doc = json.load(f)
     except (OSError, ValueError):
         return None, "profiles/pmc_traffic.json missing"
-    if doc.get("sources_sha256") != sources_sha256():
-        return None, "kernel sources changed since profiles/pmc_traffic.json was measured (run tools/profile_round.sh)"
+    have = scan_kernel_sha256()
+    if have is None or doc.get("scan_kernel_sha256") != have:
+        return None, "the scan kernel's machine code differs from the one profiles/pmc_traffic.json was measured on (run tools/profile_round.sh)"
     return int(doc["bytes_per_launch_256_streams"]) // lanes, "bytes/launch: PMC FETCH_SIZE (calibrated on the kernel's own load stream) + WRITE_SIZE on one 256-stream launch; " + doc.get("source", "profiles/pmc_traffic.json")
 
 

@@ -89,16 +89,23 @@ def test_bench_workloads_follow_baseline_configs():
     assert a.lanes == 2
 
 
-def test_pmc_traffic_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+def test_pmc_traffic_is_only_quoted_for_the_kernel_it_was_measured_on(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json carries the sha256 of the scan kernel's machine code (the symbol's bytes in the gfx950 code
+    object of the built library): the figure is quoted while the library that runs holds that very kernel -- host-side edits
+    and other kernels do not invalidate it, a different scan kernel does"""
     import json
 
     bench = _bench_module()
+    have = bench.scan_kernel_sha256()
+    assert have is not None and len(have) == 64  # (build() has run: the library is there)
+    assert bench.scan_kernel_sha256(symbol="_ZN2rt9stft_scanILi1ELi1ELb0ELb1EEEvNS_10StftParamsE") not in (None, have)  # another instantiation, another hash
+    assert bench.scan_kernel_sha256(symbol="no_such_kernel") is None
     f = tmp_path / "pmc_traffic.json"
     monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(f))
     assert bench.pmc_traffic(True, 2)[0] is None  # no file
-    f.write_text(json.dumps({"sources_sha256": "0" * 64, "bytes_per_launch_256_streams": 4456600000}))
+    f.write_text(json.dumps({"scan_kernel_sha256": "0" * 64, "bytes_per_launch_256_streams": 4456600000}))
     assert bench.pmc_traffic(True, 2)[0] is None  # stale
-    f.write_text(json.dumps({"sources_sha256": bench.sources_sha256(), "bytes_per_launch_256_streams": 4456600000}))
+    f.write_text(json.dumps({"scan_kernel_sha256": have, "bytes_per_launch_256_streams": 4456600000}))
     assert bench.pmc_traffic(True, 2)[0] == 2228300000
     assert bench.pmc_traffic(False, 2)[0] is None  # another workload
 

@@ -12,4 +12,4 @@ head -2 profiles/${pre}_kernel_stats_bench_two_lanes.csv | cut -c1-140; head -2 
 python tools/show_bench.py profiles/${pre}_bench_output_under_rocprof_two_lanes.json; python tools/show_bench.py profiles/${pre}_bench_output_under_rocprof_one_lane.json
 python -c "
 import sys; sys.path.insert(0,'.')
-import bench, json; print('pmc hash matches sources:', bench.sources_sha256() == json.load(open('profiles/pmc_traffic.json'))['sources_sha256'])"
+import bench, json; print('pmc hash matches the built scan kernel:', bench.scan_kernel_sha256() == json.load(open('profiles/pmc_traffic.json'))['scan_kernel_sha256'])"

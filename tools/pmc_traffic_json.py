@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the two rocprofv3 --pmc passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE over tools/profile_traffic.py)
-into profiles/pmc_traffic.json: corrected HBM bytes per scan launch of the default workload, tied to the kernel sources
-by their sha256 (bench.py quotes `roofline.traffic` only while that hash matches the sources it runs).
+into profiles/pmc_traffic.json: corrected HBM bytes per scan launch of the default workload, tied to the scan kernel's
+machine code by its sha256 (bench.py quotes `roofline.traffic` only while that hash matches the library it runs).
 
 usage: pmc_traffic_json.py <fetch-dir> <write-dir> <traffic.json printed by profile_traffic.py> <out.json> [source note]
 
@@ -31,7 +31,7 @@ def means(d, counter):
 def main():
     fetch_dir, write_dir, traffic_json, out = sys.argv[1:5]
     note = sys.argv[5] if len(sys.argv) > 5 else ""
-    import bench  # sources_sha256 (same function the bench checks with)
+    import bench  # scan_kernel_sha256 (same function the bench checks with)
 
     with open(traffic_json) as f:
         exact = json.loads(f.read().strip().splitlines()[-1])
@@ -46,7 +46,8 @@ def main():
     write_b = scan_w[0] * 1024
     doc = {
         "workload": f"config2: {exact['streams']} streams x {exact['segments'] * exact['nperseg']} samples, nperseg {exact['nperseg']}, one launch",
-        "sources_sha256": bench.sources_sha256(),
+        "scan_kernel": "rt::stft_scan<1, 0, false, true>",
+        "scan_kernel_sha256": bench.scan_kernel_sha256(),
         "bytes_per_launch_256_streams": int(round(read_b + write_b)),
         "read_bytes": int(round(read_b)),
         "write_bytes": int(round(write_b)),
