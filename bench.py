@@ -607,8 +607,10 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
         return round(count * reps / t, 1)
 
     out["signal_objects_per_s"] = rate(lambda: decoder.signals(kept, device_names, ts0), len(kept))
+    out["signal_batch_records_per_s"] = rate(lambda: decoder.signal_batch(kept, device_names, ts0), len(kept))
     out["csv_rows_per_s"] = rate(lambda: consume.format_signals("csv", consume.rows_from_analysis(rec, decoder, ts0_us), device_names), len(kept))
     out["note"] = ("signal_objects_per_s: Signal objects built from the records that pass the shadow filter (the reference's signal_queue.put payload); "
+                   "signal_batch_records_per_s: the same nine fields per record as a lazy sequence (SignalBatch: columns at once, a Signal object when an element is asked for); "
                    "csv_rows_per_s: the same records to `;`-separated CSV rows through rows_from_analysis + rt_format_signals")
     return out
 

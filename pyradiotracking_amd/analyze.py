@@ -21,6 +21,7 @@ Two entry levels:
 """
 from __future__ import annotations
 
+import collections.abc
 import datetime
 import logging
 import time
@@ -104,27 +105,89 @@ class _RecordDecoder:
         frequency = (self.freqs if freqs is None else np.asarray(freqs))[rec["fi"]] + self.center_freq  # :360
         return t_start, duration_s, frequency, max_dbw, avg_dbw, rec["std_db"], noise_dbw, snr_db
 
-    def signals(self, rec: np.ndarray, device_names: Sequence[str], ts_starts: Sequence[datetime.datetime]) -> List[Signal]:
+    def signal_columns(self, rec: np.ndarray, device_names: Sequence[str], ts_starts: Sequence[datetime.datetime]):
+        """The nine ``Signal`` fields of every record of ``rec`` as nine Python lists (analyze.py:420-450), the reference's
+        expressions evaluated column-wise: start and duration are whole hops, so a call holds few distinct values of either and
+        one ``timedelta`` serves all records that share it; a stream's start time is taken to UTC once where its UTC offset
+        does not change over the buffer (else record by record, as the reference does)."""
         t_start, duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = self.decode(rec)
-        out = []
+
+        def deltas(x):
+            uniq, inv = np.unique(x, return_inverse=True)
+            objs = np.empty(len(uniq), dtype=object)
+            objs[:] = [datetime.timedelta(seconds=v) for v in uniq.tolist()]  # :428, :434
+            return objs, inv
+
+        start_td, start_i = deltas(t_start)
+        dur_td, dur_i = deltas(duration_s)
         streams = rec["stream"]
-        for i in range(len(rec)):
-            s = int(streams[i])
-            ts = ts_starts[s] + datetime.timedelta(seconds=float(t_start[i]))  # :434
-            out.append(
-                Signal(
-                    device_names[s],
-                    ts.astimezone(pytz.utc),  # :449
-                    frequency[i],
-                    datetime.timedelta(seconds=float(duration_s[i])),  # :428
-                    max_dbw[i],
-                    avg_dbw[i],
-                    std_db[i],
-                    noise_dbw[i],
-                    snr_db[i],
-                )
-            )
+        utc = pytz.utc
+        # (ts_start + delta).astimezone(utc) == ts_start.astimezone(utc) + delta unless the zone's offset changes in between:
+        # checked per stream at both ends of what the call can hold
+        lo, hi = start_td[0], start_td[-1]
+        n_names = len(device_names)
+        base = np.empty(n_names, dtype=object)
+        exact = True
+        for s_ in np.unique(streams).tolist():
+            b0 = ts_starts[s_]
+            bu = b0.astimezone(utc)
+            base[s_] = bu
+            exact = exact and (b0 + lo).astimezone(utc) == bu + lo and (b0 + hi).astimezone(utc) == bu + hi
+        starts = start_td[start_i].tolist()
+        if exact:
+            ts = [b + d for b, d in zip(base[streams].tolist(), starts)]  # :434, :449
+        else:
+            ts = [(ts_starts[s_] + d).astimezone(utc) for s_, d in zip(streams.tolist(), starts)]
+        names = np.empty(n_names, dtype=object)
+        names[:] = list(device_names)
+        cols = [np.asarray(c, dtype=np.float64).tolist() for c in (frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db)]  # float(np.float32): exact
+        return [names[streams].tolist(), ts, cols[0], dur_td[dur_i].tolist()] + cols[1:]
+
+    def signals(self, rec: np.ndarray, device_names: Sequence[str], ts_starts: Sequence[datetime.datetime]) -> List[Signal]:
+        """``Signal`` objects of ``rec``: the columns above, the objects filled slot by slot (what ``Signal.__init__`` would store
+        for these types, without its conversions)."""
+        n = len(rec)
+        if n == 0:
+            return []
+        new = Signal.__new__
+        out = [new(Signal) for _ in range(n)]
+        for sig, dv, ts, fr, du, mx, av, sd, no, sn in zip(out, *self.signal_columns(rec, device_names, ts_starts)):
+            sig.device = dv
+            sig.ts = ts
+            sig.frequency = fr
+            sig.duration = du
+            sig.max = mx
+            sig.avg = av
+            sig.std = sd
+            sig.noise = no
+            sig.snr = sn
         return out
+
+    def signal_batch(self, rec: np.ndarray, device_names: Sequence[str], ts_starts: Sequence[datetime.datetime]) -> "SignalBatch":
+        """The same signals as a lazy sequence: the field columns are built at once, a ``Signal`` object only when an element
+        is asked for -- for consumers that look at some of the signals, or hand the columns on (CSV rows, the matcher)."""
+        if len(rec) == 0:
+            return SignalBatch([[] for _ in range(9)])
+        return SignalBatch(self.signal_columns(rec, device_names, ts_starts))
+
+
+class SignalBatch(collections.abc.Sequence):
+    """A read-only sequence of ``Signal`` over nine field columns (``_RecordDecoder.signal_batch``)."""
+
+    __slots__ = ("columns",)
+
+    def __init__(self, columns):
+        self.columns = columns
+
+    def __len__(self):
+        return len(self.columns[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return SignalBatch([c[i] for c in self.columns])
+        sig = Signal.__new__(Signal)
+        (sig.device, sig.ts, sig.frequency, sig.duration, sig.max, sig.avg, sig.std, sig.noise, sig.snr) = [c[i] for c in self.columns]
+        return sig
 
 
 class BatchSignalAnalyzer:
