@@ -114,6 +114,7 @@ struct rt_handle {
     int max_blocks = 0;  // workgroups per stream at max_chunks
     hipStream_t s_scan = nullptr;
     bool own_scan_stream = false;
+    hipStream_t s_detect = nullptr;  // the sparse detection's own (lower-priority) stream where the handle owns its streams, else = s_scan
     std::string err;
 
     int n_cu = 256;            // compute units of the device (the scan's grid: launch_stft_lin)
@@ -597,7 +598,15 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
 
-    hipStream_t sd = h->s_scan;  // in order behind the scan (see the header comment)
+    // The sparse detection runs on a stream of its own behind the scan's event (where rt_create made one): with two calls in flight
+    // the NEXT call's scan is ready at the same moment, and the detection kernels share the chip with its first workgroups
+    // (nperseg <= 512: one workgroup per item) or move into the CUs its waves leave at its end (nperseg 4096: a persistent grid
+    // whose waves finish an item apart) instead of taking a stretch of their own between two scans.  Safe by the slots: a call's
+    // candidate lists, row sums and record pool are its slot's, the look-back tail it reads is two rotations from the one the next
+    // scan writes, and a scan that reuses the slot waits for this call's ev_done (claim_slot).  The dense path stays in order on
+    // the scan's stream: its spectrogram is one per handle.
+    hipStream_t sd = dense ? h->s_scan : h->s_detect;
+    if (sd != h->s_scan) RT_HIP(h, hipStreamWaitEvent(sd, sl.ev_scan, 0));
     DetectArgs a = make_detect_args(h, sl, c.n_seg, h->N, c.n_seg_last);
     a.prev = h->d_tail[c.tail_read];
     a.prev_cols = h->K;
@@ -685,8 +694,8 @@ int grow_pool(rt_handle *h, Slot &sl, int64_t want) {
 // before its scratch is rewritten (its results, if never fetched, are dropped)
 int claim_slot(rt_handle *h, Slot **out, CallCtx *saved) {
     Slot &sl = h->slot[h->n_calls % kSlots];
-    // (everything of this handle runs in order on one stream, so the slot's previous GPU work is over
-    // before anything enqueued from here on starts: no event wait needed)
+    // the slot's previous call may still be in its detection (a stream of its own): what is enqueued from here on waits for it
+    if (sl.call.seq != 0 && h->s_detect != h->s_scan) (void)hipStreamWaitEvent(h->s_scan, sl.ev_done, 0);
     if (sl.pool_cap < h->pool_want && !sl.call.pending) {
         // the other slot's pool had to grow: this one follows before its next call needs it (best effort)
         if (sl.call.seq == 0 || hipEventSynchronize(sl.ev_done) == hipSuccess) (void)grow_pool(h, sl, h->pool_want);
@@ -849,6 +858,7 @@ void rt_destroy(rt_handle *h) {
         if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     }
+    if (h->own_scan_stream && h->s_detect && h->s_detect != h->s_scan) (void)hipStreamDestroy(h->s_detect);
     if (h->own_scan_stream && h->s_scan) (void)hipStreamDestroy(h->s_scan);
     delete h;
 }
@@ -1000,9 +1010,17 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
 
     if (cfg->hip_stream) {
         h->s_scan = static_cast<hipStream_t>(cfg->hip_stream);
+        h->s_detect = h->s_scan;  // (a caller's stream: everything in order on it)
     } else {
         RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking));
         h->own_scan_stream = true;
+        // The sparse detection on a stream of its own (enqueue_analysis) -- where it pays.  Measured on one box, whole path, against
+        // everything in order on one stream (profiles/r04_e_*): config 2 one lane 0.82 -> 0.74 ms per step, two lanes 0.707 -> 0.687;
+        // config-5 share (nperseg 4096, one lane) 5.60 -> 5.49; but config 3 (nperseg 1024) 14.87 -> 15.7: behind a persistent grid
+        // of 16-point-per-lane workgroups the next scan takes the chip first, the detection runs at its very end and rt_fetch --
+        // and with it the host's next rt_process -- returns a scan later than it could.  Stream priorities changed none of this.
+        if (R3 == 4 || R3 == 8) h->s_detect = h->s_scan;
+        else RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_detect, hipStreamNonBlocking));
     }
 
     const int S = cfg->n_streams, N = h->N, LG = h->LG;
@@ -1216,6 +1234,7 @@ int rt_set_stream_params(rt_handle *h, const float *threshold, const float *cali
     RT_HIP(h, hipSetDevice(h->cfg.device));
     // kernels in flight read the arrays: let them finish first (a configuration call, not on the hot path)
     RT_HIP(h, hipStreamSynchronize(h->s_scan));
+    RT_HIP(h, hipStreamSynchronize(h->s_detect));
     const size_t bytes = (size_t)h->cfg.n_streams * sizeof(float);
     auto put = [&](float *&dst, const float *src) -> int {
         if (!src) {
@@ -1360,6 +1379,7 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
         }
         if (launched) {
             (void)hipStreamSynchronize(h->s_scan);
+            (void)hipStreamSynchronize(h->s_detect);
             sl.call = CallCtx{};
         } else {
             sl.call = saved;
