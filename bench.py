@@ -391,17 +391,18 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def run(an, n_steps):
+    def run(an, n_steps, serial=False):
         """n_steps full steps (enqueue + fetch each).  The handle keeps two calls in flight, so
         step i+1 is enqueued before step i is fetched: its scan overlaps step i's detect kernels,
-        record copy and host-side fetch.  Every step's work completes inside this function."""
+        record copy and host-side fetch.  Every step's work completes inside this function.
+        `serial`: one call in flight (a step is fetched before the next is enqueued): nothing runs beside a scan launch."""
         acc = [0.0, 0.0, 0]
         rec = info = None
         enq = an.enqueue_bytes if u8 else an.enqueue
-        if n_steps:
+        if n_steps and not serial:
             enq(iq)
         for i in range(n_steps):
-            if i + 1 < n_steps:
+            if serial or i + 1 < n_steps:
                 enq(iq)
             rec = an.fetch_records()
             info = an.call_info()
@@ -471,16 +472,15 @@ def main():
     an_decoder = an.decoder
     # the scan launch alone: one lane, one launch per step, nothing running beside it
     iso_ms = None
-    if args.isolated_steps > 0 and not (lanes == 1):
+    if args.isolated_steps > 0:
+        # (one lane and one call in flight: a handle without lanes runs its detection on a stream of its own, beside the next scan)
         an.close()
         del an
         an1 = analyzer(1)
         run(an1, max(5, args.settle))  # the CPU baseline left the GPU idle: clocks back to steady state first
-        _, _, (ms1, _, _) = run(an1, args.isolated_steps)
+        _, _, (ms1, _, _) = run(an1, args.isolated_steps, serial=True)
         iso_ms = ms1 / args.isolated_steps
         an1.close()
-    elif lanes == 1:
-        iso_ms = k_ms
 
     # host sinks, outside the timed region (rank 0, one core): what the reference's path ends in -- Signal objects on the
     # queue (analyze.py:251, 280) -- and the vectorised record -> CSV route, next to the record rate the timed steps produced
@@ -492,7 +492,7 @@ def main():
     if iso_ms:
         kernel_ms, kernel_frac = iso_ms, samples_per_step_rank * bytes_per_sample / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         kernel_note = (f"the stft_scan launch ALONE: one launch over all {S} streams of the rank per step, one lane, HIP events on its stream, "
-                       + (f"{args.isolated_steps} steps after the timed region" if lanes > 1 else "the timed region itself")
+                       + f"one call in flight, {args.isolated_steps} steps after the timed region"
                        + "; a one-lane rocprofv3 --kernel-trace average of the same command reproduces it")
     else:
         kernel_ms, kernel_frac = k_ms, conc_frac

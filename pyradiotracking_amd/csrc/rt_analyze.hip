@@ -34,6 +34,7 @@ using namespace rt;
 namespace {
 
 thread_local std::string g_create_error;
+thread_local bool g_creating_lane = false;  // rt_create of a laned handle is creating one of its lanes
 
 constexpr int kSlots = 2;
 constexpr int kTails = 3;
@@ -897,7 +898,9 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             kc.segs_per_chunk = choose_chunk(*cfg, R3, cfg->n_streams, (int)(cfg->max_samples / cfg->nperseg));  // the whole batch's choice
             kc.n_streams = p->kid_base[(size_t)k + 1] - p->kid_base[(size_t)k];
             rt_handle *kid = nullptr;
+            g_creating_lane = true;
             const int rc = rt_create(&kc, &kid);
+            g_creating_lane = false;
             if (rc != RT_OK) {
                 if (p->kids.empty()) delete p; else rt_destroy(p);
                 return rc;  // g_create_error was set by the failing rt_create
@@ -1014,12 +1017,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     } else {
         RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking));
         h->own_scan_stream = true;
-        // The sparse detection on a stream of its own (enqueue_analysis) -- where it pays.  Measured on one box, whole path, against
-        // everything in order on one stream (profiles/r04_e_*): config 2 one lane 0.82 -> 0.74 ms per step, two lanes 0.707 -> 0.687;
-        // config-5 share (nperseg 4096, one lane) 5.60 -> 5.49; but config 3 (nperseg 1024) 14.87 -> 15.7: behind a persistent grid
-        // of 16-point-per-lane workgroups the next scan takes the chip first, the detection runs at its very end and rt_fetch --
-        // and with it the host's next rt_process -- returns a scan later than it could.  Stream priorities changed none of this.
-        if (R3 == 4 || R3 == 8) h->s_detect = h->s_scan;
+        // The sparse detection on a stream of its own (enqueue_analysis) -- where it pays.  Measured on one box each, whole path,
+        // against everything in order on one stream (profiles/r04_e_*): config 2 one lane 0.79 -> 0.73 ms per step, config-5 share
+        // (nperseg 4096, one lane) 5.60 -> 5.49.  Not for the lanes of a laned handle (they overlap one another's detection
+        // already: config 2 two lanes 0.688 -> 0.735, uint8 0.534 -> 0.571), not at nperseg 1024 / 2048 (config 3 14.87 -> 15.7:
+        // behind a persistent grid of 16-point-per-lane workgroups the next scan takes the chip first, the detection runs at
+        // its very end and rt_fetch -- and with it the host's next rt_process -- returns a scan later than it could).  Stream
+        // priorities changed none of this.
+        if (R3 == 4 || R3 == 8 || g_creating_lane || std::getenv("RT_EXP_ONE_STREAM")) h->s_detect = h->s_scan;  // (the variable: A/B runs, read once here)
         else RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_detect, hipStreamNonBlocking));
     }
 
