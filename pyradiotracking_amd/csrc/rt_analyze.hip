@@ -112,6 +112,7 @@ struct rt_handle {
     int max_seg = 0;       // T for max_samples
     std::vector<float> h_thr_s;  // host copy of the per-stream thresholds (empty: rt_config's for every stream)
     int max_chunks = 0;
+    bool two_level = false;  // stft_scan64 without the chunk-bit pre-filter: a stream's earliest chunks are half as long (rt_kernels.h: chunk_geometry)
     int max_blocks = 0;  // workgroups per stream at max_chunks
     hipStream_t s_scan = nullptr;
     bool own_scan_stream = false;
@@ -345,6 +346,13 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.n_seg = n_seg;
     p.segs_per_chunk = h->L;
     p.chunks = (n_seg + h->L - 1) / h->L;
+    if (h->two_level) {
+        int n_short = 0, short_len = 0, chunks = 0;
+        chunk_geometry(n_seg, h->L, true, &n_short, &short_len, &chunks);
+        p.short_chunks = n_short;
+        p.short_len = short_len;
+        p.chunks = chunks;
+    }
     p.blocks_per_stream = (p.chunks + h->GPW - 1) / h->GPW;
     p.tail_cols = h->K;
     p.work = h->d_work;
@@ -939,7 +947,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->max_seg = (int)(cfg->max_samples / h->N);
     h->L = choose_chunk(*cfg, R3, cfg->n_streams, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
-    const int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
+    int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
     h->max_blocks = max_blocks_per_stream;
     {
         // Run-length pre-filter: a run shorter than r_min cells (and not through t = 0) fails the duration gate whatever
@@ -951,6 +959,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         if (cfg->mode == RT_MODE_PREFILTER && !h->prefilter_ok) {
             delete h;
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_PREFILTER needs signal_min_duration >= 2 * segs_per_chunk STFT hops");
+        }
+        // nperseg 4096 without chunk bits (they need chunks of one length): a stream's earliest chunks are half as long, so that
+        // the last items a launch hands out are short (rt_kernels.h: chunk_geometry).  A few chunks more than max_seg / L.
+        h->two_level = scan_wave64(R3) && !h->prefilter_ok && !std::getenv("RT_EXP_ONE_LEVEL");  // (the variable: A/B runs, read once here)
+        if (h->two_level) {
+            h->max_chunks += h->max_chunks / 4 + 2;
+            max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
+            h->max_blocks = max_blocks_per_stream;
         }
         // Exact run-length pre-filter: any chunk length; its planning tiles (kPlanWords words of LDS per buffer, a halo
         // of r rows either side) must leave room for rows of their own.  Built where it is asked for, and in AUTO mode.

@@ -100,6 +100,10 @@ struct StftParams {
     const int32_t *sub_first;  // LIN instantiations, or null: [S] non-zero = a marked stream: this launch leaves it alone (its items end at
                              // once), a second launch of the subtract-first instantiation over `stream_list` = the marked streams takes it
     int32_t spec_by_stream;  // MODE 1 with a stream list: the dense spectrogram is indexed by stream, not by position in the list
+    // stft_scan64 (its items are drawn per wave, latest chunks first): the EARLIEST short_chunks chunks of a stream -- the items
+    // drawn last -- have short_len segments instead of segs_per_chunk, so that the launch's last items are short (chunk_span).
+    // 0: every chunk has segs_per_chunk segments.
+    int32_t short_chunks, short_len;
 #ifdef RT_STAMPS
     uint32_t *dbg;           // [workgroups][4 waves][kStamps] cycles per stage, [kStamps - 1] = steps taken
 #endif
@@ -1537,6 +1541,32 @@ __global__ __launch_bounds__(256) void max_abs_hot(uint32_t *abs_hot, int n_stre
     if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) *host_max = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+}
+
+// first segment and length of chunk `c` of a stream whose earliest n_short chunks are short (StftParams::short_chunks)
+struct ChunkSpan {
+    int c0, len;
+};
+__host__ __device__ inline ChunkSpan chunk_span(int c, int L, int n_short, int short_len) {
+    if (c < n_short) return ChunkSpan{c * short_len, short_len};
+    return ChunkSpan{n_short * short_len + (c - n_short) * L, L};
+}
+// The geometry for n_seg segments: a quarter of the stream (its earliest part) in chunks of half the length.  With items drawn
+// latest chunks first from one counter, the waves of a launch finish within one item's length of one another; half-length items
+// at the end halve that tail (stft_scan64, config-5 share: 1.85 of 2 wave slots busy over the launch with equal items).
+__host__ __device__ inline void chunk_geometry(int n_seg, int L, bool two_level, int *n_short, int *short_len, int *chunks) {
+    const int long0 = (n_seg + L - 1) / L;
+    if (!two_level || long0 < 4 || L < 8) {
+        *n_short = 0;
+        *short_len = L;
+        *chunks = long0 > 0 ? long0 : 0;
+        return;
+    }
+    const int k = long0 / 4;            // long chunks' worth of segments given to short ones
+    *short_len = (L + 1) / 2;
+    *n_short = 2 * k;
+    const int rest = n_seg - *n_short * *short_len;
+    *chunks = *n_short + (rest > 0 ? (rest + L - 1) / L : 0);
 }
 
 // Which kernel serves nperseg 4096: stft_scan64 (rt_scan64.h: one wave per segment, 64 bins per lane) -- the default -- or,

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                 if (e0 >= cnt) break;
                 n_mine = cnt - e0 < L ? cnt - e0 : L;
             }
-            const int c0 = chunk * L;
+            const ChunkSpan span = chunk_span(chunk, L, p.short_chunks, p.short_len);  // (the earliest chunks -- the last items -- may be short)
+            const int c0 = span.c0, c_len = span.len;
             const float thr = p.thr_s ? p.thr_s[s] : p.thr;  // wave-uniform
             const raw_t *stream_iq = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride;
 
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
             // below, whose owner cannot know: where (and only where) a lowest cell is hot the wave takes one more step on
             // segment c0 - 1 and emits the cells there that precede a hot one and are not hot themselves.
             int k7 = 0;
-            int seg = LISTED ? p.seg_list[(int64_t)s * T + e0] : ((c0 + L < T ? c0 + L : T) - 1);
+            int seg = LISTED ? p.seg_list[(int64_t)s * T + e0] : ((c0 + c_len < T ? c0 + c_len : T) - 1);
             bool halo = false;
             for (;;) {
                 RT_STAMP(0);  // loop control, the previous step's threshold test and emission
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                 const rsrc_t rp = make_rsrc(p.psum + ((int64_t)s * p.blocks_per_stream + chunk) * N, (uint32_t)(N * sizeof(float)));
 #pragma unroll
                 for (int r = 0; r < 64; ++r) raw_buffer_store_f1(acc[r], rp, lane * 4, 256 * r, 0);
-                if (p.chunk_min && (c0 + L <= T)) {
+                if (p.chunk_min && c_len == L && (c0 + L <= T)) {
                     // the quietest complete chunk of the bin so far (positive floats order like their bits): make_bin_thresholds
                     uint32_t *cm = p.chunk_min + (int64_t)s * N + lane;
 #pragma unroll
