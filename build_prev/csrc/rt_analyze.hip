@@ -155,6 +155,7 @@ struct rt_handle {
     float *d_thr_bin = nullptr, *d_thr_nat = nullptr;  // [S][N] per-bin thresholds of the exact pre-filter, lane order / bin order (make_bin_thresholds)
     int minsum_slot = -1;       // the slot whose d_chunk_min holds the latest call's chunk minima (-1: none yet)
     int run_cells = 1;          // r: cells a plateau needs unless it runs through t = 0 (plan_runs)
+    int plan_tile = 0;          // rows per planning tile
     int auto_level = RT_MODE_SPARSE;
     int dense_sticky = 0;  // calls left on auto_level before the next probe
     // the most cells at or above the absolute threshold any stream had in the last call a pre-filter level analysed: more
@@ -533,17 +534,10 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
                                sp.blocks_per_stream, c.n_seg, h->cfg.snr_threshold, sl.h_overflow, sl.d_counters, kFlagHotOverflow | kFlagThrStale);
         }
         RT_HIP(h, hipMemsetAsync(const_cast<int32_t *>(sp.seg_count), 0, ((size_t)S + 1) * sizeof(int32_t), h->s_scan));
-        {
-            // (a run needs r cells: more than the buffer holds means "only the run through t = 0", which r = n_seg + 1 says as well)
-            const int r = (int)std::min<long long>(h->run_cells, (long long)c.n_seg + 1);
-            const int tile = plan_tile_rows(c.n_seg, h->LG, r);
-            const int tpw = 64 / (h->LG / 4);
-            const int waves = (c.n_seg + tpw * tile - 1) / (tpw * tile);
-            const size_t plan_lds = ((size_t)tpw * tile + 3) & ~(size_t)3;
-            auto *kern = r <= 16 ? plan_runs<4> : r <= 256 ? plan_runs<8> : plan_runs<16>;
-            hipLaunchKernelGGL(kern, dim3(waves, S), dim3(64), plan_lds, h->s_scan, sp.cell_hot, sl.d_cell_need,
-                               sl.d_seg_list, const_cast<int32_t *>(sp.seg_count), c.n_seg, h->LG, r, tile);
-        }
+        const int tiles = (c.n_seg + h->plan_tile - 1) / h->plan_tile;
+        const size_t plan_lds = 3 * sizeof(unsigned long long) * (size_t)plan_rows_padded(h->plan_tile, h->run_cells) * (h->LG / 4) + sizeof(uint32_t) * (size_t)h->plan_tile;
+        hipLaunchKernelGGL(plan_runs, dim3(tiles, S), dim3(64), plan_lds, h->s_scan, sp.cell_hot, sl.d_cell_need,
+                           sl.d_seg_list, const_cast<int32_t *>(sp.seg_count), c.n_seg, h->LG, h->run_cells, h->plan_tile);
         RT_HIP(h, hipMemcpyAsync(sl.h_seg_total, sp.seg_count + S, sizeof(int32_t), hipMemcpyDeviceToHost, h->s_scan));
         launch_scan<7>(h, sp, blocks, c.u8);
     } else if (mode == RT_MODE_PREFILTER) {
@@ -974,13 +968,17 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
             h->max_blocks = max_blocks_per_stream;
         }
-        // Exact run-length pre-filter: any chunk length, any plateau length the planner's counters hold (rt_kernels.h: plan_runs).
-        // Built where it is asked for, and in AUTO mode.
+        // Exact run-length pre-filter: any chunk length; its planning tiles (kPlanWords words of LDS per buffer, a halo
+        // of r rows either side) must leave room for rows of their own.  Built where it is asked for, and in AUTO mode.
         h->run_cells = (int)std::max<long long>(1, std::min<long long>(r_min, 1 << 20));
-        const bool fits = std::min<long long>(h->run_cells, (long long)h->max_seg + 1) <= kPlanMaxRun && h->max_seg >= 2;
+        const int rows_max = kPlanWords / (h->LG / 4);  // rows of 64-bit words (four lanes each) per LDS buffer
+        // tiles a few halos long (one wave each, rt_kernels.h: plan_runs): 14 r rows -- sixteen blocks of r with the halo, a lane
+        // per block and word of a row -- at least 32, within what a buffer holds (the rows are padded to whole blocks: 3 r off)
+        h->plan_tile = std::min(rows_max / h->run_cells * h->run_cells - 2 * h->run_cells, std::max(32, std::min(14 * h->run_cells, kPlanWords / 4)));
+        const bool fits = h->plan_tile >= 8 && h->max_seg >= 2;
         if (cfg->mode == RT_MODE_RUNFILTER && !fits) {
             delete h;
-            return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length (in STFT hops) is beyond the planner's counters");
+            return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length does not fit the planning tiles at this nperseg");
         }
         h->runfilter_ok = fits && (cfg->mode == RT_MODE_RUNFILTER || cfg->mode == RT_MODE_AUTO);
         if (h->runfilter_ok && cfg->mode == RT_MODE_AUTO) {
@@ -1209,6 +1207,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_runs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(3 * sizeof(unsigned long long) * kPlanWords + sizeof(uint32_t) * (kPlanWords / 4))));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dense));
 #undef RT_CREATE_HIP

@@ -1389,143 +1389,142 @@ __global__ __launch_bounds__(256) void plan_pass_b(const uint16_t *full, uint16_
 // Per bin these are window operations along t, done for the 16 bins of a lane at once on its 16-bit words:
 //     E[t] = AND_{j<r} H[t+j]   (a window of r set bits starts at t)      by doubling: P_1 = H, P_2k[t] = P_k[t] & P_k[t+k]
 //     C[t] = OR_{j<r}  E[t-j]   (t lies in such a window)                 likewise with OR and negative offsets
+// One workgroup per (tile of rows, stream), the tile with a halo of r rows either side in LDS (three buffers of 32 KiB).
 // Writes need[t] = C[t] | C[t+1] for the tile's rows and appends the rows with any bit set to the stream's segment list
 // (order irrelevant: the detection sorts its cells).
 // The 16-bit words of four neighbouring lanes are handled as one 64-bit word (the operations are bitwise, lg is a multiple of
-// 16): a row is w = lg / 4 words.
-//
-// Streaming form, no LDS passes: a lane owns one word column of one tile of rows and walks it upwards in time with two
-// bit-sliced counters (K bit planes of 64 independent counters each):
-//     run[u]   = length of the threshold run ending at row u, as a sticky flag   SAT[u] = (run[u] >= r)
-//     since[u] = rows since the last SAT row, as a flag                          FAR[u] = (since[u] >= r)
-// SAT[u] says a window of r set bits ends at u, so row t lies in a run of >= r cells iff some u in t .. t + r - 1 has SAT,
-// i.e. C[t] = ~FAR[t + r - 1]: every decision r - 1 rows behind the row just read, nothing kept but the counters.  Rows
-// before the buffer count as set (a run through t = 0 may continue a plateau of the previous buffer: any length keeps it),
-// rows past it as clear.  A tile reads r - 1 rows below and r above its own (the counters start empty / far).
-// Before: the tile and its halo in LDS, van Herk / Gil-Werman window AND and OR in fifteen LDS passes with a wave barrier
-// between them, one wave per workgroup -- 0.36 ms for the 157 MB of bits of 4 096 streams at the reference's default
-// geometry, five times what its bytes take (profiles/r04_d_*); the first version (doubling, 16-bit words, tiles of 1 000
-// rows in 100 KiB of LDS) took 3.3 ms, twice the scan it serves.
-// One wave per workgroup: 64 / w tiles of `tile_rows` rows side by side (a lane per tile and word column; the wave's rows
-// are contiguous), LDS only for a byte per row (does the row keep anything?), from which the stream's segment list is
-// appended with one returned atomic per wave (order irrelevant: the detection sorts its cells).
-constexpr int kPlanRowsPerWave = 16384;  // rows of one wave at most (its byte flags in LDS)
-constexpr int kPlanMaxRun = 65536;       // r at most (16 counter planes)
-template <int K>
+// 16), tiles are short (a few halos long), so that several workgroups share a CU: the first version -- 16-bit words, tiles
+// of 1 000 rows, one workgroup of 100 KiB of LDS per CU -- took 3.3 ms per call at 4 096 streams of the reference's
+// default geometry, twice the scan it serves.
+constexpr int kPlanWords = 4096;  // 64-bit words per LDS buffer at most (32 KiB; three buffers)
+// ONE WAVE per tile, no workgroup barrier; the window operations in a constant number of passes: rows in blocks of r, a running
+// AND (OR) down and up each block, and a window of r rows is the tail of one block's run and the head of the next one's
+// (van Herk / Gil-Werman).  Doubling (P_2k[t] = P_k[t] & P_k[t + k], ten passes for r = 9) made the kernel 0.28 - 0.39 ms for
+// the 157 MB of bits of 4 096 streams at the reference's default geometry, twice what its bytes take (profiles/r04_a_*).
+// Dynamic LDS: three buffers of rows_p x lg / 4 words, rows_p = tile_rows + 2 r rounded up to whole blocks, + tile_rows words.
+__host__ __device__ inline int plan_rows_padded(int tile_rows, int r) { return (tile_rows + 2 * r + r - 1) / r * r; }
 __global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *need, int32_t *seg_list, int32_t *seg_count,
                                                 int n_seg, int lg, int r, int tile_rows) {
-    extern __shared__ unsigned char plan_any[];  // [64 / w * tile_rows]
-    using u64 = unsigned long long;
-    const int s = blockIdx.y, lane = threadIdx.x;
-    const int w = lg / 4;                     // 64-bit words per row (4 .. 64)
-    const int tpw = 64 / w;                   // tiles per wave
-    const int c = lane % w, tj = lane / w;
-    const int B = tile_rows;
-    const int wave_rows = tpw * B;
-    const int row0 = blockIdx.x * wave_rows;  // the wave's first row
-    const int a = row0 + tj * B;              // this lane's tile: rows a .. a + B - 1
-    for (int i = lane * 4; i < wave_rows; i += 256) *reinterpret_cast<uint32_t *>(plan_any + i) = 0u;  // (the block is a multiple of 4 bytes)
-    wave_sync();
-    const u64 *H = reinterpret_cast<const u64 *>(hot + (int64_t)s * n_seg * lg) + c;
-    u64 *Nd = reinterpret_cast<u64 *>(need + (int64_t)s * n_seg * lg) + c;
-    // bit k of r - 1 as a mask: (plane ^ inv[k]) is all ones where the plane agrees with it
-    u64 inv[K];
+    extern __shared__ unsigned long long plan_buf[];
+    const int s = blockIdx.y, tid = threadIdx.x;
+    const int w = lg / 4;                                  // 64-bit words per row
+    const int t0 = blockIdx.x * tile_rows;                 // first row of the tile
+    const int rows = tile_rows + 2 * r;                    // with the halo
+    const int rows_p = plan_rows_padded(tile_rows, r);     // ... in whole blocks of r (the rows beyond `rows` are zero)
+    const int words = rows_p * w;
+    unsigned long long *A = plan_buf, *Up = plan_buf + words, *Dn = plan_buf + 2 * words;
+    uint32_t *row_any = reinterpret_cast<uint32_t *>(plan_buf + 3 * words);  // [tile_rows]
+    const unsigned long long *H = reinterpret_cast<const unsigned long long *>(hot + (int64_t)s * n_seg * lg);
+    // A = H on rows t0 - r .. t0 + tile_rows + r - 1 (zero outside the buffer and in the padding); eight loads in flight per lane
+    // (one at a time -- a loop the compiler cannot unroll -- every lane paid a memory round trip per word: most of the kernel's time)
+    for (int i0 = tid; i0 < words; i0 += 64 * 8) {
+        unsigned long long v[8];
 #pragma unroll
-    for (int k = 0; k < K; ++k) inv[k] = (((unsigned)(r - 1) >> k) & 1u) ? 0ull : ~0ull;
-    u64 c1[K], c2[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { c1[k] = 0ull; c2[k] = 0ull; }
-    u64 sat = 0ull, far = ~0ull, c_prev = 0ull;
-    const int t_end = (a + B < n_seg) ? a + B : n_seg;  // rows of this tile inside the buffer
-    const int n_steps = B + 2 * r;  // rows a - r + 1 .. a + B + r - 1 (+ 1: a multiple of nothing in particular; the batches below round up)
-    // rows in batches of eight, the next batch requested before the current one is counted
-    auto load_rows = [&](int i0, u64 (&dst)[8]) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int u = a - r + 1 + i0 + j;
-            dst[j] = (u < 0) ? ~0ull : (u < n_seg) ? H[(int64_t)u * w] : 0ull;
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            const int row = i / w, t = t0 - r + row;
+            v[u] = (i < words && row < rows && t >= 0 && t < n_seg) ? H[(int64_t)t * w + i % w] : 0ull;
         }
-    };
-    u64 h[8], hn[8];
-    load_rows(0, hn);
-    for (int i0 = 0; i0 < n_steps; i0 += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = hn[j];
-        if (i0 + 8 < n_steps) load_rows(i0 + 8, hn);
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 64 * u < words) A[i0 + 64 * u] = v[u];
+    }
+    for (int i = tid; i < tile_rows; i += 64) row_any[i] = 0u;
+    wave_sync();
+    const int n_blk = rows_p / r;
+    // E[t] = AND of the r rows from t on = (block's rows t .. end) & (next rows up to t + r - 1): Dn[t] & Up[t + r - 1]
+    for (int i = tid; i < n_blk * w; i += 64) {
+        const int base = (i / w) * r * w + i % w;
+        unsigned long long run = ~0ull;
+        for (int k0 = 0; k0 < r; k0 += 4) {  // rows block start .. t (four LDS reads in flight)
+            unsigned long long v[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int u = a - r + 1 + i0 + j;
-            const u64 hh = h[j];
-            // SAT: the run through u has r cells or more (run[u - 1] reached r - 1 at some point and the bit stayed set)
-            u64 eq = ~0ull;
+            for (int u = 0; u < 4; ++u) v[u] = (k0 + u < r) ? A[base + (k0 + u) * w] : ~0ull;
 #pragma unroll
-            for (int k = 0; k < K; ++k) eq &= c1[k] ^ inv[k];
-            sat = hh & (sat | eq);
-            u64 carry = ~0ull;
+            for (int u = 0; u < 4; ++u) { run &= v[u]; if (k0 + u < r) Up[base + (k0 + u) * w] = run; }
+        }
+        run = ~0ull;
+        for (int k0 = r - 1; k0 >= 0; k0 -= 4) {  // rows t .. block end
+            unsigned long long v[4];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const u64 t = c1[k] ^ carry;
-                carry &= c1[k];
-                c1[k] = t & hh;  // (a clear bit ends the run)
-            }
-            // FAR: no SAT row among the last r
-            eq = ~0ull;
+            for (int u = 0; u < 4; ++u) v[u] = (k0 - u >= 0) ? A[base + (k0 - u) * w] : ~0ull;
 #pragma unroll
-            for (int k = 0; k < K; ++k) eq &= c2[k] ^ inv[k];
-            far = ~sat & (far | eq);
-            carry = ~0ull;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const u64 t = c2[k] ^ carry;
-                carry &= c2[k];
-                c2[k] = t & ~sat;
-            }
-            const u64 c_now = ~far;  // C[u - r + 1]
-            // need[t] = C[t] | C[t + 1] for t = u - r (the cell before a run: `data` starts on it)
-            const int t = u - r;
-            if (t >= a && t < t_end) {
-                const u64 v = c_prev | ((t + 1 < n_seg) ? c_now : 0ull);
-                Nd[(int64_t)t * w] = v;
-                if (v) plan_any[t - row0] = 1;  // (benign race: every writer stores 1)
-            }
-            c_prev = c_now;
+            for (int u = 0; u < 4; ++u) { run &= v[u]; if (k0 - u >= 0) Dn[base + (k0 - u) * w] = run; }
         }
     }
     wave_sync();
-    // the wave's rows that keep anything go to the stream's list: counted, places reserved by ONE returned atomic, then written
-    int total = 0;
-    for (int b0 = 0; b0 < wave_rows; b0 += 64) {  // (wave-uniform bounds)
-        const bool has = b0 + lane < wave_rows && plan_any[b0 + lane];
-        total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(has));
+    for (int i = tid; i < words; i += 64) {
+        const int j = i + (r - 1) * w;
+        A[i] = Dn[i] & (j < words ? Up[j] : 0ull);  // (r = 1: Dn[i] & Up[i] = H[i])
     }
-    if (total == 0) return;  // (wave-uniform)
-    int base = 0;
-    if (lane == 0) {
-        base = atomicAdd(&seg_count[s], total);
-        // the batch's total (word [S] of the counts) tells the host how selective the level is on this input
-        atomicAdd(&seg_count[gridDim.y], total);
+    wave_sync();
+    // C[t] = OR of E over the r rows up to t = (block's rows start .. t) | (rows t - r + 1 .. end of the block before)
+    for (int i = tid; i < n_blk * w; i += 64) {
+        const int base = (i / w) * r * w + i % w;
+        unsigned long long run = 0ull;
+        for (int k0 = 0; k0 < r; k0 += 4) {
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k0 + u < r) ? A[base + (k0 + u) * w] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { run |= v[u]; if (k0 + u < r) Up[base + (k0 + u) * w] = run; }
+        }
+        run = 0ull;
+        for (int k0 = r - 1; k0 >= 0; k0 -= 4) {
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k0 - u >= 0) ? A[base + (k0 - u) * w] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { run |= v[u]; if (k0 - u >= 0) Dn[base + (k0 - u) * w] = run; }
+        }
     }
-    base = __builtin_amdgcn_readfirstlane(base);
-    for (int b0 = 0; b0 < wave_rows; b0 += 64) {
-        const bool has = b0 + lane < wave_rows && plan_any[b0 + lane];
+    wave_sync();
+    unsigned long long *Cres = A;
+    for (int i = tid; i < words; i += 64) {
+        const int j = i - (r - 1) * w;
+        Cres[i] = Up[i] | (j >= 0 ? Dn[j] : 0ull);
+    }
+    wave_sync();
+    // the run through t = 0, whatever its length (first tile only): and the rows up from t = 0 until nothing is left
+    if (t0 == 0) {
+        for (int l = tid; l < w; l += 64) {
+            unsigned long long z = ~0ull;
+            for (int t = 0; t < tile_rows + r && t < n_seg && z; ++t) {
+                z &= H[(int64_t)t * w + l];
+                Cres[(t + r) * w + l] |= z;
+            }
+        }
+    }
+    wave_sync();
+    // need[t] = C[t] | C[t + 1] (the cell before a run), rows of this tile only; remember which rows hold anything
+    unsigned long long *Nd = reinterpret_cast<unsigned long long *>(need + (int64_t)s * n_seg * lg);
+    for (int i = tid; i < tile_rows * w; i += 64) {
+        const int row = i / w, t = t0 + row;
+        if (t >= n_seg) break;
+        const int j = (row + r) * w + i % w;
+        unsigned long long v = Cres[j];
+        if (t + 1 < n_seg) v |= Cres[j + w];
+        Nd[(int64_t)t * w + i % w] = v;
+        if (v) row_any[row] = 1u;  // (benign race: every writer stores 1)
+    }
+    wave_sync();
+    // The tile's rows that hold anything go to the stream's list: one returned atomic per 64 rows reserves their places (an atomic
+    // per row, and one per thread on the batch's total -- a single word for every workgroup of the launch -- was the first version)
+    for (int row0 = 0; row0 < tile_rows; row0 += 64) {  // (wave-uniform bounds)
+        const int row = row0 + tid;
+        const bool has = row < tile_rows && row_any[row] && t0 + row < n_seg;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
-        if (has) seg_list[(int64_t)s * n_seg + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = row0 + b0 + lane;
-        base += __builtin_popcountll(m);
+        if (m == 0ull) continue;
+        const int total = __builtin_popcountll(m);
+        int base = 0;
+        if (tid == 0) {
+            base = atomicAdd(&seg_count[s], total);
+            // the batch's total (word [S] of the counts) tells the host how selective the level is on this input
+            atomicAdd(&seg_count[gridDim.y], total);
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (has) seg_list[(int64_t)s * n_seg + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t0 + row;
     }
-}
-
-// Rows per planning tile for a call of n_seg segments: tiles a few halos long (a tile reads 2 r - 1 rows beside its own),
-// a whole number of waves' worth of them per stream (a wave holds 64 / w tiles side by side), a wave's rows within its flags.
-__host__ __device__ inline int plan_tile_rows(int n_seg, int lg, int r) {
-    const int tpw = 64 / (lg / 4);
-    const int target = (4 * r > 64) ? 4 * r : 64;
-    int waves = n_seg / (tpw * target);
-    if (waves < 1) waves = 1;
-    const int waves_min = (n_seg + kPlanRowsPerWave - 1) / kPlanRowsPerWave;
-    if (waves < waves_min) waves = waves_min;
-    const int tiles = waves * tpw;
-    int rows = (n_seg + tiles - 1) / tiles;
-    return rows < 1 ? 1 : rows;
 }
 
 // The largest per-stream count of cells at or above the absolute threshold (StftParams::abs_hot, left by a MODE 4 / 6
@@ -1900,10 +1899,7 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
 // ---------------------------------------------------------------------------
 // sparse detection: one WAVE per (stream, bucket), bucket = bin & (kBuckets-1)
 // ---------------------------------------------------------------------------
-#ifndef RT_EXP_SMALL
-#define RT_EXP_SMALL 1024
-#endif
-constexpr int kSmallBucket = RT_EXP_SMALL;  // buckets up to this many cells use the small-LDS instantiation
+constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
 constexpr int kCandCapMax = 64;     // plateaus a bucket wave stages in LDS before it finishes them (a.cand_cap <= this); no limit per bucket
 
 // Bitonic sort of 64*M (key, value) pairs held in registers, element i = m*64 + lane.
@@ -2173,7 +2169,7 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
 
     // row means of the bucket's bins: np.mean(row) (analyze.py:375) from the scan's partial sums
 #ifndef RT_DETECT_ABLATE
-#define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort, 4 = no run statistics, 5 = no hand-over of the records, 6 = stop before the runs are gated
+#define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort
 #endif
     for (int r = lane; r < F / kBuckets && (!LARGE || wave == 0); r += 64) {
         const int bin = bkt + kBuckets * r;
@@ -2186,38 +2182,24 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
         int hb = 0;  // bits of bin / kBuckets
         while ((1 << hb) < F / kBuckets) ++hb;
         const bool packed = hb + a.tbits + 10 <= 32;
-        const bool bitmap = hb + a.tbits <= 15 && n2 >= 128 && kSmallBucket >= 1024;  // (64 cells: the network is as cheap)
+        const bool bitmap = hb + a.tbits <= 15 && n2 >= 128;  // (64 cells: the network is as cheap)
         switch (RT_DETECT_ABLATE == 2 ? 0 : (bitmap ? n2 + 1 : packed ? n2 : -n2)) {
             case 0: for (int i = lane; i < n; i += 64) { keys[i] = src[i].x; vals[i] = __uint_as_float(src[i].y); } break;
             case 129: sort_bucket_bitmap<2>(src, n, lane, keys, vals, a.tbits, bkt); break;
             case 257: sort_bucket_bitmap<4>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#if RT_EXP_SMALL >= 512
             case 513: sort_bucket_bitmap<8>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
-#if RT_EXP_SMALL >= 512
             case 1025: sort_bucket_bitmap<16>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
             case 64: sort_bucket_packed<1>(src, n, lane, keys, vals, a.tbits, bkt); break;
             case 128: sort_bucket_packed<2>(src, n, lane, keys, vals, a.tbits, bkt); break;
             case 256: sort_bucket_packed<4>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#if RT_EXP_SMALL >= 512
             case 512: sort_bucket_packed<8>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
-#if RT_EXP_SMALL >= 512
             case 1024: sort_bucket_packed<16>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
             // very long buffers (bin and time bits leave no room for the position): (key, value) pairs
             case -64: sort_bucket_regs<1>(src, n, lane, keys, vals); break;
             case -128: sort_bucket_regs<2>(src, n, lane, keys, vals); break;
             case -256: sort_bucket_regs<4>(src, n, lane, keys, vals); break;
-#if RT_EXP_SMALL >= 512
             case -512: sort_bucket_regs<8>(src, n, lane, keys, vals); break;
-#endif
-#if RT_EXP_SMALL >= 512
             default: sort_bucket_regs<16>(src, n, lane, keys, vals); break;
-#else
-            default: sort_bucket_regs<4>(src, n, lane, keys, vals); break;
-#endif
         }
         wave_sync();
         if (RT_DETECT_ABLATE == 3) return;
@@ -2275,7 +2257,7 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
                 const int t = start + k;
                 return t < 0 ? prev(-t) : vals[off + t];
             };
-            const RunStats st = (RT_DETECT_ABLATE == 4) ? RunStats{cell(0), cell(1), 0.f} : run_stats_wave(end - start, cell);
+            const RunStats st = run_stats_wave(end - start, cell);
             if (lane == 0) {
                 cand[c].max_p = st.max_p;
                 cand[c].mean_p = st.mean_p;
@@ -2284,7 +2266,6 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
             }
         }
         wave_sync();
-        if (RT_DETECT_ABLATE == 5) return;
         int slot = 0;
         if (lane == 0) slot = atomicAdd(&a.raw_count[s], ncand);
         slot = __builtin_amdgcn_readfirstlane(slot);
@@ -2323,7 +2304,6 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
         bool keep = false;
         int fi = 0, b = 0, e = 0, start = 0;
         float av = 0.f;
-        if (RT_DETECT_ABLATE == 6) { if (__builtin_amdgcn_ballot_w64(is_end) == 12345ull) keys[0] = 1u; continue; }
         if (is_end) {
             const uint32_t key0 = keys[first];
             fi = (int)(key >> a.tbits);
@@ -2374,11 +2354,8 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
     if (ncand) drain(ncand);
 }
 
-#ifndef RT_EXP_DETECT_OCC
-#define RT_EXP_DETECT_OCC 1
-#endif
 template <bool LARGE>
-__global__ __launch_bounds__(256, LARGE ? 1 : RT_EXP_DETECT_OCC) void detect_bucket(const DetectArgs a) {
+__global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     // small: 4 waves = 4 buckets per workgroup; large: the 4 waves sort ONE bucket together in
     // LDS, then wave 0 finishes it alone

@@ -1225,7 +1225,7 @@ def test_dense_input_everything_above_threshold():
         assert margin < 2e-4, (fi, st, en, margin)
 
 
-def _noisy_batch(n_streams, blen, fs, nperseg, seed, noise_sigma=1e-5, peak_dbw=(-140.0, -126.0), n_buffers=2):
+def _noisy_batch(n_streams, blen, fs, nperseg, seed, noise_sigma=1e-5, peak_dbw=(-140.0, -126.0), n_buffers=2, pulse_ms=15.0):
     """streams whose noise floor (2 sigma^2 / fs = -160 dBW at sigma 1e-5 and 2.048 MS/s) lies around the thresholds used
     below, with 15 ms pulses 20..34 dB over it (their hamming side lobes, -43 dB, stay under the thresholds), some across the
     buffer boundary"""
@@ -1233,11 +1233,12 @@ def _noisy_batch(n_streams, blen, fs, nperseg, seed, noise_sigma=1e-5, peak_dbw=
     out = []
     for s in range(n_streams):
         rng = np.random.default_rng([seed, s])
-        pulses = synth.random_pulses(rng, n_buffers * blen, fs, w, 5 * n_buffers, peak_dbw=peak_dbw)
-        pulses.append(synth.Pulse(blen - int(0.005 * fs) - 11 * s, int(0.015 * fs), (0.05 + 0.04 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))
-        pulses.append(synth.Pulse(0, int(0.011 * fs), (-0.3 + 0.03 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))  # a run that starts at t = 0
+        pulses = synth.random_pulses(rng, n_buffers * blen, fs, w, 5 * n_buffers, peak_dbw=peak_dbw, dur_ms=(pulse_ms, pulse_ms))
+        pd = pulse_ms / 1000.0
+        pulses.append(synth.Pulse(blen - int(0.005 * fs) - 11 * s, int(pd * fs), (0.05 + 0.04 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))
+        pulses.append(synth.Pulse(0, int((pd - 0.004) * fs), (-0.3 + 0.03 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))  # a run that starts at t = 0
         # ... and one that reaches only 4 .. 20 segments into the next buffer: its run through t = 0 ends inside the first chunk
-        pulses.append(synth.Pulse(blen - int(0.015 * fs) + (4 + 3 * s) * nperseg, int(0.015 * fs), (0.31 + 0.02 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))
+        pulses.append(synth.Pulse(blen - int(pd * fs) + (4 + 3 * s) * nperseg, int(pd * fs), (0.31 + 0.02 * s) * fs, synth.amp_for_peak_dbw(peak_dbw[1], w, fs)))
         out.append(synth.make_stream(synth.StreamSpec(n_buffers * blen, fs, pulses, noise_sigma=noise_sigma), seed=900 + s).reshape(n_buffers, blen))
     return np.stack(out)  # [S, n_buffers, B]
 
@@ -1375,6 +1376,35 @@ def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
         d8.enqueue_bytes(raw); r8.enqueue_bytes(raw)
         w8 = d8.fetch_records()
         assert len(w8) > n_streams and r8.fetch_records().tobytes() == w8.tobytes()
+
+
+@pytest.mark.parametrize("min_ms,n_seg", [(17.0, 1500), (17.0, 250), (20.0, 1200)])
+def test_exact_run_length_prefilter_with_long_minimum_plateaus(min_ms, n_seg):
+    """The planner between the two scans counts run lengths in bit planes (rt_kernels.h: plan_runs, 4 / 8 / 16 planes by the
+    minimum plateau length in hops): 17 ms at 2.048 MS/s and nperseg 256 are 271 hops (16 planes); a buffer of 250
+    segments is shorter than, or barely longer than, the plateau it would take -- only runs through t = 0 and their look-back
+    remain.  Records byte-identical to the dense path over two buffers, one and two lanes."""
+    _need_gpu()
+    fs, nperseg, n_streams = 2048000, 256, 6
+    blen = nperseg * n_seg + 24
+    thr_dbw = -160.0
+    iq = _noisy_batch(n_streams, blen, fs, nperseg, seed=int(min_ms) + n_seg, noise_sigma=1e-5, peak_dbw=(-140.0, -126.0), pulse_ms=min_ms + 8.0)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, signal_threshold_dbw=thr_dbw, signal_min_duration_ms=min_ms, signal_max_duration_ms=80.0)
+    dense = _batch_for(kw, n_streams, blen, "dense")
+    run = _batch_for(kw, n_streams, blen, "runfilter")
+    run2 = _batch_for(kw, n_streams, blen, "runfilter", lanes=2)
+    total = 0
+    for k in range(2):
+        chunk = np.ascontiguousarray(iq[:, k])
+        for b in (dense, run, run2):
+            b.enqueue(chunk)
+        want = dense.fetch_records()
+        got = run.fetch_records()
+        assert run.native.call_info().mode_used == _native.RT_MODE_RUNFILTER
+        assert got.tobytes() == want.tobytes(), (min_ms, n_seg, k, len(got), len(want))
+        assert run2.fetch_records().tobytes() == want.tobytes()
+        total += len(want)
+    assert total > 0, "no plateau of that length in the input: the case tests nothing"
 
 
 def test_auto_does_not_probe_the_sparse_level_while_the_noise_would_overflow_it():
