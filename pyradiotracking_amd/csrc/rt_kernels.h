@@ -1900,10 +1900,7 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
 // ---------------------------------------------------------------------------
 // sparse detection: one WAVE per (stream, bucket), bucket = bin & (kBuckets-1)
 // ---------------------------------------------------------------------------
-#ifndef RT_EXP_SMALL
-#define RT_EXP_SMALL 1024
-#endif
-constexpr int kSmallBucket = RT_EXP_SMALL;  // buckets up to this many cells use the small-LDS instantiation
+constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
 constexpr int kCandCapMax = 64;     // plateaus a bucket wave stages in LDS before it finishes them (a.cand_cap <= this); no limit per bucket
 
 // Bitonic sort of 64*M (key, value) pairs held in registers, element i = m*64 + lane.
@@ -2186,38 +2183,24 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
         int hb = 0;  // bits of bin / kBuckets
         while ((1 << hb) < F / kBuckets) ++hb;
         const bool packed = hb + a.tbits + 10 <= 32;
-        const bool bitmap = hb + a.tbits <= 15 && n2 >= 128 && kSmallBucket >= 1024;  // (64 cells: the network is as cheap)
+        const bool bitmap = hb + a.tbits <= 15 && n2 >= 128;  // (64 cells: the network is as cheap)
         switch (RT_DETECT_ABLATE == 2 ? 0 : (bitmap ? n2 + 1 : packed ? n2 : -n2)) {
             case 0: for (int i = lane; i < n; i += 64) { keys[i] = src[i].x; vals[i] = __uint_as_float(src[i].y); } break;
             case 129: sort_bucket_bitmap<2>(src, n, lane, keys, vals, a.tbits, bkt); break;
             case 257: sort_bucket_bitmap<4>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#if RT_EXP_SMALL >= 512
             case 513: sort_bucket_bitmap<8>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
-#if RT_EXP_SMALL >= 512
             case 1025: sort_bucket_bitmap<16>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
             case 64: sort_bucket_packed<1>(src, n, lane, keys, vals, a.tbits, bkt); break;
             case 128: sort_bucket_packed<2>(src, n, lane, keys, vals, a.tbits, bkt); break;
             case 256: sort_bucket_packed<4>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#if RT_EXP_SMALL >= 512
             case 512: sort_bucket_packed<8>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
-#if RT_EXP_SMALL >= 512
             case 1024: sort_bucket_packed<16>(src, n, lane, keys, vals, a.tbits, bkt); break;
-#endif
             // very long buffers (bin and time bits leave no room for the position): (key, value) pairs
             case -64: sort_bucket_regs<1>(src, n, lane, keys, vals); break;
             case -128: sort_bucket_regs<2>(src, n, lane, keys, vals); break;
             case -256: sort_bucket_regs<4>(src, n, lane, keys, vals); break;
-#if RT_EXP_SMALL >= 512
             case -512: sort_bucket_regs<8>(src, n, lane, keys, vals); break;
-#endif
-#if RT_EXP_SMALL >= 512
             default: sort_bucket_regs<16>(src, n, lane, keys, vals); break;
-#else
-            default: sort_bucket_regs<4>(src, n, lane, keys, vals); break;
-#endif
         }
         wave_sync();
         if (RT_DETECT_ABLATE == 3) return;
@@ -2374,11 +2357,8 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
     if (ncand) drain(ncand);
 }
 
-#ifndef RT_EXP_DETECT_OCC
-#define RT_EXP_DETECT_OCC 1
-#endif
 template <bool LARGE>
-__global__ __launch_bounds__(256, LARGE ? 1 : RT_EXP_DETECT_OCC) void detect_bucket(const DetectArgs a) {
+__global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     // small: 4 waves = 4 buckets per workgroup; large: the 4 waves sort ONE bucket together in
     // LDS, then wave 0 finishes it alone
