@@ -540,6 +540,7 @@ def main():
             "streams_rank0": S,
             "samples_per_stream": blen,
             "segments_per_stream": n_seg,
+            "segments_per_chunk": int(getattr(info, "segs_per_chunk", 0)),
             "mode": {1: "dense", 2: "sparse", 3: "prefilter", 4: "runfilter"}.get(info.mode_used, "?"),
             "fallbacks": fell_back,
             "records_per_step": n_records_total,

@@ -267,7 +267,7 @@ typedef struct rt_call_info {
     float ms_stft;            /* RT_FLAG_TIMING: STFT/scan kernel, HIP events, ms        */
     float ms_detect;          /* RT_FLAG_TIMING: detect kernel(s), ms                    */
     float ms_total;           /* RT_FLAG_TIMING: first launch to last launch, ms         */
-    float reserved2;
+    int32_t segs_per_chunk;   /* the handle's chunk length (rt_config.segs_per_chunk, or what 0 chose); was reserved */
 } rt_call_info;
 
 int rt_get_call_info(rt_handle *h, rt_call_info *info);

@@ -67,7 +67,7 @@ class RtCallInfo(C.Structure):
         ("ms_stft", C.c_float),
         ("ms_detect", C.c_float),
         ("ms_total", C.c_float),
-        ("reserved2", C.c_float),
+        ("segs_per_chunk", C.c_int32),
     ]
 
 

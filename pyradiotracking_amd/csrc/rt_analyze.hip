@@ -291,15 +291,28 @@ int choose_chunk(const rt_config &cfg, int R3, int n_streams, int n_seg) {
         if (blocks >= 2048) break;
         L >>= 1;
     }
-    if (L == 32 && R3 < 4 && n_seg > 32) {
-        // nperseg <= 512, a batch that fills the chip: a workgroup holds GPW chunks and its lane groups walk in step, so the chunks
-        // of a stream cost (workgroups) x L steps whatever the last workgroup holds.  The shortest L with the same number of
-        // workgroups: 1 171 segments (the reference's default geometry, 300 kS/s) = 37 chunks of 32 in three workgroups of 16, eleven
-        // lane groups idle -- or 47 chunks of 25 in the same three, one idle: 22 % fewer steps.  Config 2 (8 000 segments) and
-        // config 4 (2 048) keep 32.  (Not a function of the number of streams, like the rules below.)
-        const int wgs = (n_seg + GPW * 32 - 1) / (GPW * 32);
-        const int lb = (n_seg + GPW * wgs - 1) / (GPW * wgs);
-        if (lb >= 16) L = lb;
+    if (L == 32 && R3 < 4 && n_seg > 32 && !keep_long) {
+        // nperseg <= 512, a batch that fills the chip, no chunk bits to serve: a workgroup holds GPW chunks and its lane groups walk in
+        // step, so a stream costs (workgroups) x L steps whatever its last workgroup holds -- 1 171 segments (the reference's default
+        // geometry) are 37 chunks of 32 in three workgroups of 16, eleven lane groups idle, or 47 chunks of 25 in the same three, one
+        // idle: 22 % fewer steps (551 -> 636 k MS/s).  Among the lengths 20 .. 32 the one with the fewest steps, a step of overhead per
+        // workgroup, and 2 % against multiples of eight (a wave's four lane groups read four chunks L x 2 KiB apart: 32- and 64-KiB
+        // strides are the slowest per step in every sweep).  (Not a function of the number of streams, like the rules below.)
+        // Where the chunk bits exist (config 2 / 4 geometry) the chunks stay 32 long: at config 2 a length of 25 (20 full workgroups
+        // per stream instead of 15.6) makes the scan alone 1.5 - 5.5 % faster on four boxes and the uint8 path 2 %, the whole path with
+        // two lanes the same, and the chunk-bit and exact pre-filter levels 2 - 7 % slower (shorter chunks are less selective, more
+        // workgroups in the second scan); config 4 (2 048 segments = four full workgroups) is fastest at 32 anyway --
+        // profiles/r04_q_chunk_length_sweep_nperseg256.txt.
+        double best = 0.0;
+        for (int cand = 20; cand <= 32; ++cand) {
+            const int64_t chunks = (n_seg + cand - 1) / cand;
+            const int64_t wgs = (chunks + GPW - 1) / GPW;
+            const double cost = (double)wgs * (cand + 1.0) * (cand % 8 == 0 ? 1.02 : 1.0);
+            if (best == 0.0 || cost < best * (1.0 - 1e-9)) {
+                best = cost;
+                L = cand;
+            }
+        }
     }
     if (L == 32 && !keep_long && R3 >= 4) {
         // nperseg >= 1024, a batch that fills the chip: the chunk length is chosen by what a workgroup costs.  All lane
@@ -1549,6 +1562,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     unsigned long long flags = sl.h_counters[2];
     h->info = rt_call_info{};
     h->info.n_seg = c.n_seg;
+    h->info.segs_per_chunk = h->L;
     h->info.n_hot = 0;
     // Guard of the detrend by linearity (rt_kernels.h: StftParams::dc_flag).  The form carries a stream's constant offset through
     // the transform: harmless while the offset is <= 60 dB over the per-sample noise (any <= 16-bit front end; <= 0.02 dB against
@@ -1810,6 +1824,7 @@ int rt_fetch(rt_handle *h, rt_record *out, size_t cap, size_t *n_out) {
         }
         const rt_call_info &ki = k->info;
         h->info.n_seg = ki.n_seg;
+        h->info.segs_per_chunk = ki.segs_per_chunk;
         h->info.mode_used = i == 0 ? ki.mode_used : (ki.mode_used < h->info.mode_used ? ki.mode_used : h->info.mode_used);
         h->info.fell_back |= ki.fell_back;
         h->info.n_dense_streams += ki.n_dense_streams;
