@@ -1378,6 +1378,26 @@ def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
         assert len(w8) > n_streams and r8.fetch_records().tobytes() == w8.tobytes()
 
 
+@pytest.mark.parametrize("fs,n_streams,n_seg,lanes,want", [
+    (300000, 4096, 1171, 1, 25),   # the reference's default geometry, a batch that fills the chip: 47 chunks of 25 in three workgroups
+    (300000, 4096, 1171, 2, 25),   # the lanes take the whole batch's choice
+    (2048000, 256, 8000, 1, 32),   # config 2: chunk bits exist (8 ms = 127 hops >= 2 * 32 - 1), the chunks stay 32 long
+    (2048000, 4, 8000, 1, 32),     # ... for a small batch too
+    (300000, 4, 1171, 1, 4),       # a small batch without chunk bits: short chunks, more workgroups
+])
+def test_call_info_reports_the_chunk_length(fs, n_streams, n_seg, lanes, want):
+    """rt_call_info.segs_per_chunk: the chunk length the handle runs with (rt_analyze.hip: choose_chunk).  It sets the order in
+    which a row's partial sums are added, so shards and lanes of one population must agree on it: it depends on the geometry
+    and on whether the batch fills the chip, never on how the batch is split."""
+    _need_gpu()
+    blen = 256 * n_seg
+    b = _batch_for(dict(sample_rate=fs, fft_nperseg=256), n_streams, blen, "auto", lanes=lanes)
+    iq = np.zeros((n_streams, 256 * 8), np.complex64)  # (a short buffer: the chunk length is the handle's, not the call's)
+    b.enqueue(iq)
+    b.fetch_records()
+    assert b.native.call_info().segs_per_chunk == want
+
+
 @pytest.mark.parametrize("min_ms,n_seg", [(17.0, 1500), (17.0, 250), (20.0, 1200)])
 def test_exact_run_length_prefilter_with_long_minimum_plateaus(min_ms, n_seg):
     """The planner between the two scans counts run lengths in bit planes (rt_kernels.h: plan_runs, 4 / 8 / 16 planes by the
