@@ -339,5 +339,85 @@ RT_HD void rank_and_shadow(int32_t i, int32_t n, const Rec *rec, const long long
     *shadow_out = shadow;
 }
 
+// ---- exact run-length pre-filter: the planner's arithmetic (rt_kernels.h: plan_runs; host copy in rt_hostcheck.cpp) ----
+// One 64-bit word = 64 independent cells (the threshold bits of four lanes' sixteen bins each); the planner walks a word column
+// upwards in time with two bit-sliced counters of K planes, r = the cells a plateau needs:
+//     SAT[u] = the threshold run ending at row u has r cells or more     (sticky while the run lasts)
+//     FAR[u] = no SAT row among the last r rows
+// step(h) takes row u's word and returns C[u - r + 1] = ~FAR[u]: "row u - r + 1 lies in a threshold run of >= r cells".
+// K planes hold counts up to 2^K - 1 >= r - 1; a count that wraps while its flag is already set changes nothing.
+constexpr int kPlanRowsPerWave = 16384;  // rows of one wave at most (its byte flags in LDS)
+constexpr int kPlanMaxRun = 65536;       // r at most (16 counter planes)
+template <int K>
+struct RunPlanner {
+    unsigned long long c1[K], c2[K], inv[K], sat, far;
+    RT_HD void init(int r) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            c1[k] = 0ull;
+            c2[k] = 0ull;
+            inv[k] = (((unsigned)(r - 1) >> k) & 1u) ? 0ull : ~0ull;  // (plane ^ inv[k]) is all ones where the plane agrees with bit k of r - 1
+        }
+        sat = 0ull;
+        far = ~0ull;
+    }
+    RT_HD unsigned long long step(unsigned long long hh) {
+        unsigned long long eq = ~0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k) eq &= c1[k] ^ inv[k];
+        sat = hh & (sat | eq);  // run[u - 1] reached r - 1 at some point and the bit stayed set
+        unsigned long long carry = ~0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long t = c1[k] ^ carry;
+            carry &= c1[k];
+            c1[k] = t & hh;  // (a clear bit ends the run)
+        }
+        eq = ~0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k) eq &= c2[k] ^ inv[k];
+        far = ~sat & (far | eq);
+        carry = ~0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long t = c2[k] ^ carry;
+            carry &= c2[k];
+            c2[k] = t & ~sat;
+        }
+        return ~far;
+    }
+};
+// Rows per planning tile for a call of n_seg segments: tiles a few halos long (a tile reads 2 r - 1 rows beside its own),
+// a whole number of waves' worth of them per stream (a wave holds 64 / w tiles side by side), a wave's rows within its flags.
+RT_HD int plan_tile_rows(int n_seg, int lg, int r) {
+    const int tpw = 64 / (lg / 4);
+    const int target = (4 * r > 64) ? 4 * r : 64;
+    int waves = n_seg / (tpw * target);
+    if (waves < 1) waves = 1;
+    const int waves_min = (n_seg + kPlanRowsPerWave - 1) / kPlanRowsPerWave;
+    if (waves < waves_min) waves = waves_min;
+    const int tiles = waves * tpw;
+    int rows = (n_seg + tiles - 1) / tiles;
+    return rows < 1 ? 1 : rows;
+}
+// One word column of one tile (rows a .. a + B - 1 of a buffer of n_seg rows): `row(u)` yields row u's word for 0 <= u < n_seg,
+// `emit(t, need)` receives need[t] = C[t] | C[t + 1] (the cell before a run: `data` starts on it) for the tile's rows inside
+// the buffer.  Rows before the buffer count as set (a run through t = 0 may continue a plateau of the previous buffer: any
+// length keeps it), rows past it as clear.  The kernel runs the same steps, eight rows per batch with the loads ahead.
+template <int K, class Row, class Emit>
+RT_HD void plan_tile_column(int a, int B, int n_seg, int r, Row row, Emit emit) {
+    RunPlanner<K> pl;
+    pl.init(r);
+    unsigned long long c_prev = 0ull;
+    const int t_end = (a + B < n_seg) ? a + B : n_seg;
+    for (int u = a - r + 1; u <= a + B + r - 1; ++u) {
+        const unsigned long long hh = (u < 0) ? ~0ull : (u < n_seg) ? row(u) : 0ull;
+        const unsigned long long c_now = pl.step(hh);
+        const int t = u - r;
+        if (t >= a && t < t_end) emit(t, c_prev | ((t + 1 < n_seg) ? c_now : 0ull));
+        c_prev = c_now;
+    }
+}
+
 }  // namespace rt
 #endif

@@ -96,4 +96,23 @@ int hc_probe_ruled_out(int target, int level, int valid, unsigned long long abs_
 int hc_minsum_group(int L, int gpw) { return minsum_group(L, gpw); }
 double hc_minsum_margin(int m) { return (double)minsum_margin(m); }
 
+// The planner of the exact run-length pre-filter (rt_core.h: RunPlanner, plan_tile_column -- the arithmetic of the plan_runs
+// kernel) on one stream's threshold words hot[n_seg][w] (64-bit words): need[n_seg][w], tiled exactly as the kernel tiles a call
+// of n_seg rows of lg = 4 w lanes (tile_rows = 0) or with the given tile length.  Returns the number of counter planes used.
+int hc_plan_runs(const unsigned long long *hot, unsigned long long *need, int n_seg, int w, int r_in, int tile_rows) {
+    const int r = r_in < n_seg + 1 ? r_in : n_seg + 1;  // (as the host side of the launch clamps it)
+    const int B = tile_rows > 0 ? tile_rows : plan_tile_rows(n_seg, 4 * w, r);
+    const int planes = r <= 16 ? 4 : r <= 256 ? 8 : 16;
+    for (int a = 0; a < n_seg; a += B)
+        for (int c = 0; c < w; ++c) {
+            auto row = [&](int u) { return hot[(size_t)u * w + c]; };
+            auto emit = [&](int t, unsigned long long v) { need[(size_t)t * w + c] = v; };
+            if (planes == 4) plan_tile_column<4>(a, B, n_seg, r, row, emit);
+            else if (planes == 8) plan_tile_column<8>(a, B, n_seg, r, row, emit);
+            else plan_tile_column<16>(a, B, n_seg, r, row, emit);
+        }
+    return planes;
+}
+int hc_plan_tile_rows(int n_seg, int lg, int r) { return plan_tile_rows(n_seg, lg, r); }
+
 }  // extern "C"

@@ -1409,8 +1409,7 @@ __global__ __launch_bounds__(256) void plan_pass_b(const uint16_t *full, uint16_
 // One wave per workgroup: 64 / w tiles of `tile_rows` rows side by side (a lane per tile and word column; the wave's rows
 // are contiguous), LDS only for a byte per row (does the row keep anything?), from which the stream's segment list is
 // appended with one returned atomic per wave (order irrelevant: the detection sorts its cells).
-constexpr int kPlanRowsPerWave = 16384;  // rows of one wave at most (its byte flags in LDS)
-constexpr int kPlanMaxRun = 65536;       // r at most (16 counter planes)
+// (kPlanRowsPerWave, kPlanMaxRun, RunPlanner, plan_tile_rows: rt_core.h -- shared with the host check of the CPU test-suite)
 template <int K>
 __global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *need, int32_t *seg_list, int32_t *seg_count,
                                                 int n_seg, int lg, int r, int tile_rows) {
@@ -1428,14 +1427,9 @@ __global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *n
     wave_sync();
     const u64 *H = reinterpret_cast<const u64 *>(hot + (int64_t)s * n_seg * lg) + c;
     u64 *Nd = reinterpret_cast<u64 *>(need + (int64_t)s * n_seg * lg) + c;
-    // bit k of r - 1 as a mask: (plane ^ inv[k]) is all ones where the plane agrees with it
-    u64 inv[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) inv[k] = (((unsigned)(r - 1) >> k) & 1u) ? 0ull : ~0ull;
-    u64 c1[K], c2[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { c1[k] = 0ull; c2[k] = 0ull; }
-    u64 sat = 0ull, far = ~0ull, c_prev = 0ull;
+    RunPlanner<K> pl;  // (rt_core.h: the two bit-sliced counters)
+    pl.init(r);
+    u64 c_prev = 0ull;
     const int t_end = (a + B < n_seg) ? a + B : n_seg;  // rows of this tile inside the buffer
     const int n_steps = B + 2 * r;  // rows a - r + 1 .. a + B + r - 1 (+ 1: a multiple of nothing in particular; the batches below round up)
     // rows in batches of eight, the next batch requested before the current one is counted
@@ -1456,31 +1450,7 @@ __global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *n
         for (int j = 0; j < 8; ++j) {
             const int u = a - r + 1 + i0 + j;
             const u64 hh = h[j];
-            // SAT: the run through u has r cells or more (run[u - 1] reached r - 1 at some point and the bit stayed set)
-            u64 eq = ~0ull;
-#pragma unroll
-            for (int k = 0; k < K; ++k) eq &= c1[k] ^ inv[k];
-            sat = hh & (sat | eq);
-            u64 carry = ~0ull;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const u64 t = c1[k] ^ carry;
-                carry &= c1[k];
-                c1[k] = t & hh;  // (a clear bit ends the run)
-            }
-            // FAR: no SAT row among the last r
-            eq = ~0ull;
-#pragma unroll
-            for (int k = 0; k < K; ++k) eq &= c2[k] ^ inv[k];
-            far = ~sat & (far | eq);
-            carry = ~0ull;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const u64 t = c2[k] ^ carry;
-                carry &= c2[k];
-                c2[k] = t & ~sat;
-            }
-            const u64 c_now = ~far;  // C[u - r + 1]
+            const u64 c_now = pl.step(hh);  // C[u - r + 1]
             // need[t] = C[t] | C[t + 1] for t = u - r (the cell before a run: `data` starts on it)
             const int t = u - r;
             if (t >= a && t < t_end) {
@@ -1512,20 +1482,6 @@ __global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *n
         if (has) seg_list[(int64_t)s * n_seg + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = row0 + b0 + lane;
         base += __builtin_popcountll(m);
     }
-}
-
-// Rows per planning tile for a call of n_seg segments: tiles a few halos long (a tile reads 2 r - 1 rows beside its own),
-// a whole number of waves' worth of them per stream (a wave holds 64 / w tiles side by side), a wave's rows within its flags.
-__host__ __device__ inline int plan_tile_rows(int n_seg, int lg, int r) {
-    const int tpw = 64 / (lg / 4);
-    const int target = (4 * r > 64) ? 4 * r : 64;
-    int waves = n_seg / (tpw * target);
-    if (waves < 1) waves = 1;
-    const int waves_min = (n_seg + kPlanRowsPerWave - 1) / kPlanRowsPerWave;
-    if (waves < waves_min) waves = waves_min;
-    const int tiles = waves * tpw;
-    int rows = (n_seg + tiles - 1) / tiles;
-    return rows < 1 ? 1 : rows;
 }
 
 // The largest per-stream count of cells at or above the absolute threshold (StftParams::abs_hot, left by a MODE 4 / 6

@@ -8,8 +8,14 @@ plain definitions on random threshold maps -- the arguments DESIGN.md gives for 
 * run-length pre-filter: chunks with an all-hot bit in themselves or a neighbour (chunk 0: the cells of the run through
   t = 0) contain every cell of every run that can pass the duration gate or continue a run of the previous buffer.
 
+* exact run-length pre-filter, the planner (rt_core.h: RunPlanner / plan_tile_column, the arithmetic of the plan_runs kernel,
+  compiled for the host): need = the cells of threshold runs of at least r cells and of the run through t = 0, plus the cell
+  before each -- against that definition written out per bit, for every tiling and every counter width.
+
 `hot[t]` below is "cell t of one bin passes the absolute threshold" (what the kernel keeps as bits per lane).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -123,3 +129,69 @@ def test_prefilter_chunks_contain_every_run_that_can_matter(seed):
         if e - b >= r_min or b == 0:  # long enough, or it may continue a run of the previous buffer
             cells = set(range(b, e)) | ({b - 1} if b > 0 else set())  # + the cell the walk stops on (T11)
             assert cells <= emitted, (b, e, sorted(cells - emitted)[:5])
+
+
+# ---------------------------------------------------------------------------
+# the planner of the exact run-length pre-filter: bit-sliced counters against the definition
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hc():
+    from pyradiotracking_amd import build
+    lib = C.CDLL(build.build_hostcheck())
+    lib.hc_plan_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.hc_plan_tile_rows.argtypes = [C.c_int, C.c_int, C.c_int]
+    return lib
+
+
+def _need_by_definition(hot_bits, r):
+    """hot_bits [T][cells] bool -> need [T][cells]: C[t] = t lies in a run of >= r set cells (rows before the buffer count as
+    set: the run through t = 0 may continue a plateau of the previous buffer, any length keeps it); need[t] = C[t] | C[t + 1]"""
+    T, n = hot_bits.shape
+    ext = np.concatenate([np.ones((r - 1, n), bool), hot_bits])
+    c_ext = np.zeros_like(ext)
+    for j in range(n):
+        col = ext[:, j]
+        edges = np.flatnonzero(np.diff(np.concatenate([[0], col.view(np.int8), [0]])))
+        for b, e in zip(edges[0::2], edges[1::2]):
+            if e - b >= r:
+                c_ext[b:e, j] = True
+    c = c_ext[r - 1:]
+    need = c.copy()
+    need[:-1] |= c[1:]
+    return need
+
+
+def _bits_to_words(bits, w):
+    T = bits.shape[0]
+    return np.packbits(bits.reshape(T, w, 64), axis=2, bitorder="little").view(np.uint64).reshape(T, w)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_planner_counters_equal_the_run_length_definition(hc, seed):
+    rng = np.random.default_rng([77, seed])
+    w = int(rng.choice([4, 8, 16, 64]))                       # 64-bit words per row: nperseg 256 .. 4096
+    T = int(rng.choice([1, 2, 9, 37, 150, 400, 1171]))
+    r = int(rng.choice([1, 2, 9, 15, 16, 17, 63, 255, 256, 257, 300, 1200]))  # 4 / 8 / 16 planes, and r beyond the buffer
+    tile = int(rng.choice([0, 0, 1, 7, 64, 100]))             # 0: the kernel's own tiling (rt_core.h: plan_tile_rows)
+    bits = np.zeros((T, w * 64), bool)
+    for j in range(w * 64):
+        bits[:, j] = _random_hot(rng, T) if j % 7 else (rng.random(T) < rng.choice([0.0, 0.5, 1.0]))
+    if rng.random() < 0.5:
+        bits[:, : w * 8] = True                               # bins set throughout: runs longer than any counter
+    hot = np.ascontiguousarray(_bits_to_words(bits, w))
+    need = np.zeros_like(hot)
+    planes = hc.hc_plan_runs(hot.ctypes.data, need.ctypes.data, T, w, r, tile)
+    r_eff = min(r, T + 1)
+    assert planes == (4 if r_eff <= 16 else 8 if r_eff <= 256 else 16)
+    want = _bits_to_words(_need_by_definition(bits, r_eff), w)
+    assert np.array_equal(need, want), (seed, w, T, r, tile)
+
+
+def test_planner_tiles_fit_the_kernels_flags(hc):
+    """a wave's rows (64 / w tiles side by side) stay within the byte flags it keeps in LDS, whatever the call"""
+    for lg in (16, 32, 64, 128, 256):
+        for n_seg in (1, 2, 100, 1171, 8000, 65535, 1 << 20):
+            for r in (1, 9, 63, 127, 1000, 65536):
+                rows = hc.hc_plan_tile_rows(n_seg, lg, min(r, n_seg + 1))
+                tpw = 64 // (lg // 4)
+                assert rows >= 1 and tpw * rows <= 16384 + tpw, (lg, n_seg, r, rows)
