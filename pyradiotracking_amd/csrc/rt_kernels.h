@@ -129,6 +129,18 @@ constexpr int kBuckets = 16;  // candidate lists per stream: bucket = bin & 15 (
 
 constexpr int kStageCap = 128;  // candidate cells staged per wave before a flush (1 KiB)
 
+// P[r] for a register index that differs from lane to lane: a binary tree of selects on the bits of r (CNT - 1 v_cndmask; written
+// as a recursion on scalars -- with local arrays for the levels hipcc turned the tree into an indexed load from scratch)
+template <int LO, int CNT, int NP>
+__device__ __forceinline__ float pick_range(const float (&P)[NP], int r) {
+    if constexpr (CNT == 1) {
+        return P[LO];
+    } else {
+        const float lo = pick_range<LO, CNT / 2>(P, r), hi = pick_range<LO + CNT / 2, CNT / 2>(P, r);
+        return (r & (CNT / 2)) ? hi : lo;
+    }
+}
+
 // Append a wave's staged candidate cells to the 16 per-bucket lists of its
 // stream (bucket = bin & (kBuckets-1)).  Two passes over the <= kStageCap staged cells:
 // count per bucket (ballots), lanes 0..15 reserve their bucket's slots with one
@@ -1155,25 +1167,35 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 // the mere presence of this rare block made the kernel 4 % slower at nperseg 256 and 8 % at 1024)
                 int lt_e = lt;
                 asm volatile("" : "+v"(lt_e));
-                int need = 0;  // cells this wave emits in this step (scalar arithmetic on ballots)
+                // Lane-centric: a lane counts its own cells, the counts' exclusive prefix over the wave and their total come from
+                // the five bit planes of the counts (<= 16), and every lane stores its cells -- one or two where a tag sits -- in a
+                // loop as long as the busiest lane's count, the power picked out of the registers by a select tree.  (Register by
+                // register -- sixteen ballots for the total, sixteen more with a rank and a divergent store each -- the block was
+                // ~260 instructions of every emitting step, and at config 2 every second wave step emits.)
+                const int cnt = __builtin_popcount(emit);
+                int off = 0, need = 0;  // this lane's first place; cells this wave emits in this step
 #pragma unroll
-                for (int r = 0; r < 16; ++r) need += __builtin_popcountll(__builtin_amdgcn_ballot_w64((emit >> r) & 1u));
+                for (int k = 0; k < 5; ++k) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(((cnt >> k) & 1) != 0);
+                    off += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) << k;
+                    need += __builtin_popcountll(m) << k;
+                }
                 if (stg_n + need > kStageLimit) {
                     flush_stage(p, s, stg, stg_n);
                     stg_n = 0;
                 }
                 if (need <= kStageLimit) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool mine = (emit >> r) & 1u;
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
-                        if (mine) {
-                            const int off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    uint32_t e = emit;
+                    int o = stg_n + off;
+                    while (__builtin_amdgcn_ballot_w64(e != 0u) != 0ull) {  // (wave-uniform)
+                        if (e) {
+                            const int r = __builtin_ctz(e);
+                            e &= e - 1u;
                             const uint32_t key = ((uint32_t)bin_of<R3>(lt_e, r) << p.tbits) | (uint32_t)seg;
-                            stg[stg_n + off] = make_uint2(key, __float_as_uint(P[r]));
+                            stg[o++] = make_uint2(key, __float_as_uint(pick_range<0, 16>(P, r)));
                         }
-                        stg_n += __builtin_popcountll(m);
                     }
+                    stg_n += need;
                 } else {
                     // more than a staging area in one step (dense input): straight to memory -- unless one of the
                     // stream's lists has overflowed already (count > capacity): then the call is re-run dense

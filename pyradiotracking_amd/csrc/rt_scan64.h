@@ -83,17 +83,7 @@ __device__ __forceinline__ void w64_prefetch(rsrc_t r, float *area, int lane) {
         raw_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(area) + 2 * PB * j), SZ, lane * SZ, 4 * PB * j, 0, kAuxNT);
 }
 
-// P[r] for a register index that differs from lane to lane: a binary tree of selects on the bits of r (63 v_cndmask; written
-// as a recursion on scalars -- with local arrays for the levels hipcc turned the tree into an indexed load from scratch)
-template <int LO, int CNT>
-__device__ __forceinline__ float pick_range(const float (&P)[64], int r) {
-    if constexpr (CNT == 1) {
-        return P[LO];
-    } else {
-        const float lo = pick_range<LO, CNT / 2>(P, r), hi = pick_range<LO + CNT / 2, CNT / 2>(P, r);
-        return (r & (CNT / 2)) ? hi : lo;
-    }
-}
+// P[r] for a register index that differs from lane to lane (rt_kernels.h: pick_range, 63 v_cndmask)
 __device__ __forceinline__ float pick64(const float (&P)[64], int r) { return pick_range<0, 64>(P, r); }
 
 // a lane's 64-bit word of per-bin bits as two 32-bit halves (bit kb of the word = bin lane + 64 kb)
