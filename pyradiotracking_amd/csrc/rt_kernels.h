@@ -1764,6 +1764,75 @@ __device__ __forceinline__ void push_candidate(const DetectArgs &a, RecLds &l, i
     }
 }
 
+// ---- cross-lane steps without LDS round trips (a ds_bpermute is ~100 cycles of latency per dependent step) ----
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+// the value lane (lane ^ OFF) holds, OFF = 1, 2, 4, 8 (inside a row of 16 lanes)
+template <int OFF>
+__device__ __forceinline__ int xor_lane(int v) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8, "row-local offsets only");
+    if constexpr (OFF == 1) return dpp_mov<0xB1>(v);                   // quad_perm [1,0,3,2]
+    else if constexpr (OFF == 2) return dpp_mov<0x4E>(v);              // quad_perm [2,3,0,1]
+    else if constexpr (OFF == 4) return dpp_mov<0x141>(dpp_mov<0x1B>(v));  // quads reversed, then the halves of eight mirrored: i -> i ^ 4
+    else return dpp_mov<0x128>(v);                                     // row_ror:8
+}
+// One step of a butterfly reduction, every lane: op(v of the lane, v of lane ^ OFF) -- the pairs of the halving fold of
+// rt::run_stats (p[l] op= p[l + OFF]), so a chain OFF = 32, 16 .. 1 leaves that fold's result in every lane, bit for bit as the
+// __shfl_xor chain it replaces did (op is commutative; no re-association).  OFF = 16 / 32 use gfx950's row / half swaps:
+// v_permlane16_swap (v, v) yields (rows 0 0 2 2, rows 1 1 3 3) of v, v_permlane32_swap (lower half twice, upper half twice).
+template <int OFF, class T, class Op>
+__device__ __forceinline__ T butterfly_step(T v, Op op) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        const int bits = __builtin_bit_cast(int, v);
+        if constexpr (OFF <= 8) {
+            return op(v, __builtin_bit_cast(T, xor_lane<OFF>(bits)));
+        } else {
+            const auto r = (OFF == 16) ? __builtin_amdgcn_permlane16_swap((unsigned)bits, (unsigned)bits, false, false)
+                                       : __builtin_amdgcn_permlane32_swap((unsigned)bits, (unsigned)bits, false, false);
+            return op(__builtin_bit_cast(T, (int)r[0]), __builtin_bit_cast(T, (int)r[1]));
+        }
+    } else {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+        const int lo = (int)(uint32_t)bits, hi = (int)(uint32_t)(bits >> 32);
+        if constexpr (OFF <= 8) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)xor_lane<OFF>(hi) << 32) | (uint32_t)xor_lane<OFF>(lo);
+            return op(v, __builtin_bit_cast(T, o));
+        } else {
+            const auto rl = (OFF == 16) ? __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false)
+                                        : __builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false);
+            const auto rh = (OFF == 16) ? __builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false)
+                                        : __builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false);
+            const unsigned long long x = ((unsigned long long)rh[0] << 32) | rl[0], y = ((unsigned long long)rh[1] << 32) | rl[1];
+            return op(__builtin_bit_cast(T, x), __builtin_bit_cast(T, y));
+        }
+    }
+}
+template <class T, class Op>
+__device__ __forceinline__ T butterfly_all(T v, Op op) {
+    v = butterfly_step<32>(v, op);
+    v = butterfly_step<16>(v, op);
+    v = butterfly_step<8>(v, op);
+    v = butterfly_step<4>(v, op);
+    v = butterfly_step<2>(v, op);
+    v = butterfly_step<1>(v, op);
+    return v;
+}
+// inclusive scan over the 64 lanes of a wave with `op` (associative, identity `ident`): row_shr 1 / 2 / 4 / 8 inside the rows of
+// 16, then row_bcast15 / row_bcast31 carry the rows' totals upwards (lanes without a source keep the identity)
+template <class Op>
+__device__ __forceinline__ int wave_scan_inclusive(int v, int ident, Op op) {
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xF, 0xF, false));  // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xF, 0xF, false));  // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xF, 0xF, false));  // row_shr:8
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 // phase 2: np.max / np.mean / np.std(dB(.)) of one plateau by one wave, in the
 // canonical order of rt::run_stats (64 interleaved partials, halving fold).
 template <class Cell>
@@ -1779,26 +1848,19 @@ __device__ __forceinline__ RunStats run_stats_wave(int n, Cell cell) {
         if (v != v) any_nan = 1;
         if (v > pm) pm = v;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ps += __shfl_xor(ps, off, 64);
-        pd += __shfl_xor(pd, off, 64);
-        const float o = __shfl_xor(pm, off, 64);
-        if (o > pm) pm = o;
-        any_nan |= __shfl_xor(any_nan, off, 64);
-    }
-    ps = __shfl(ps, 0, 64);
-    pd = __shfl(pd, 0, 64);
-    pm = __shfl(pm, 0, 64);
+    // (butterflies: every lane ends with the fold's result -- the same operations in the same pairs as the host's halving fold)
+    const auto add64 = [](double x, double y) { return x + y; };
+    ps = butterfly_all(ps, add64);
+    pd = butterfly_all(pd, add64);
+    pm = butterfly_all(pm, [](float x, float y) { return y > x ? y : x; });
+    any_nan = butterfly_all(any_nan, [](int x, int y) { return x | y; });
     const double mean_db = pd / (double)n;
     double pa = 0.0;
     for (int k = lane; k < n; k += 64) {
         const double d = (double)db10(cell(k)) - mean_db;
         pa += d * d;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pa += __shfl_xor(pa, off, 64);
-    pa = __shfl(pa, 0, 64);
+    pa = butterfly_all(pa, add64);
     RunStats r;
     r.max_p = any_nan ? NAN : pm;
     r.mean_p = (float)(ps / (double)n);
@@ -2073,12 +2135,7 @@ __device__ __forceinline__ void sort_bucket_bitmap(const uint2 *src, int n, int 
         before[j].w = run;
         run += (uint32_t)__builtin_popcount(w.w);
     }
-    uint32_t incl = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)incl, off, 64);
-        if (lane >= off) incl += u;
-    }
+    const uint32_t incl = (uint32_t)wave_scan_inclusive((int)run, 0, [](int x, int y) { return x + y; });
     const uint32_t excl = incl - run;
 #pragma unroll
     for (int j = 0; j < 4; ++j) pv4[lane * 4 + j] = make_uint4(before[j].x + excl, before[j].y + excl, before[j].z + excl, before[j].w + excl);
@@ -2272,12 +2329,7 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
         const bool next_adj = ab && (i + 1 < n) && (t + 1 < T) && keys[i + 1] == key + 1 && is_above(i + 1);
         const bool is_start = ab && !prev_adj;
         const bool is_end = ab && !next_adj;
-        int first = is_start ? i : -1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int u = __shfl_up(first, off, 64);
-            if (lane >= off) first = first > u ? first : u;
-        }
+        int first = wave_scan_inclusive(is_start ? i : -1, -1, [](int x, int y) { return x > y ? x : y; });
         first = first > carry ? first : carry;
         carry = __builtin_amdgcn_readlane(first, 63);
 
