@@ -554,7 +554,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
             const int waves = (c.n_seg + tpw * tile - 1) / (tpw * tile);
             const size_t plan_lds = ((size_t)tpw * tile + 3) & ~(size_t)3;
             auto *kern = r <= 16 ? plan_runs<4> : r <= 256 ? plan_runs<8> : plan_runs<16>;
-            hipLaunchKernelGGL(kern, dim3(waves, S), dim3(64), plan_lds, h->s_scan, sp.cell_hot, sl.d_cell_need,
+            hipLaunchKernelGGL(kern, dim3(S, waves), dim3(64), plan_lds, h->s_scan, sp.cell_hot, sl.d_cell_need,
                                sl.d_seg_list, const_cast<int32_t *>(sp.seg_count), c.n_seg, h->LG, r, tile);
         }
         RT_HIP(h, hipMemcpyAsync(sl.h_seg_total, sp.seg_count + S, sizeof(int32_t), hipMemcpyDeviceToHost, h->s_scan));

@@ -1437,13 +1437,13 @@ __global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *n
                                                 int n_seg, int lg, int r, int tile_rows) {
     extern __shared__ unsigned char plan_any[];  // [64 / w * tile_rows]
     using u64 = unsigned long long;
-    const int s = blockIdx.y, lane = threadIdx.x;
+    const int s = blockIdx.x, lane = threadIdx.x;  // (streams along x: a grid's y extent ends at 65 535)
     const int w = lg / 4;                     // 64-bit words per row (4 .. 64)
     const int tpw = 64 / w;                   // tiles per wave
     const int c = lane % w, tj = lane / w;
     const int B = tile_rows;
     const int wave_rows = tpw * B;
-    const int row0 = blockIdx.x * wave_rows;  // the wave's first row
+    const int row0 = blockIdx.y * wave_rows;  // the wave's first row
     const int a = row0 + tj * B;              // this lane's tile: rows a .. a + B - 1
     for (int i = lane * 4; i < wave_rows; i += 256) *reinterpret_cast<uint32_t *>(plan_any + i) = 0u;  // (the block is a multiple of 4 bytes)
     wave_sync();
@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(64) void plan_runs(const uint16_t *hot, uint16_t *n
     if (lane == 0) {
         base = atomicAdd(&seg_count[s], total);
         // the batch's total (word [S] of the counts) tells the host how selective the level is on this input
-        atomicAdd(&seg_count[gridDim.y], total);
+        atomicAdd(&seg_count[gridDim.x], total);
     }
     base = __builtin_amdgcn_readfirstlane(base);
     for (int b0 = 0; b0 < wave_rows; b0 += 64) {
