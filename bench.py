@@ -56,6 +56,21 @@ WORKLOADS = {
     "config5": dict(total=8192, sample_rate=3200000, samples=3200000, nperseg=4096, window="hamming", trains=True),
 }
 
+# What `other_configs` times after the headline at N = 1 (one GPU's share of every BASELINE configuration + the reference's
+# defaults with a real receiver's noise floor).  Same generator, same seed as --workload configN; lanes as bench defaults.
+OTHER_CONFIGS = [
+    ("config3", dict(streams=4096, sample_rate=2400000, samples=2400000, nperseg=1024, window="hann", trains=False, lanes=1,
+                     what="BASELINE config 3, the whole population on one GPU")),
+    ("config4", dict(streams=32768, sample_rate=2048000, samples=524288, nperseg=256, window="hamming", trains=False, lanes=2,
+                     what="BASELINE config 4, all 32 768 streams on one GPU at B = 524 288 (137 GB resident): the N = 1 point of north_star's sharded curve")),
+    ("config5_share", dict(streams=1024, sample_rate=3200000, samples=3200000, nperseg=4096, window="hamming", trains=True, lanes=1,
+                           what="BASELINE config 5, the 1 024-stream share one GPU of eight analyses (tag trains)")),
+    ("default_geometry_noise_floor", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=256, window="hamming", trains=False, lanes=2,
+                                          noise_dbw=-88.0, settle=20,
+                                          what="the reference's defaults (300 kS/s, nperseg 256, -90 dBW, 8-40 ms) with the noise floor at -88 dBW, 2 dB OVER "
+                                               "the threshold (a real RTL-SDR): AUTO reaches the exact run-length pre-filter")),
+]
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -102,6 +117,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--parity-streams", type=int, default=16)
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
+                    help="after the headline, time the other BASELINE configurations (3, 4, the config-5 share) and the reference's default "
+                         "geometry with a noise floor over its threshold in the same run -> `other_configs` in the JSON line.  auto: on for the bare "
+                         "default command at N = 1")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps per configuration of --other-configs")
+    ap.add_argument("--other-budget-s", type=float, default=240.0,
+                    help="wall-clock budget of the whole --other-configs block: a configuration is only started while it is not spent")
     return ap.parse_args()
 
 
@@ -195,6 +217,23 @@ def pmc_traffic(default_workload, lanes):
     if have is None or doc.get("scan_kernel_sha256") != have:
         return None, "the scan kernel's machine code differs from the one profiles/pmc_traffic.json was measured on (run tools/profile_round.sh)"
     return int(doc["bytes_per_launch_256_streams"]) // lanes, "bytes/launch: PMC FETCH_SIZE (calibrated on the kernel's own load stream) + WRITE_SIZE on one 256-stream launch; " + doc.get("source", "profiles/pmc_traffic.json")
+
+
+_ORIG_AFFINITY = None  # the cores the job had before the rank pinned itself (the CPU baseline's workers get them back)
+
+
+def affinity_summary(plan_entry):
+    """A rank's core set for the JSON line: compact cpulist text, NUMA node, whether the mask is in force."""
+    cpus = sorted(plan_entry.get("cpus") or [])
+    runs, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        runs.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return {"cpulist": ",".join(runs), "n": len(cpus), "numa_node": plan_entry.get("numa_node"), "pinned": bool(plan_entry.get("pinned")),
+            "how": plan_entry.get("how")}
 
 
 def _tail(path, n=25):
@@ -313,6 +352,20 @@ def main():
     if share_gpu:
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    # NUMA-local ranks, before this process has touched a GPU (the runtime's helper threads inherit the mask): the cores of the
+    # NUMA node the rank's GPU hangs off, shared evenly with the other ranks of that node (pyradiotracking_amd/affinity.py;
+    # the reference pins each analyzer with taskset, __main__.py:122-128).  RT_BENCH_NO_PIN=1 leaves the process where it is.
+    from pyradiotracking_amd import affinity
+
+    global _ORIG_AFFINITY
+    try:
+        _ORIG_AFFINITY = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        _ORIG_AFFINITY = None
+    if os.environ.get("RT_BENCH_NO_PIN") == "1":
+        cpu_plan = {"cpus": _ORIG_AFFINITY or [], "numa_node": None, "pci": None, "how": "not pinned (RT_BENCH_NO_PIN=1)", "pinned": False}
+    else:
+        cpu_plan = affinity.pin_rank(rank, [0] * world if share_gpu else list(range(world)))
     if world != args.gpus and rank == 0:
         # a launcher's WORLD_SIZE is what actually runs; the JSON line reports it as n_gpus
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); running {world}", file=sys.stderr)
@@ -437,6 +490,7 @@ def main():
     # which GPU every rank ran on (ordinal, PCI address): a SCALE record shows N distinct devices without any collective library
     me = device_identity(torch, local_rank)
     me["rank"] = rank
+    me["cpus"] = affinity_summary(cpu_plan)
     if world > 1:
         devices = [None] * world
         dist.all_gather_object(devices, me)
@@ -487,6 +541,21 @@ def main():
     sinks = None
     if rank == 0:
         sinks = host_sinks(an_decoder, rec, [str(i) for i in range(lo, hi)], n_records_total * args.steps / elapsed)
+
+    # (d) as SURVEY wrote it: the drop-in class on config 1 from host memory, as a latency (N = 1, default command)
+    latency = None
+    if rank == 0 and world == 1 and default_workload and not args.no_cpu_baseline:
+        latency = single_stream_latency(local_rank)
+
+    # the other BASELINE configurations and the reference's defaults under a real noise floor, timed in this same run
+    others = None
+    if world == 1 and (args.other_configs == "on" or (args.other_configs == "auto" and default_workload)):
+        if args.isolated_steps <= 0:
+            an.close()
+            del an
+        del iq, rec
+        torch.cuda.empty_cache()
+        others = other_configs(torch, args, local_rank)
 
     conc_frac = achieved / HBM_PEAK_GBS
     if iso_ms:
@@ -561,6 +630,10 @@ def main():
         "roofline": roofline,
         "host_sinks": sinks,
     }
+    if latency is not None:
+        out.update(latency)
+    if others is not None:
+        out["other_configs"] = others
     if base is not None:
         out["cpu_baseline"] = base
     if parity is not None:
@@ -616,16 +689,23 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
     return out
 
 
-def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed):
+def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed, spread=0):
     """The oracle on the host cores over a bounded sample of the same IQ bits (``timed``), and the GPU records of the
-    sampled parity streams against it: count, bin, start, end, shadow verdict exact, the five dB figures within 0.1 dB."""
+    sampled parity streams against it: count, bin, start, end, shadow verdict exact, the five dB figures within 0.1 dB.
+    ``spread`` (untimed): that many streams, first, last and an even spread, instead of first and last only.
+    The ONLY place of this file that touches ``oracle/`` (always as the checker / the reported baseline)."""
     import numpy as np
 
-    from oracle import cpu_bench
+    from oracle import analyze_oracle, cpu_bench
 
+    # the baseline is "the node's own host cores": the oracle's workers get the cores the job had before the rank pinned itself
+    pinned_to = None
     try:
+        if _ORIG_AFFINITY:
+            pinned_to = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, _ORIG_AFFINITY)
         cores = len(os.sched_getaffinity(0))
-    except AttributeError:
+    except (AttributeError, OSError):
         cores = os.cpu_count() or 1
     S = iq.shape[0]
     if timed:
@@ -634,6 +714,10 @@ def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed):
         # parity streams: first and last of the batch plus an even spread; the CPU sample = those + the next ones up to n
         k = min(S, max(args.parity_streams, 2))
         parity_ids = sorted({int(round(i * (S - 1) / max(1, k - 1))) for i in range(k)})
+    elif spread:
+        k = min(S, max(spread, 2))
+        parity_ids = sorted({int(round(i * (S - 1) / max(1, k - 1))) for i in range(k)})
+        workers, n = min(len(parity_ids), 8), len(parity_ids)
     else:
         workers = 2
         parity_ids = sorted({0, S - 1})
@@ -647,6 +731,11 @@ def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed):
         res = cpu_bench.run(path, len(rows), kw, workers, parity=range(len(parity_ids)))
     finally:
         os.unlink(path)
+        if pinned_to:
+            try:
+                os.sched_setaffinity(0, pinned_to)
+            except OSError:
+                pass
     base = None
     if timed:
         samples = len(rows) * n_seg * nperseg
@@ -659,15 +748,25 @@ def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed):
             "sample": f"{len(rows)} of the {S} streams (same IQ bits, {blen} samples each), one oracle process per core; "
             f"single-core rate {per_core:.1f} MSamples/s",
         }
-    # the bench analyses the same resident buffer in every step: its records are those of that buffer arriving after
-    # itself (look-back live), which is what the oracle's second pass over the parity streams returns
-    dec = an.decoder
+    parity = compare_with_oracle(an.decoder, rec, parity_ids, res["results"])
+    parity["streams"] = "first, last and an even spread of the batch" if (timed or spread) else "first and last of the shard"
+    if timed:
+        base.update(config1_single_core(analyze_oracle))
+    return base, parity
+
+
+def compare_with_oracle(dec, rec, parity_ids, results):
+    """GPU records of the streams `parity_ids` against the oracle's rows (results[j] for parity_ids[j]).
+    The bench analyses the same resident buffer in every step: its records are those of that buffer arriving after
+    itself (look-back live), which is what the oracle's second pass over the parity streams returns."""
+    import numpy as np
+
     checked = mismatched = 0
     worst_db = 0.0
     for j, s in enumerate(parity_ids):
         mine = rec[rec["stream"] == s]
         _, _, _, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = dec.decode(mine)
-        want = res["results"][j]
+        want = results[j]
         ok = [(int(r["fi"]), int(r["start"]), int(r["end"]), not bool(r["shadowed"])) for r in mine] == [w[:4] for w in want]
         if ok:
             for i, w in enumerate(want):
@@ -677,9 +776,188 @@ def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed):
                     ok &= d <= 0.1
         checked += 1
         mismatched += 0 if ok else 1
-    return base, {"streams_checked": checked, "streams_mismatched": mismatched, "records_checked": int(sum(len(res["results"][j]) for j in range(len(parity_ids)))),
-                  "fields": "count, bin, start, end, shadow verdict exact; max/avg/std/noise/snr within 0.1 dB", "worst_db_difference": round(worst_db, 6),
-                  "streams": "first, last and an even spread of the batch" if timed else "first and last of the shard"}
+    return {"streams_checked": checked, "streams_mismatched": mismatched, "records_checked": int(sum(len(results[j]) for j in range(len(parity_ids)))),
+            "fields": "count, bin, start, end, shadow verdict exact; max/avg/std/noise/snr within 0.1 dB", "worst_db_difference": round(worst_db, 6)}
+
+
+def config1_stream():
+    """BASELINE config 1: one 300 kS/s stream, one second, one 20 ms tone at +50 kHz from sample 90 000, A = 1e-2, seed 0."""
+    from pyradiotracking_amd import synth
+
+    return synth.make_stream(synth.StreamSpec(300000, 300000, [synth.Pulse(90000, 6000, 50000.0, 1e-2)]), seed=0)
+
+
+def config1_single_core(oracle, reps=8):
+    """the reference's own case -- ONE process on ONE core on config 1 -- as milliseconds of CPU per
+    second of IQ (the reference is real-time while this stays under 1 000; its own log line is off by 10 x)."""
+    import datetime
+
+    iq = config1_stream()
+    ts = datetime.datetime(2024, 1, 1)
+    oa = oracle.OracleAnalyzer(device="0")
+    oa.process(iq, ts)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        every, kept = oa.process(iq, ts)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"config1_single_core_ms_per_s": round(ms, 3), "config1_single_core_MSamples_per_s": round(0.3 / (ms * 1e-3), 2),
+            "config1_signals": [len(every), len(kept)],
+            "config1_note": "BASELINE config 1 (1 stream, 300 kS/s, 1-s buffer, one 20 ms tone at +50 kHz): the oracle in this process on one core, "
+                            f"steady state (look-back live), mean of {reps} buffers; [signals before, after the shadow filter]"}
+
+
+def single_stream_latency(gpu, reps=50):
+    """The reference's real-time requirement (analyze.py:223-229: a callback must return within the buffer's own length)
+    as a number: one config-1 buffer from HOST memory through SignalAnalyzer.process_samples -- clock book-keeping,
+    upload, scan + detection, records -> Signal objects on the queue.  Median / worst of `reps` callbacks, milliseconds."""
+    import queue
+
+    import numpy as np
+
+    from pyradiotracking_amd.analyze import SignalAnalyzer
+
+    iq = config1_stream()
+    q = queue.SimpleQueue()
+    an = SignalAnalyzer("0", gpu=gpu, signal_queue=q)
+    for _ in range(5):
+        an.process_samples(iq)
+    while not q.empty():
+        q.get()
+    lat = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        an.process_samples(iq)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    n_msgs = 0
+    while not q.empty():
+        q.get()
+        n_msgs += 1
+    an._batch.close()
+    return {"single_stream_latency_ms": round(float(np.median(lat)), 3), "single_stream_latency_worst_ms": round(float(max(lat)), 3),
+            "single_stream_latency_note": f"BASELINE config 1 buffer (300 000 complex64 samples in host memory) through SignalAnalyzer.process_samples, "
+                                          f"Signal objects on the queue; median and worst of {reps} callbacks ({n_msgs // reps} messages each); "
+                                          "the reference needs < 1 000 ms per callback to keep up with the SDR"}
+
+
+def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_streams=4):
+    """One configuration of OTHER_CONFIGS on this GPU: its IQ generated in HBM, `steps` timed steps of the whole path
+    (two calls in flight, the bench default lanes), sampled streams against the oracle, then the scan launch alone on one
+    lane.  Everything it allocates is released before it returns."""
+    import numpy as np
+
+    from pyradiotracking_amd import synth
+    from pyradiotracking_amd.analyze import BatchSignalAnalyzer, window_coefficients
+
+    t_begin = time.perf_counter()
+    S, fs, blen, nperseg, lanes = spec["streams"], spec["sample_rate"], spec["samples"], spec["nperseg"], spec["lanes"]
+    n_seg = blen // nperseg
+    dev = f"cuda:{local_rank}"
+    win = window_coefficients(spec["window"], nperseg)
+    extra = {}
+    if spec.get("noise_dbw") is not None:
+        extra["noise_sigma"] = float(np.sqrt(10.0 ** (spec["noise_dbw"] / 10.0) * fs / 2.0))
+    iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=spec["trains"], first_stream=0, **extra)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_begin
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=spec["window"])
+    names = [str(i) for i in range(S)]
+    stream = torch.cuda.current_stream()
+
+    def analyzer(n_lanes):
+        return BatchSignalAnalyzer(names, sdr_callback_length=blen, gpu=local_rank, mode="auto", timing=True,
+                                   hip_stream=stream.cuda_stream if n_lanes <= 1 else None, lanes=n_lanes, **kw)
+
+    def run(an, n_steps, serial=False):
+        acc = [0.0, 0.0, 0]
+        rec = info = None
+        if n_steps and not serial:
+            an.enqueue(iq)
+        for i in range(n_steps):
+            if serial or i + 1 < n_steps:
+                an.enqueue(iq)
+            rec = an.fetch_records()
+            info = an.call_info()
+            acc[0] += info.ms_stft
+            acc[1] += info.ms_detect
+            acc[2] += info.fell_back
+        return rec, info, acc
+
+    an = analyzer(lanes)
+    run(an, spec.get("settle", 4))
+    run(an, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec, info, (ms_stft, ms_detect, fell_back) = run(an, steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    samples = S * n_seg * nperseg
+    value = samples * steps / elapsed / 1e6
+    mode_used = {1: "dense", 2: "sparse", 3: "prefilter", 4: "runfilter"}.get(info.mode_used, "?")
+    # parity: sampled streams against the oracle (the same bits, copied back)
+    _, parity = cpu_baseline(None, an, iq, rec, kw, blen, n_seg, nperseg, timed=False, spread=parity_streams)
+    n_records = int(len(rec))
+    an.close()
+    del an
+    # the scan launch alone: one lane, one call in flight
+    an1 = analyzer(1)
+    run(an1, 3)
+    iso = 5
+    _, info1, (ms1, _, _) = run(an1, iso, serial=True)
+    an1.close()
+    del an1, iq
+    torch.cuda.empty_cache()
+    kernel_ms = ms1 / iso
+    two_scans = mode_used in ("prefilter", "runfilter")
+    scan_name = "stft_scan64" if nperseg == 4096 else "stft_scan"
+    return {
+        "name": name,
+        "workload": f"{S} streams x {fs} SPS x {blen} samples complex64, nperseg {nperseg} {spec['window']}, "
+                    + ("tag trains, 8-16 tags/stream" if spec["trains"] else "4-8 sparse 15 ms pulses/stream")
+                    + (f", noise floor {spec['noise_dbw']} dBW" if spec.get("noise_dbw") is not None else "") + f" -- {spec['what']}",
+        "value": round(value, 1),
+        "unit": "MSamples/s",
+        "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "lanes": lanes,
+        "mode": mode_used,
+        "fallbacks": int(fell_back),
+        "segments_per_chunk": int(getattr(info, "segs_per_chunk", 0)),
+        "records_per_step": n_records,
+        "kernel": (f"{scan_name}: threshold-bit scan + planning + listed scan of a step (first launch to scan event)" if two_scans else scan_name),
+        "kernel_ms": round(kernel_ms, 4),
+        "kernel_ms_note": f"one lane, one call in flight, HIP events on its stream, mean of {iso} steps after the timed ones",
+        "algorithmic_bytes_per_launch": samples * BYTES_PER_SAMPLE,
+        "frac": round(samples * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms > 0 else None,
+        "whole_path_frac": round(value * 1e6 * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
+        "detect_kernel_ms": round(ms_detect / max(1, steps) / max(1, lanes), 4),
+        "parity_streams_checked": parity["streams_checked"],
+        "parity_streams_mismatched": parity["streams_mismatched"],
+        "parity_records_checked": parity["records_checked"],
+        "parity_worst_db_difference": parity["worst_db_difference"],
+        "generate_s": round(t_gen, 1),
+        "wall_s": round(time.perf_counter() - t_begin, 1),
+    }
+
+
+def other_configs(torch, args, local_rank):
+    """The `other_configs` block of the N = 1 line: every configuration of OTHER_CONFIGS, in order, while the block's
+    wall-clock budget lasts (a configuration that does not run is listed as skipped, never silently dropped)."""
+    out = []
+    t0 = time.perf_counter()
+    configs = OTHER_CONFIGS
+    if os.environ.get("RT_BENCH_OTHER_CONFIGS_JSON"):  # (tests: a scaled-down table, same code path)
+        configs = [(n, dict(sp)) for n, sp in json.loads(os.environ["RT_BENCH_OTHER_CONFIGS_JSON"])]
+    for name, spec in configs:
+        spent = time.perf_counter() - t0
+        if spent > args.other_budget_s:
+            out.append({"name": name, "skipped": f"the block's budget of {args.other_budget_s:.0f} s was spent ({spent:.0f} s) before this configuration"})
+            continue
+        try:
+            out.append(measure_other(torch, name, spec, local_rank, args.other_steps))
+        except Exception as e:  # a configuration that fails (e.g. no memory for 137 GB on a shared GPU) must not take the headline with it
+            out.append({"name": name, "failed": f"{type(e).__name__}: {e}"[:500]})
+            torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -165,6 +165,14 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     devs = d["config"]["devices"]
     assert [x["rank"] for x in devs] == [0, 1] and all(x["ordinal"] == 0 for x in devs)  # RT_BENCH_SHARE_GPU: both on GPU 0
     assert all(x["name"] for x in devs)
+    # every rank pinned itself before its first GPU call; two ranks on one GPU (one NUMA node) get disjoint core sets
+    # (the reference: taskset per analyzer, __main__.py:122-128)
+    from pyradiotracking_amd import affinity
+
+    sets = [set(affinity.parse_cpulist(x["cpus"]["cpulist"])) for x in devs]
+    assert all(x["cpus"]["pinned"] and x["cpus"]["n"] == len(c) > 0 for x, c in zip(devs, sets)), devs
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert not (sets[0] & sets[1]), devs
 
 
 def test_bench_fails_fast_when_a_rank_dies_before_the_rendezvous():
@@ -210,3 +218,34 @@ def test_bench_strong_scaling_population_is_the_same_at_every_n():
     assert len({d["config"]["records_per_step"] for d in runs.values()}) == 1, {n: d["config"]["records_per_step"] for n, d in runs.items()}
     assert len({d["config"]["candidate_cells_per_step"] for d in runs.values()}) == 1
     assert runs[1]["config"]["records_per_step"] > 0 and "cpu_baseline" in runs[1]
+
+
+def test_bench_other_configs_block_is_timed_in_the_same_run(monkeypatch):
+    """`other_configs`: after the headline the same process times further configurations (scaled down here), each with its
+    own parity check against the oracle, kernel time and fractions; the headline keys stay what they were"""
+    import bench
+
+    small = [
+        ("config3", dict(streams=24, sample_rate=2400000, samples=240000, nperseg=1024, window="hann", trains=False, lanes=1, what="scaled down")),
+        ("default_geometry_noise_floor", dict(streams=32, sample_rate=300000, samples=300000, nperseg=256, window="hamming", trains=False, lanes=2,
+                                              noise_dbw=-88.0, settle=6, what="scaled down")),
+    ]
+    env_cfg = json.dumps(small)
+    env = dict(os.environ, RT_BENCH_OTHER_CONFIGS_JSON=env_cfg)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--settle", "2", "--isolated-steps", "2",
+                        "--streams", "32", "--cpu-streams", "4", "--parity-streams", "4", "--other-configs", "on", "--other-steps", "3"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["workload"].startswith("config2") and d["value"] > 0
+    oc = d["other_configs"]
+    assert [o["name"] for o in oc] == ["config3", "default_geometry_noise_floor"], oc
+    for o in oc:
+        assert "failed" not in o and "skipped" not in o, o
+        assert o["value"] > 0 and o["kernel_ms"] > 0 and 0 < o["frac"] < 1 and 0 < o["whole_path_frac"] < 1
+        assert o["parity_streams_checked"] == 4 and o["parity_streams_mismatched"] == 0, o
+        assert o["steps"] == 3
+    assert oc[1]["mode"] in ("runfilter", "dense") and oc[0]["mode"] == "sparse", oc
+    assert bench.OTHER_CONFIGS[1][1]["streams"] == 32768  # the real block: all of config 4 on one GPU
