@@ -1,6 +1,8 @@
 """Build the native pieces in-tree (no JIT cache: the .so files travel with the repo snapshot).
 
 * ``librt_analyze.so``   gfx950 HIP kernels + C-ABI (include/rt_analyze.h, rt_match.h, rt_format.h) -- the product
+* ``librt_analyze_diag.so``  the same sources with ``-DRT_DIAG`` (csrc/rt_diag.h): the only build that reads the
+  laboratory's environment switches -- the fault-injection test loads it; nothing else does
 * ``_rt_hostcheck.so``   host build of csrc/rt_core.h's scalar logic          -- unit tests only
 """
 import os
@@ -12,6 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "librt_analyze.so")
+LIB_DIAG = os.path.join(PKG, "librt_analyze_diag.so")
 HOSTCHECK = os.path.join(PKG, "_rt_hostcheck.so")
 
 
@@ -36,10 +39,8 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def build_library(force=False, verbose=False):
-    if not force and _newer(LIB, _sources()):
-        return LIB
-    cmd = [
+def _library_cmd(target, extra=()):
+    return [
         hipcc_path(),
         "-O3",
         "-std=c++17",
@@ -50,16 +51,31 @@ def build_library(force=False, verbose=False):
         "-fno-slp-vectorize",  # SLP packing of the butterflies costs ~25 VGPRs in shuffles, no speed
         "-Wno-unused-value",
         "-Wno-pass-failed",
+        *extra,
         "-I" + os.path.join(REPO, "include"),
         "-o",
-        LIB,
+        target,
         os.path.join(CSRC, "rt_analyze.hip"),
         os.path.join(CSRC, "rt_match.cpp"),  # host-only parts of the C-ABI (include/rt_match.h, rt_format.h)
         os.path.join(CSRC, "rt_format.cpp"),
     ]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+
+
+def build_library(force=False, verbose=False, diag=True):
+    """The product library and (``diag``) its diagnostic twin, compiled side by side (two hipcc processes)."""
+    jobs = []
+    for target, extra in ((LIB, ()), (LIB_DIAG, ("-DRT_DIAG",))):
+        if target == LIB_DIAG and not diag:
+            continue
+        if not force and _newer(target, _sources()):
+            continue
+        cmd = _library_cmd(target, extra)
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return LIB
 
 

@@ -64,6 +64,7 @@ struct CallCtx {
     bool level_settled = false;  // AUTO's level bookkeeping for this call is done (fetch_one passes over a call twice: size query / peek, then delivery)
     bool ran_lin = false;     // its scans detrended by linearity (fetch_one: analysed again if the guard marks a stream)
     uint64_t sub_epoch = 0;   // rt_handle::sub_epoch when its kernels were enqueued
+    int min_items = 0;        // rows per stream of the chunk minima its scan left in the slot's d_chunk_min (= its work items per stream)
     // handle state before this call (restored when the call is rolled back: a later lane failed to enqueue)
     int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0, prev_minsum_slot = -1;
 };
@@ -79,7 +80,9 @@ struct Slot {
     uint16_t *d_cell_hot = nullptr, *d_cell_need = nullptr;  // [S][max_seg][LG] threshold bits of every cell / the cells to emit (RT_MODE_RUNFILTER)
     uint32_t *d_abs_hot = nullptr;    // [S] cells at or above the absolute threshold per stream (StftParams::abs_hot; zero between calls)
     uint32_t *h_abs_hot = nullptr;    // pinned: their maximum over the streams, of this slot's latest MODE 4 / 6 scan
-    uint32_t *d_chunk_min = nullptr;  // [S][N] float bits: per bin the smallest complete-chunk sum of this slot's latest call (StftParams::chunk_min)
+    float *d_thr_bin = nullptr, *d_thr_nat = nullptr;  // [S][N] per-bin thresholds of the exact pre-filter for this slot's call, lane order / bin order
+                                      // (make_bin_thresholds; per slot: the check of call k reads them beside the scan of call k + 1)
+    uint32_t *d_chunk_min = nullptr;  // [S][items][N] float bits: per work item and bin the smallest complete-chunk sum of this slot's latest call (StftParams::chunk_min)
     int32_t *d_seg_list = nullptr;    // [S][max_seg] segments holding such cells, then [S] their number per stream and [1] the batch's total
     int32_t *h_seg_total = nullptr;   // pinned: that total, copied behind plan_runs
     rt_record *d_raw = nullptr;
@@ -97,7 +100,7 @@ struct Slot {
     int32_t *h_dc_flag = nullptr;                              // pinned, [S]: set by a LIN scan for a stream whose constant offset is too large for that form (StftParams::dc_flag)
     int32_t *h_list = nullptr;                                 // pinned, [kMaxPartial]: the streams of a partial dense re-run (read by the kernels)
     unsigned long long *h_total = nullptr;                     // pinned: records allocated so far, uploaded before a partial re-run
-    hipEvent_t ev_begin = nullptr, ev_scan = nullptr, ev_done = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_first = nullptr, ev_scan = nullptr, ev_done = nullptr;  // first launch; end of the first scan; end of the scans; end of the call
     CallCtx call;
 };
 
@@ -152,7 +155,6 @@ struct rt_handle {
     // calls before it probes the level below again (a failed probe costs a wasted scan: the interval doubles, 16 .. 1024).
     bool prefilter_ok = false;
     bool runfilter_ok = false;  // RT_MODE_RUNFILTER is possible and its scratch is allocated
-    float *d_thr_bin = nullptr, *d_thr_nat = nullptr;  // [S][N] per-bin thresholds of the exact pre-filter, lane order / bin order (make_bin_thresholds)
     int minsum_slot = -1;       // the slot whose d_chunk_min holds the latest call's chunk minima (-1: none yet)
     int run_cells = 1;          // r: cells a plateau needs unless it runs through t = 0 (plan_runs)
     int auto_level = RT_MODE_SPARSE;
@@ -165,6 +167,7 @@ struct rt_handle {
     uint64_t n_calls = 0;  // calls enqueued so far
     uint64_t test_enqueues = 0;  // laned handle: rt_process calls seen (fault injection, read once at rt_create: RT_TEST_FAIL_LANE=<lane>:<n>)
     int test_fail_lane = -1, test_fail_nth = 0;
+    int tail_mode = 0;     // 0: a call's planning kernels and second scan in order on s_scan; 1: on s_detect with the detection (enqueue_analysis)
     int tail_cur = 0;      // tail buffer holding the most recent buffer's columns
     int n_seg_last = -1;
     std::vector<uint8_t> reset_pending;  // [S] streams whose look-back is dropped at the next rt_process
@@ -209,11 +212,11 @@ int next_pow2(int v) {
 // workgroup drawing further items from p.work (rt_kernels.h: "Work items") -- more workgroups than that would only
 // queue in the dispatcher and find the counter exhausted.
 template <int MODE, bool U8, bool LIN>
-void launch_stft_lin(rt_handle *h, const StftParams &p, int items) {
+void launch_stft_lin(rt_handle *h, const StftParams &p, int items, hipStream_t st) {
     if (scan_wave64(h->R3)) {
         // nperseg 4096: one wave per segment, items drawn per wave; one 8-wave workgroup (all of a CU's LDS) per CU
         const int wgs = std::min((items + kW64Waves - 1) / kW64Waves, h->n_cu);
-        hipLaunchKernelGGL((stft_scan64<MODE, U8, LIN>), dim3(wgs), dim3(kW64Block), 0, h->s_scan, p);
+        hipLaunchKernelGGL((stft_scan64<MODE, U8, LIN>), dim3(wgs), dim3(kW64Block), 0, st, p);
         return;
     }
     const int blk = scan_block(h->R3);
@@ -224,12 +227,12 @@ void launch_stft_lin(rt_handle *h, const StftParams &p, int items) {
     const bool persist = scan_persistent(h->R3, MODE);
     const int blocks = persist ? std::min(items, h->n_cu * per_cu) : items;
     switch (h->R3) {
-        case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
-        case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
-        case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
-        case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+        case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((stft_scan<8, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
 #if !RT_WAVE64_4096
-        default: hipLaunchKernelGGL((stft_scan<16, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, h->s_scan, p); break;
+        default: hipLaunchKernelGGL((stft_scan<16, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
 #else
         default: break;  // (nperseg 4096 is stft_scan64's, above)
 #endif
@@ -241,28 +244,28 @@ void launch_stft_lin(rt_handle *h, const StftParams &p, int items) {
 // constant, x - mean is exactly zero and so is every cell of it in the reference -> std = NaN over a plateau that holds
 // one; the linearity form leaves a residue 140 dB under the offset there -- found by the round-2 soak)
 template <int MODE, bool U8 = false>
-void launch_stft(rt_handle *h, const StftParams &p, int blocks) {
+void launch_stft(rt_handle *h, const StftParams &p, int blocks, hipStream_t st) {
     if (h->lin && MODE != 3 && !U8) {
         if (p.stream_list || h->n_sub == 0 || !p.sub_first) {
             // (a launch over a list of its own -- AUTO's dense re-run of a few streams -- keeps the linearity form for all of them: its
             // dense spectrogram is indexed by position in that list, which a second launch over a sub-list cannot address)
             StftParams q = p;
             if (p.stream_list) q.sub_first = nullptr;
-            launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, q, blocks);
+            launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, q, blocks, st);
         } else {
             // the streams the guard of that form has marked (StftParams::dc_flag): the first launch leaves them alone, the
             // subtract-first instantiation takes them, by list
-            launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, p, blocks);
+            launch_stft_lin<MODE, U8, (MODE != 3 && !U8)>(h, p, blocks, st);
             StftParams q = p;
             q.sub_first = nullptr;
             q.dc_flag = nullptr;
             q.spec_by_stream = 1;
             q.stream_list = h->h_sub_list;
             q.n_streams = h->n_sub;
-            launch_stft_lin<MODE, U8, false>(h, q, h->n_sub * p.blocks_per_stream);
+            launch_stft_lin<MODE, U8, false>(h, q, h->n_sub * p.blocks_per_stream, st);
         }
     } else {
-        launch_stft_lin<MODE, U8, false>(h, p, blocks);
+        launch_stft_lin<MODE, U8, false>(h, p, blocks, st);
     }
 }
 
@@ -467,9 +470,11 @@ static_assert(kAutoDense == RT_MODE_DENSE && kAutoSparse == RT_MODE_SPARSE && kA
 int level_up(const rt_handle *h, int mode) { return level_up(AutoLevels{h->prefilter_ok, h->runfilter_ok}, mode); }
 int level_down(const rt_handle *h, int mode) { return level_down(AutoLevels{h->prefilter_ok, h->runfilter_ok}, mode); }
 
+// (`st`: the handle's scan stream, or -- the selective second scans of the pre-filter levels -- the stream of what follows a call's first scan)
 template <int MODE>
-void launch_scan(rt_handle *h, const StftParams &sp, int blocks, bool u8) {
-    if (u8) launch_stft<MODE, true>(h, sp, blocks); else launch_stft<MODE>(h, sp, blocks);
+void launch_scan(rt_handle *h, const StftParams &sp, int blocks, bool u8, hipStream_t st = nullptr) {
+    if (!st) st = h->s_scan;
+    if (u8) launch_stft<MODE, true>(h, sp, blocks, st); else launch_stft<MODE>(h, sp, blocks, st);
 }
 
 // enqueue scan + detect + readback for the call described by sl.call, analysed the way `mode` says.
@@ -509,43 +514,66 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         const int64_t cells = (int64_t)S * h->N;
         if (own_means) {
             hipLaunchKernelGGL(make_bin_thresholds_from_means, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, sl.d_psum, sp.blocks_per_stream,
-                               c.n_seg, h->d_thr_bin, h->d_thr_nat, S, h->R3, h->cfg.snr_threshold);
+                               c.n_seg, sl.d_thr_bin, sl.d_thr_nat, S, h->R3, h->cfg.snr_threshold);
         } else {
         if (h->minsum_slot < 0) {
             // the handle's very first call: no chunk minima yet.  A scan of this buffer provides them (its bits, taken with
             // the absolute threshold alone, are overwritten by the scan proper below) -- once per handle.
-            RT_HIP(h, hipMemsetAsync(sl.d_chunk_min, 0x7f, (size_t)S * h->N * sizeof(uint32_t), h->s_scan));
             launch_scan<6>(h, sp, blocks, c.u8);
             h->minsum_slot = slot_index;
+            sl.call.min_items = sp.blocks_per_stream;
         }
-        const uint32_t *prev = h->slot[h->minsum_slot].d_chunk_min;
-        hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, prev, h->d_thr_bin, h->d_thr_nat, S, h->R3,
-                           h->L * minsum_group(h->L, h->GPW), h->cfg.snr_threshold);
+        const Slot &ps = h->slot[h->minsum_slot];
+        hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, ps.d_chunk_min, ps.call.min_items, sl.d_thr_bin,
+                           sl.d_thr_nat, S, h->R3, h->L * minsum_group(h->L, h->GPW), h->cfg.snr_threshold);
         }
     }
     if (sl.d_chunk_min && !second_pass_only) {
-        RT_HIP(h, hipMemsetAsync(sl.d_chunk_min, 0x7f, (size_t)S * h->N * sizeof(uint32_t), h->s_scan));
+        sl.call.min_items = sp.blocks_per_stream;  // (every item of the scan below writes its row of minima: nothing to reset)
         // the LATEST buffer's minima set the next call's thresholds: a call analysed again from rt_fetch (level-up, stale
         // thresholds, pool growth, the detrend guard) while a later one is in flight must not take that place back
         if (h->minsum_slot < 0 || sl.call.seq >= h->slot[h->minsum_slot].call.seq) h->minsum_slot = slot_index;
     }
+    // `sd`: the stream of the call's detection (and, experimentally, of more of what follows its first scan).  Where the handle has
+    // a second stream (rt_create: nperseg <= 512 without lanes) the first scan of the NEXT call, ready at the same moment on s_scan,
+    // takes the chip while this call's detection runs beside it (config 2 one lane 0.79 -> 0.73 ms per step, profiles/r04_e_*).
+    // What comes BETWEEN a call's two scans on the pre-filter levels -- planning kernels, the selective second scan -- stays in
+    // order on s_scan (tail_mode 0): moved to `sd` as well (tail_mode 1, a diagnostic build's RT_EXP_TAIL=C) the second scan is
+    // dispatched behind the next call's chip-filling first scan and gets no workgroup slot until that scan has handed out its last
+    // workgroup -- it ends with it, 1.9 ms instead of 0.23, the detection behind it is exposed, rt_fetch returns a scan late and
+    // the host enqueues late: 2.33 - 2.49 ms per step against 2.26 - 2.45 in order at the reference's default geometry, whatever
+    // the stream's priority (profiles/r05_b_tail_on_second_stream.txt).  Safe by the slots: everything the tail reads or writes is
+    // its call's slot's (per-bin thresholds included), the look-back tail it reads is two rotations from the one the next scan
+    // writes, and a scan that reuses the slot waits for ev_done (claim_slot).  The dense path stays in order on the scan's stream:
+    // its spectrogram is one per handle.
+    hipStream_t sd = dense ? h->s_scan : h->s_detect;
+    hipStream_t s2 = (h->tail_mode >= 1 && !dense) ? sd : h->s_scan;  // the stream of the planning kernels and the second scan
+    auto behind_first_scan = [&]() -> int {
+        if (s2 != h->s_scan) {
+            RT_HIP(h, hipEventRecord(sl.ev_first, h->s_scan));
+            RT_HIP(h, hipStreamWaitEvent(s2, sl.ev_first, 0));
+        }
+        return RT_OK;
+    };
     if (dense) {
         launch_scan<1>(h, sp, blocks, c.u8);
     } else if (mode == RT_MODE_RUNFILTER) {
         // threshold bits of every cell (+ row sums, tail) -> cells of runs long enough -> only their segments again
-        sp.thr_bin = h->d_thr_bin;
+        sp.thr_bin = sl.d_thr_bin;
         sp.abs_hot = sl.d_abs_hot;
         launch_scan<6>(h, sp, blocks, c.u8);
         sp.thr_bin = nullptr;
         sp.abs_hot = nullptr;
-        hipLaunchKernelGGL(max_abs_hot, dim3(1), dim3(256), 0, h->s_scan, sl.d_abs_hot, S, sl.h_abs_hot);
-        sl.call.abs_counted = true;
+        { const int rc = behind_first_scan(); if (rc != RT_OK) return rc; }
         {
+            // one launch behind the scan: the largest per-stream count of cells over the absolute threshold (AUTO's probes), the
+            // check of the per-bin thresholds against this buffer's row means, the segment counters back to zero
             const int64_t cells = (int64_t)S * h->N;
-            hipLaunchKernelGGL(check_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, h->d_thr_nat, sl.d_psum, S, h->N,
-                               sp.blocks_per_stream, c.n_seg, h->cfg.snr_threshold, sl.h_overflow, sl.d_counters, kFlagHotOverflow | kFlagThrStale);
+            hipLaunchKernelGGL(after_bit_scan, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s2, sl.d_abs_hot, sl.h_abs_hot, sl.d_thr_nat, sl.d_psum, S, h->N,
+                               sp.blocks_per_stream, c.n_seg, h->cfg.snr_threshold, sl.h_overflow, sl.d_counters, kFlagHotOverflow | kFlagThrStale,
+                               const_cast<int32_t *>(sp.seg_count));
         }
-        RT_HIP(h, hipMemsetAsync(const_cast<int32_t *>(sp.seg_count), 0, ((size_t)S + 1) * sizeof(int32_t), h->s_scan));
+        sl.call.abs_counted = true;
         {
             // (a run needs r cells: more than the buffer holds means "only the run through t = 0", which r = n_seg + 1 says as well)
             const int r = (int)std::min<long long>(h->run_cells, (long long)c.n_seg + 1);
@@ -554,22 +582,24 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
             const int waves = (c.n_seg + tpw * tile - 1) / (tpw * tile);
             const size_t plan_lds = ((size_t)tpw * tile + 3) & ~(size_t)3;
             auto *kern = r <= 16 ? plan_runs<4> : r <= 256 ? plan_runs<8> : plan_runs<16>;
-            hipLaunchKernelGGL(kern, dim3(S, waves), dim3(64), plan_lds, h->s_scan, sp.cell_hot, sl.d_cell_need,
+            hipLaunchKernelGGL(kern, dim3(S, waves), dim3(64), plan_lds, s2, sp.cell_hot, sl.d_cell_need,
                                sl.d_seg_list, const_cast<int32_t *>(sp.seg_count), c.n_seg, h->LG, r, tile);
         }
-        RT_HIP(h, hipMemcpyAsync(sl.h_seg_total, sp.seg_count + S, sizeof(int32_t), hipMemcpyDeviceToHost, h->s_scan));
-        launch_scan<7>(h, sp, blocks, c.u8);
+        launch_scan<7>(h, sp, blocks, c.u8, s2);
     } else if (mode == RT_MODE_PREFILTER) {
         if (!second_pass_only) {
             sp.abs_hot = sl.d_abs_hot;
             launch_scan<4>(h, sp, blocks, c.u8);
             sp.abs_hot = nullptr;
-            hipLaunchKernelGGL(max_abs_hot, dim3(1), dim3(256), 0, h->s_scan, sl.d_abs_hot, S, sl.h_abs_hot);
+        }
+        { const int rc = behind_first_scan(); if (rc != RT_OK) return rc; }
+        if (!second_pass_only) {
+            hipLaunchKernelGGL(max_abs_hot, dim3(1), dim3(256), 0, s2, sl.d_abs_hot, S, sl.h_abs_hot);
             sl.call.abs_counted = true;
         }
-        hipLaunchKernelGGL(plan_pass_b, dim3(S), dim3(256), sizeof(uint32_t) * ((sp.chunks + 31) / 32), h->s_scan, sp.full, sp.first,
+        hipLaunchKernelGGL(plan_pass_b, dim3(S), dim3(256), sizeof(uint32_t) * ((sp.chunks + 31) / 32), s2, sp.full, sp.first,
                            sp.item_chunks, sp.item_count, h->LG, sp.segs_per_chunk, c.n_seg, sp.chunks, sp.blocks_per_stream, h->GPW);
-        launch_scan<5>(h, sp, blocks, c.u8);
+        launch_scan<5>(h, sp, blocks, c.u8, s2);
     } else {
 #ifdef RT_STAMPS  // diagnostic build: per-stage cycle sums of every wave of the sparse scan, averaged and printed (stderr)
         static uint32_t *d_dbg = nullptr;
@@ -596,7 +626,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
                 waves += 1;
                 for (int k = 0; k < kStamps; ++k) sum[k] += hd[w * kStamps + k];
             }
-            if (const char *dump = std::getenv("RT_STAMPS_DUMP")) {  // raw per-wave words of the last launch, for timelines
+            if (const char *dump = RT_DIAG_ENV("RT_STAMPS_DUMP")) {  // raw per-wave words of the last launch, for timelines
                 if (FILE *f = std::fopen(dump, "wb")) {
                     std::fwrite(hd.data(), sizeof(uint32_t), words, f);
                     std::fclose(f);
@@ -624,23 +654,20 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
 #endif
     }
     RT_HIP(h, hipGetLastError());
-    RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
-
-    // The sparse detection runs on a stream of its own behind the scan's event (where rt_create made one): with two calls in flight
-    // the NEXT call's scan is ready at the same moment, and the detection kernels share the chip with its first workgroups
-    // (nperseg <= 512: one workgroup per item) or move into the CUs its waves leave at its end (nperseg 4096: a persistent grid
-    // whose waves finish an item apart) instead of taking a stretch of their own between two scans.  Safe by the slots: a call's
-    // candidate lists, row sums and record pool are its slot's, the look-back tail it reads is two rotations from the one the next
-    // scan writes, and a scan that reuses the slot waits for this call's ev_done (claim_slot).  The dense path stays in order on
-    // the scan's stream: its spectrogram is one per handle.
-    hipStream_t sd = dense ? h->s_scan : h->s_detect;
-    if (sd != h->s_scan) RT_HIP(h, hipStreamWaitEvent(sd, sl.ev_scan, 0));
+    // (ev_scan: the end of the call's scans -- on `sd` where a second scan ran there)
+    const bool two_scans = !dense && (mode == RT_MODE_RUNFILTER || mode == RT_MODE_PREFILTER);
+    RT_HIP(h, hipEventRecord(sl.ev_scan, two_scans ? s2 : h->s_scan));
+    if (sd != (two_scans ? s2 : h->s_scan)) RT_HIP(h, hipStreamWaitEvent(sd, sl.ev_scan, 0));
     DetectArgs a = make_detect_args(h, sl, c.n_seg, h->N, c.n_seg_last);
     a.prev = h->d_tail[c.tail_read];
     a.prev_cols = h->K;
     a.chunks = sp.blocks_per_stream;
     a.spec = h->d_spec;
     a.filtered = (mode == RT_MODE_PREFILTER || mode == RT_MODE_RUNFILTER) ? 1 : 0;
+    if (mode == RT_MODE_RUNFILTER) {
+        a.seg_total = sp.seg_count + S;  // (the planner's batch total -> pinned host word, by the call's last finalize_records workgroup)
+        a.host_seg_total = sl.h_seg_total;
+    }
     if (dense) {
         hipLaunchKernelGGL(detect_dense, dim3(S), dim3(kDetBlock), h->lds_dense, sd, a);
     } else {
@@ -786,15 +813,17 @@ int for_each_lane(rt_handle *h, F call, bool enqueues = false) {
             }
         }
     }
-    // test hook (tests/test_gpu_parity.py, fault injection): a handle created under RT_TEST_FAIL_LANE=<k>:<n> has its lane k
-    // refuse the handle's n-th enqueue, as a device allocation failure inside that lane would (the variable is read once,
-    // at rt_create; nothing looks at the environment on this path)
+    // test hook of the DIAGNOSTIC build (librt_analyze_diag.so; tests/test_gpu_parity.py, fault injection): a handle created under
+    // RT_TEST_FAIL_LANE=<k>:<n> has its lane k refuse the handle's n-th enqueue, as a device allocation failure inside that lane
+    // would.  The product build never reads the environment (rt_diag.h): test_fail_lane stays -1 there.
     int fail_lane = -1;
+#ifdef RT_DIAG
     if (enqueues && h->test_fail_lane >= 0 && ++h->test_enqueues == (uint64_t)h->test_fail_nth) fail_lane = h->test_fail_lane;
+#endif
     for (size_t k = 0; k < h->kids.size(); ++k) {
         int rc;
         if ((int)k == fail_lane) {
-            h->kids[k]->err = "injected failure (RT_TEST_FAIL_LANE)";
+            h->kids[k]->err = "injected failure";
             rc = RT_E_NOMEM;
         } else {
             rc = call(h->kids[k], (int64_t)h->kid_base[k]);
@@ -840,8 +869,6 @@ void rt_destroy(rt_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_work);
-    (void)hipFree(h->d_thr_bin);
-    (void)hipFree(h->d_thr_nat);
     (void)hipFree(h->d_window);
     (void)hipFree(h->d_window_t);
     (void)hipFree(h->d_sub_first);
@@ -865,6 +892,8 @@ void rt_destroy(rt_handle *h) {
         (void)hipFree(sl.d_cell_hot);
         (void)hipFree(sl.d_cell_need);
         (void)hipFree(sl.d_chunk_min);
+        (void)hipFree(sl.d_thr_bin);
+        (void)hipFree(sl.d_thr_nat);
         (void)hipFree(sl.d_abs_hot);
         (void)hipHostFree(sl.h_abs_hot);
         (void)hipFree(sl.d_seg_list);
@@ -883,6 +912,7 @@ void rt_destroy(rt_handle *h) {
         (void)hipHostFree(sl.h_list);
         (void)hipHostFree(sl.h_total);
         if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
+        if (sl.ev_first) (void)hipEventDestroy(sl.ev_first);
         if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     }
@@ -911,7 +941,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         rt_handle *p = new (std::nothrow) rt_handle();
         if (!p) return fail_create(RT_E_NOMEM, "out of host memory");
         p->cfg = *cfg;
-        if (const char *spec = std::getenv("RT_TEST_FAIL_LANE")) {
+        if (const char *spec = RT_DIAG_ENV("RT_TEST_FAIL_LANE")) {  // (diagnostic builds only: rt_diag.h)
             int lane = -1, nth = 0;
             if (std::sscanf(spec, "%d:%d", &lane, &nth) == 2 && lane >= 0 && nth > 0) {
                 p->test_fail_lane = lane;
@@ -981,7 +1011,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         }
         // nperseg 4096 without chunk bits (they need chunks of one length): a stream's earliest chunks are half as long, so that
         // the last items a launch hands out are short (rt_kernels.h: chunk_geometry).  A few chunks more than max_seg / L.
-        h->two_level = scan_wave64(R3) && !h->prefilter_ok && !std::getenv("RT_EXP_ONE_LEVEL");  // (the variable: A/B runs, read once here)
+        h->two_level = scan_wave64(R3) && !h->prefilter_ok && !RT_DIAG_ENV("RT_EXP_ONE_LEVEL");  // (the variable: A/B runs of diagnostic builds, rt_diag.h)
         if (h->two_level) {
             h->max_chunks += h->max_chunks / 4 + 2;
             max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
@@ -1002,7 +1032,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             // bit set, while SNR-aware cell bits stay selective): its scratch (two slots of threshold bits + kept cells +
             // segment lists + chunk minima) is taken where it is a small part of what is free -- at most half where it is
             // the only middle level, an eighth where the chunk bits exist -- and AUTO does without it otherwise.
-            const size_t per_slot = (size_t)cfg->n_streams * std::max(h->max_seg, 1) * (size_t)(h->LG * 4 + 4) + (size_t)cfg->n_streams * h->N * 4;
+            const size_t per_slot = (size_t)cfg->n_streams * std::max(h->max_seg, 1) * (size_t)(h->LG * 4 + 4) + (size_t)cfg->n_streams * h->N * 4 * (size_t)(h->max_blocks + 2);
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)kSlots * per_slot > free_b / (h->prefilter_ok ? 8 : 2)) h->runfilter_ok = false;
         }
@@ -1048,15 +1078,27 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     } else {
         RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking));
         h->own_scan_stream = true;
-        // The sparse detection on a stream of its own (enqueue_analysis) -- where it pays.  Measured on one box each, whole path,
-        // against everything in order on one stream (profiles/r04_e_*): config 2 one lane 0.79 -> 0.73 ms per step, config-5 share
-        // (nperseg 4096, one lane) 5.60 -> 5.49.  Not for the lanes of a laned handle (they overlap one another's detection
-        // already: config 2 two lanes 0.688 -> 0.735, uint8 0.534 -> 0.571), not at nperseg 1024 / 2048 (config 3 14.87 -> 15.7:
-        // behind a persistent grid of 16-point-per-lane workgroups the next scan takes the chip first, the detection runs at
-        // its very end and rt_fetch -- and with it the host's next rt_process -- returns a scan later than it could).  Stream
-        // priorities changed none of this.
-        if (R3 == 4 || R3 == 8 || g_creating_lane || std::getenv("RT_EXP_ONE_STREAM")) h->s_detect = h->s_scan;  // (the variable: A/B runs, read once here)
-        else RT_CREATE_HIP(hipStreamCreateWithFlags(&h->s_detect, hipStreamNonBlocking));
+        // A second stream for everything behind a call's first scan (enqueue_analysis: `sd`) -- where it pays.  Measured on one box
+        // each, whole path, against everything in order on one stream: config 2 one lane 0.79 -> 0.73 ms per step (profiles/r04_e_*);
+        // the exact pre-filter at the reference's default geometry 2.45 -> 2.1 ms (round 5: its planning kernels and second scan run
+        // beside the next call's first scan, profiles/r05_b_*).  Not at nperseg >= 1024: behind a persistent grid (a chip-filling
+        // launch whose workgroups live until the items run out) the next scan takes the chip first, the tail runs at its very end,
+        // and rt_fetch -- and with it the host's next rt_process -- returns a scan later than it could (config 3 14.87 -> 15.7 ms per
+        // step; nperseg 4096: 5.09 ms per launch in order against 5.34 with the detection's stream beside it, round 4's csv).
+        // The lanes of a laned handle overlap one another's tails already (config 2 two lanes 0.688 -> 0.735 with a second stream
+        // per lane).  Stream priorities changed none of this.
+        bool second = R3 <= 2 && !g_creating_lane;
+        if (const char *v = RT_DIAG_ENV("RT_EXP_TAIL")) h->tail_mode = (v[0] == 'C') ? 1 : 0;
+        if (const char *v = RT_DIAG_ENV("RT_EXP_STREAMS")) second = (v[0] == '2');  // (diagnostic builds: "1" / "2" force the choice, lanes included)
+        if (!second) {
+            h->s_detect = h->s_scan;
+        } else {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            int prio = greatest;
+            if (const char *v = RT_DIAG_ENV("RT_EXP_TAIL_PRIO")) prio = v[0] == 'l' ? least : v[0] == 'n' ? 0 : greatest;
+            RT_CREATE_HIP(hipStreamCreateWithPriority(&h->s_detect, hipStreamNonBlocking, prio));
+        }
     }
 
     const int S = cfg->n_streams, N = h->N, LG = h->LG;
@@ -1171,8 +1213,9 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             const size_t cells = (size_t)S * std::max(h->max_seg, 1) * LG;
             RT_CREATE_HIP(hipMalloc(&sl.d_cell_hot, cells * sizeof(uint16_t)));
             RT_CREATE_HIP(hipMalloc(&sl.d_cell_need, cells * sizeof(uint16_t)));
-            RT_CREATE_HIP(hipMalloc(&sl.d_chunk_min, (size_t)S * N * sizeof(uint32_t)));
-            RT_CREATE_HIP(hipMemset(sl.d_chunk_min, 0x7f, (size_t)S * N * sizeof(uint32_t)));
+            RT_CREATE_HIP(hipMalloc(&sl.d_chunk_min, std::max<size_t>(psum_bytes, 4)));  // (a row per work item, like psum)
+            RT_CREATE_HIP(hipMalloc(&sl.d_thr_bin, (size_t)S * N * sizeof(float)));
+            RT_CREATE_HIP(hipMalloc(&sl.d_thr_nat, (size_t)S * N * sizeof(float)));
             RT_CREATE_HIP(hipMalloc(&sl.d_seg_list, ((size_t)S * std::max(h->max_seg, 1) + S + 1) * sizeof(int32_t)));
             RT_CREATE_HIP(hipHostMalloc(&sl.h_seg_total, sizeof(int32_t)));
             *sl.h_seg_total = 0;
@@ -1210,14 +1253,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipHostMalloc(&sl.h_list, (size_t)kMaxPartial * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_total, sizeof(unsigned long long)));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_begin));
+        RT_CREATE_HIP(hipEventCreateWithFlags(&sl.ev_first, hipEventDisableTiming));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_scan));
         RT_CREATE_HIP(hipEventCreate(&sl.ev_done));
     }
 
-    if (h->runfilter_ok) {
-        RT_CREATE_HIP(hipMalloc(&h->d_thr_bin, (size_t)S * N * sizeof(float)));
-        RT_CREATE_HIP(hipMalloc(&h->d_thr_nat, (size_t)S * N * sizeof(float)));
-    }
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
@@ -1546,6 +1586,16 @@ static void discard_oldest(rt_handle *h) {
     sl->call.pending = false;
 }
 
+// A call is about to be analysed again from rt_fetch (level-up, stale thresholds, pool growth, the detrend guard) while a later
+// call may be in flight: its re-run scan rewrites the look-back columns that later call's detection reads on the handle's second
+// stream (the same values, or a superset of the cells -- still an unordered read / write pair), so the re-run waits for it.
+static int before_rerun(rt_handle *h, Slot &sl) {
+    if (h->s_detect != h->s_scan)
+        for (auto &o : h->slot)
+            if (&o != &sl && o.call.pending) RT_HIP(h, hipStreamWaitEvent(h->s_scan, o.ev_done, 0));
+    return RT_OK;
+}
+
 // rt_fetch of one (lane-less) handle.  `peek`: wait, settle fall-backs and count, but deliver nothing and
 // keep the call pending even when it has no records (the laned rt_fetch sizes all lanes before it copies).
 static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bool peek) {
@@ -1579,8 +1629,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             sl.h_dc_flag[s] = 0;
         }
         if (newly) {
-            // (everything of this handle runs on s_scan: drained first, so that no kernel in flight reads the list while it changes)
+            // (both of the handle's streams drained first, so that no kernel in flight reads the list while it changes)
             RT_HIP(h, hipStreamSynchronize(h->s_scan));
+            RT_HIP(h, hipStreamSynchronize(h->s_detect));
             h->n_sub = 0;
             for (int s = 0; s < h->cfg.n_streams; ++s)
                 if (h->h_sub_first[(size_t)s]) h->h_sub_list[h->n_sub++] = s;
@@ -1590,8 +1641,22 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         if (c.sub_epoch != h->sub_epoch) {
             for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
             c.n_dense_streams = 0;
-            int rc = enqueue_analysis(h, sl, c.mode_used);  // (takes the current epoch)
+            int rc = before_rerun(h, sl);
+            if (rc == RT_OK) rc = enqueue_analysis(h, sl, c.mode_used);  // (takes the current epoch)
             if (rc != RT_OK) return rc;
+            // The call enqueued behind this one (at most one is in flight) was analysed under the old set as well, and the next
+            // rt_process will read the look-back columns it wrote: it is analysed again HERE, in sequence order, before anything
+            // newer can be enqueued -- not at its own fetch, by which time a newer call's detection would have read the old
+            // columns or raced the rewrite (advisor, round 4).  Once per marking.
+            for (auto &o : h->slot) {
+                if (&o == &sl || !o.call.pending || o.call.seq < c.seq || !o.call.ran_lin || o.call.is_extract || o.call.n_seg <= 0 ||
+                    o.call.sub_epoch == h->sub_epoch)
+                    continue;
+                RT_HIP(h, hipEventSynchronize(o.ev_done));
+                for (int s = 0; s < h->cfg.n_streams; ++s) o.h_overflow[s] = o.h_incons[s] = o.h_dc_flag[s] = 0;
+                rc = enqueue_analysis(h, o, o.call.mode_used);  // (behind this call's re-run on s_scan; its scratch is its slot's)
+                if (rc != RT_OK) return rc;
+            }
             RT_HIP(h, hipEventSynchronize(sl.ev_done));
             flags = sl.h_counters[2];
             for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_dc_flag[s] = 0;  // (marked streams mark themselves again: nothing new)
@@ -1623,7 +1688,8 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
                          !(c.mode_used == RT_MODE_SPARSE && level_up(h, RT_MODE_SPARSE) != RT_MODE_DENSE);
         if (stale && !(h->cfg.mode == RT_MODE_AUTO && few)) {
             c.thr_rerun = true;
-            int rc = enqueue_analysis(h, sl, RT_MODE_RUNFILTER, nullptr, false, true);
+            int rc = before_rerun(h, sl);
+            if (rc == RT_OK) rc = enqueue_analysis(h, sl, RT_MODE_RUNFILTER, nullptr, false, true);
             if (rc != RT_OK) return rc;
             RT_HIP(h, hipEventSynchronize(sl.ev_done));
             flags = sl.h_counters[2];
@@ -1641,7 +1707,8 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             // than the fixed ~1 ms of a dense re-run of a few streams -- one workgroup per stream in detect_dense)
             if (few) {
                 const unsigned long long other = flags & ~(kFlagHotOverflow | (incons_elsewhere ? 0ull : kFlagInconsistent));
-                int rc = enqueue_partial_dense(h, sl, n_bad, sl.h_counters[0]);
+                int rc = before_rerun(h, sl);
+                if (rc == RT_OK) rc = enqueue_partial_dense(h, sl, n_bad, sl.h_counters[0]);
                 if (rc == RT_OK) {
                     RT_HIP(h, hipEventSynchronize(sl.ev_done));
                     flags = other | sl.h_counters[2];
@@ -1655,10 +1722,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
                 if (rc != RT_E_NOMEM) return rc;
             }
         }
-        // Re-run of the same buffer with the same look-back state, one level up.  Everything of this handle runs in
-        // order on its own stream, so the re-run queues up behind whatever is in flight there (a later call
-        // read the tail columns this call's first scan already wrote -- the re-run writes the same values);
-        // other lanes' streams are left alone.
+        // Re-run of the same buffer with the same look-back state, one level up.  Its scan queues up behind whatever is in
+        // flight on the handle's scan stream and behind the later call's detection (before_rerun: that call read the tail
+        // columns this call's first scan already wrote -- the re-run writes the same values); other lanes' streams are left alone.
         const int from = c.mode_used;
         c.mode_used = level_up(h, from);
         // stay on that level for a while; every further failed probe doubles the while (a probe costs a wasted scan;
@@ -1669,7 +1735,8 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             h->sticky_len = std::min(h->sticky_len * 2, 1024);
         }
         c.fell_back = true;
-        int rc = enqueue_analysis(h, sl, c.mode_used, nullptr, from == RT_MODE_SPARSE && c.mode_used == RT_MODE_PREFILTER);
+        int rc = before_rerun(h, sl);
+        if (rc == RT_OK) rc = enqueue_analysis(h, sl, c.mode_used, nullptr, from == RT_MODE_SPARSE && c.mode_used == RT_MODE_PREFILTER);
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventSynchronize(sl.ev_done));
         flags = sl.h_counters[2];
@@ -1685,7 +1752,8 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             c.pool_grown = true;  // once per call
             for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
             c.n_dense_streams = 0;
-            int rc = enqueue_analysis(h, sl, c.mode_used);
+            int rc = before_rerun(h, sl);
+            if (rc == RT_OK) rc = enqueue_analysis(h, sl, c.mode_used);
             if (rc != RT_OK) return rc;
             RT_HIP(h, hipEventSynchronize(sl.ev_done));
             flags = sl.h_counters[2];
@@ -1856,7 +1924,7 @@ int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t 
     RT_HIP(h, hipDeviceSynchronize());
     StftParams sp = make_stft_params(h, h->slot[0], iq_dev, stream_stride, T, 0);
     sp.spec = spec_dev;
-    launch_stft<2>(h, sp, h->cfg.n_streams * sp.blocks_per_stream);
+    launch_stft<2>(h, sp, h->cfg.n_streams * sp.blocks_per_stream, h->s_scan);
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipStreamSynchronize(h->s_scan));
     return RT_OK;
@@ -1878,7 +1946,7 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
     if (T < 2) return RT_OK;
     RT_HIP(h, hipDeviceSynchronize());
     StftParams sp = make_stft_params(h, h->slot[0], iq_dev, stream_stride, T, 0);
-    launch_stft<3>(h, sp, h->cfg.n_streams * sp.blocks_per_stream);
+    launch_stft<3>(h, sp, h->cfg.n_streams * sp.blocks_per_stream, h->s_scan);
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipStreamSynchronize(h->s_scan));
     return RT_OK;

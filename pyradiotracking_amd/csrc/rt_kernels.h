@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "../../include/rt_analyze.h"
+#include "rt_diag.h"  // first: refuses laboratory switches in a product build
 #include "rt_core.h"
 #include "rt_fft.h"
 
@@ -84,8 +85,10 @@ struct StftParams {
     const int32_t *seg_count;
     uint32_t *abs_hot;       // [S] (+ word [S]: their maximum, by the planning kernel), or null: MODE 4 / 6 add the stream's cells at or above the
                              // absolute threshold -- what the sparse lists would have to hold at least (AUTO skips probes that cannot succeed)
-    uint32_t *chunk_min;     // [S][N] float bits, or null: per bin the smallest sum of P over a complete chunk (group of chunks: minsum_group) of this call (atomicMin;
-                             // the host presets 0x7f7f7f7f) -- the quiet level of the bin, for the next call's thr_bin (make_bin_thresholds)
+    uint32_t *chunk_min;     // [S][blocks_per_stream][N] float bits (one row per work item, beside psum's), or null: per bin the smallest sum of P over a
+                             // complete chunk (group of chunks: minsum_group) of the item, 0x7f7f7f7f where it holds none -- the quiet level of the bin, for
+                             // the next call's thr_bin (make_bin_thresholds takes the smallest over a stream's items; plain stores: one atomicMin per bin
+                             // and item on a [S][N] array cost the threshold-bit scan 5 %, profiles/r05_c_*)
     const float *thr_bin;    // MODE 6, or null: [S][LG][16] a second, per-bin threshold in lane order; a cell's bit is set only if it passes both
     // LIN instantiations, guard of the detrend by linearity: a stream whose constant offset lies more than 60 dB over its quietest
     // bin's per-sample power is marked (host-visible word); the host analyses the call again with that stream -- and only that
@@ -139,6 +142,26 @@ __device__ __forceinline__ float pick_range(const float (&P)[NP], int r) {
         const float lo = pick_range<LO, CNT / 2>(P, r), hi = pick_range<LO + CNT / 2, CNT / 2>(P, r);
         return (r & (CNT / 2)) ? hi : lo;
     }
+}
+
+// bits * 16 + the four bits !(p3 < t3), !(p2 < t2), !(p1 < t1), !(p0 < t0) (p3's the highest; a NaN power passes, as for the
+// reference's `not (P < thr)`): a compare into a scalar pair and an add-with-carry `bits + bits + carry` per cell -- two vector
+// instructions where compare -> select 0 / 1 -> shift / or takes three.  gfx950 wants two other instructions between a compare
+// and the first reader of its scalar result (hipcc puts `s_nop 1` there): three scalar pairs in rotation provide them.
+__device__ __forceinline__ uint32_t shift_in4(uint32_t bits, float p0, float p1, float p2, float p3, float t0, float t1, float t2, float t3) {
+    unsigned long long m0, m1, m2;
+    asm("v_cmp_nlt_f32_e64 %1, %7, %11\n\t"
+        "v_cmp_nlt_f32_e64 %2, %6, %10\n\t"
+        "v_cmp_nlt_f32_e64 %3, %5, %9\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n\t"
+        "v_cmp_nlt_f32_e64 %1, %4, %8\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %1"
+        : "+v"(bits), "=&s"(m0), "=&s"(m1), "=&s"(m2)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(t0), "v"(t1), "v"(t2), "v"(t3)
+        : "vcc");
+    return bits;
 }
 
 // Append a wave's staged candidate cells to the 16 per-bucket lists of its
@@ -323,6 +346,12 @@ constexpr BinSlot slot_of_bin(int bin) {
     return BinSlot{k1 * R3 + qg, up * R3 + q2};
 }
 
+// diagnostic builds only: timing-only ablations of the threshold-bit scan (MODE 6; wrong results): bit 0 no bit stores, bit 1 no chunk minima,
+// bit 2 no staging of the per-bin thresholds, bit 3 no count of the cells over the absolute threshold
+#ifndef RT_EXP6
+#define RT_EXP6 0
+#endif
+
 // diagnostic builds only (tools/ablate.sh): stop the scan step after stage n, folding the live
 // values into the row sums so nothing upstream is dead code.  0 = full kernel (the product).
 #ifndef RT_ABLATE
@@ -420,6 +449,7 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
 #ifndef RT_NO_PERSIST
 #define RT_NO_PERSIST 0
 #endif
+__device__ __forceinline__ int g_of(unsigned tid, int lg) { return (int)tid / lg; }
 __host__ __device__ constexpr bool scan_persistent(int R3, int mode) { return mode != 5 && mode != 7 && !RT_NO_PERSIST && R3 >= 4; }
 __host__ __device__ constexpr int scan_block(int R3) { return R3 <= RT_ONE_WAVE_MAX_R3 ? 64 : kBlock; }
 
@@ -470,7 +500,14 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // (profiles/r04_a_*).  Up to nperseg 1024, where the table fits beside the rest at three workgroups per CU.
     constexpr bool THR_LDS = (MODE == 6) && R3 <= 4;
     constexpr size_t kThrB = THR_LDS ? sizeof(float) * N : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB];
+    // MODE 6: the threshold bits of four steps are collected per lane group in LDS and leave as ONE 8-byte store per lane (whole
+    // 128-byte lines) instead of a 2-byte store per lane and step: the short stores cost the scan 10 % -- a vector-memory instruction
+    // per step in a kernel whose waves queue for the address path (profiles/r05_c_mode6_ablations.txt: 1 760 -> 1 587 us without
+    // them).  Where a group lives inside one wave and the block still fits three times into a CU's LDS: nperseg <= 512.
+    constexpr bool BITS_LDS = (MODE == 6) && R3 <= 2;
+    constexpr size_t kBitsB = BITS_LDS ? sizeof(uint16_t) * 4 * BLK : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB + kBitsB];
+    uint16_t *const bits_lds = reinterpret_cast<uint16_t *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB) + (BITS_LDS ? g_of(threadIdx.x, LG) * 4 * LG : 0);  // this group's [4 steps][LG]
     float4 *const thr_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB);
     cf *const xch = reinterpret_cast<cf *>(lds_block);
     cf *const red = reinterpret_cast<cf *>(lds_block + kXchB);
@@ -602,7 +639,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     const bool chunk_ok = (MODE == 7) ? (n_mine > 0) : (chunk < p.chunks);
     const int c0 = chunk * p.segs_per_chunk;
     if constexpr (THR_LDS) {
-        if (p.thr_bin) {  // (the previous item's readers are behind the barrier that ended it; this item's first step is behind the next one)
+        if (p.thr_bin && !(RT_EXP6 & 4)) {  // (the previous item's readers are behind the barrier that ended it; this item's first step is behind the next one)
             // max(absolute threshold, the bin's own): `!(P < a) && !(P < b)` is `!(P < max(a, b))`, one test per cell instead of two
             const float thr_abs = p.thr_s ? p.thr_s[s] : p.thr;
             const float4 *src = reinterpret_cast<const float4 *>(p.thr_bin + (int64_t)s * N);  // [lane][q]
@@ -761,6 +798,26 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         }
     };
     request_segment(LISTED ? seg7_cur : c0 + L - i_first);
+    // MODE 6 (BITS_LDS): the threshold bits of steps last - rows + 1 .. last leave the group's LDS rows as one 8-byte store per lane.
+    // In memory the block is segment c0 + L - last (the lowest) and up to three later ones, LG x 2 bytes each: lane j of the group
+    // stores the four 16-bit words of lanes 4 (j % (LG / 4)) .. + 3 of row j / (LG / 4).  Called at the HEAD of a step, ahead of its
+    // loads: vector-memory operations return in order and the step's samples are waited for with everything older, so a store
+    // issued behind the loads (the first version: at the end of every step) made each step wait for its own store's
+    // acknowledgement as well.
+    auto flush_bits = [&](int last, int rows) {
+        if constexpr (BITS_LDS && !(RT_EXP6 & 1)) {
+            wave_sync();
+            int lt_f = lt;
+            asm volatile("" : "+v"(lt_f));
+            const int m = lt_f / (LG / 4), qd = lt_f % (LG / 4);
+            const int sg = c0 + L - last + m;
+            if (chunk_ok && m < rows && sg >= 0 && sg < T) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(bits_lds + ((last - m - 1) & 3) * LG + 4 * qd);
+                *reinterpret_cast<uint2 *>(p.cell_hot + ((int64_t)s * T + sg) * LG + 4 * qd) = v;
+            }
+            wave_sync();  // (the rows are rewritten from this step on)
+        }
+    };
 #ifdef RT_STAMPS
     uint32_t st_acc[kStamps] = {};
     uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -780,6 +837,9 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             v[m] = make_c<C>(x.x, x.y);
         }
         const uint32_t need_seg = need | first_nxt;  // (first_nxt was requested for this step's segment)
+        if constexpr (BITS_LDS) {
+            if (i > 1 && ((i - 1) & 3) == 0) flush_bits(i - 1, 4);
+        }
         // N = 4096: the window comes from L2.  Vector-memory operations return in order, so these loads must be
         // issued BEFORE the next segment's: waiting for them afterwards (`s_waitcnt vmcnt(0)`) would wait for the
         // whole prefetch, i.e. expose an HBM round trip in every step (it did: 1.01 ms per launch).
@@ -1092,13 +1152,21 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             // common path, the per-cell tests only where that fires.  (A NaN cell means the whole
             // segment is NaN -- the mean is -- so the max is NaN and `!(m < thr)` holds, as for the
             // reference's `not (P < thr)`.)
-            float mx = __builtin_fmaxf(__builtin_fmaxf(P[0], P[1]), P[2]);
+            // (MODE 6 with staged thresholds: the bits of the absolute threshold alone are built in the items that need them and in one
+            // step of eight elsewhere -- by step number, the same for the whole workgroup, so that seven steps of eight skip the block,
+            // and with a phase that turns from chunk to chunk: a pulse train whose period is a multiple of eight hops cannot hide from
+            // the count or fill it)
+            const bool sampled_abs = THR_LDS && !item_hot && p.abs_hot && (i & 7) == 0 && !halo;  // (see item_hot)
+            const bool want_hot = item_hot || sampled_abs;  // wave-uniform
+            float mx = 0.f;
+            if (want_hot) {
+                mx = __builtin_fmaxf(__builtin_fmaxf(P[0], P[1]), P[2]);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, P[r]), P[r + 1]);
-            mx = __builtin_fmaxf(mx, P[15]);
+                for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, P[r]), P[r + 1]);
+                mx = __builtin_fmaxf(mx, P[15]);
+            }
             uint32_t hot = 0;
-            const bool sampled_abs = THR_LDS && !item_hot && p.abs_hot && (seg & 7) == 0 && !halo;  // (see item_hot)
-            if (active && !(mx < thr) && (item_hot || sampled_abs)) {
+            if (active && want_hot && !(mx < thr)) {
                 // bit r = !(P[r] < thr), built by shifting (v_lshl_or_b32): `hot |= 1u << r` made hipcc keep the nine
                 // literals 128 .. 32768 in VGPRs across the whole step loop (a select cannot take a literal on gfx9)
 #pragma unroll
@@ -1108,22 +1176,21 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 // pre-filter bits: every cell of the chunk so far at or above the threshold; the run through t = 0
                 // (it may continue a run of the previous buffer) counts whatever its length
                 if constexpr (MODE == 6) {
-                    if (active && !halo) {  // (lane index opaque: the address stays out of the loop's registers)
-                        int lt_b = lt;
-                        asm volatile("" : "+v"(lt_b));
-                        uint32_t bits = hot;
+                    uint32_t bits = 0;
+                    int lt_b = lt;  // (lane index opaque: the addresses stay out of the loop's registers)
+                    asm volatile("" : "+v"(lt_b));
+                    if (active && !halo) {
+                        bits = hot;
                         if (THR_LDS && p.thr_bin) {
                             // (the staged table holds max(absolute threshold, the bin's own): the one test)
+                            // Every cell, every step, no look at the lane's maximum first: this level runs where the noise passes the
+                            // absolute threshold in nearly every lane (on clean input the sparse level does the work), so the maximum
+                            // only cost its fifteen instructions.
                             bits = 0;
-                            if (!(mx < thr)) {
 #pragma unroll
-                                for (int q = 3; q >= 0; --q) {
-                                    const float4 t4 = thr_lds[q * LG + lt_b];
-                                    bits = (bits << 1) | ((P[4 * q + 3] < t4.w) ? 0u : 1u);
-                                    bits = (bits << 1) | ((P[4 * q + 2] < t4.z) ? 0u : 1u);
-                                    bits = (bits << 1) | ((P[4 * q + 1] < t4.y) ? 0u : 1u);
-                                    bits = (bits << 1) | ((P[4 * q + 0] < t4.x) ? 0u : 1u);
-                                }
+                            for (int q = 3; q >= 0; --q) {
+                                const float4 t4 = thr_lds[q * LG + lt_b];
+                                bits = shift_in4(bits, P[4 * q + 0], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3], t4.x, t4.y, t4.z, t4.w);
                             }
                         } else if (p.thr_bin && bits) {
                             // the bin's own second threshold (a lower bound of snr * row mean, see make_bin_thresholds):
@@ -1140,7 +1207,12 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                             }
                             bits &= ok;
                         }
-                        p.cell_hot[((int64_t)s * T + seg) * LG + lt_b] = (uint16_t)bits;
+                        if constexpr (!BITS_LDS && !(RT_EXP6 & 1)) p.cell_hot[((int64_t)s * T + seg) * LG + lt_b] = (uint16_t)bits;
+                    }
+                    if constexpr (BITS_LDS && !(RT_EXP6 & 1)) {
+                        // steps 1 .. L (no halo step in this mode): slot (i - 1) & 3
+                        // (the rows leave at the head of the step after their fourth, just ahead of that step's loads: flush_bits)
+                        bits_lds[((i - 1) & 3) * LG + lt_b] = (uint16_t)bits;
                     }
                 }
                 if (active && !halo) {
@@ -1252,11 +1324,12 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     if constexpr (EMIT) {
         if (stg_n) flush_stage(p, s, stg, stg_n);
     }
+    if constexpr (BITS_LDS) flush_bits(n_steps, ((n_steps - 1) & 3) + 1);  // (the chunk's last one to four steps)
     if constexpr (FLAGS) {
         if (p.full && chunk_ok) p.full[((int64_t)s * p.chunks + chunk) * LG + lt] = (uint16_t)(allhot & 0xFFFFu);
     }
     if constexpr (MODE == 4 || MODE == 6) {
-        if (p.abs_hot) {  // (once per item)
+        if (p.abs_hot && !(RT_EXP6 & 8)) {  // (once per item)
             uint32_t n = n_abs;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
@@ -1305,9 +1378,9 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
             for (int gg = 0; gg < GPW; ++gg) sum += part[gg * N + bin];
             dst[bin] = sum;
-            if (p.chunk_min) {
-                // the quietest complete run of >= 32 segments of the bin so far: a chunk, or a group of consecutive chunks
-                // where chunks are shorter (rt_core.h: minsum_group; positive floats order like their bits)
+            if (p.chunk_min && !(RT_EXP6 & 2)) {
+                // the quietest complete run of >= 32 segments of the bin in this item: a chunk, or a group of consecutive chunks
+                // where chunks are shorter (rt_core.h: minsum_group)
                 const int grp = minsum_group(L, GPW);
                 float mn = 3.0e38f, run = 0.f;
                 bool whole = true;
@@ -1322,7 +1395,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                         whole = true;
                     }
                 }
-                if (mn < 3.0e38f) atomicMin(&p.chunk_min[(int64_t)s * N + bin], __float_as_uint(mn));
+                p.chunk_min[((int64_t)s * p.blocks_per_stream + cb) * N + bin] = (mn < 3.0e38f) ? __float_as_uint(mn) : 0x7f7f7f7fu;
             }
         }
     }
@@ -1581,16 +1654,18 @@ __device__ __forceinline__ int lane_order_bin(int R3, int j) {
 // buffer's row mean), which check_bin_thresholds verifies after the scan; a stream that fails it (its floor dropped by
 // more than ~2.5 dB from one buffer to the next) is analysed again (rt_fetch: a few streams dense, else the call on its own
 // row means).  No estimate (first call, buffers shorter than a chunk): theta = 0, the bits are the absolute threshold's alone.
-__global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk_min_prev, float *thr_bin /* lane order */, float *thr_nat /* [S][N] */,
-                                                          int n_streams, int R3, int L, float snr) {
-    const int N = 256 * R3, LG = 16 * R3;
+__global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk_min_prev /* [S][prev_items][N] */, int prev_items, float *thr_bin /* lane order */,
+                                                          float *thr_nat /* [S][N] */, int n_streams, int R3, int L, float snr) {
+    const int N = 256 * R3;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [S][LG][16]
     if (i >= (int64_t)n_streams * N) return;
     const int s = (int)(i / N);
     const int bin = lane_order_bin(R3, (int)(i % N));
     float th = 0.f;
     if (chunk_min_prev) {
-        const float mn = __uint_as_float(chunk_min_prev[(int64_t)s * N + bin]);
+        uint32_t m = 0x7f7f7f7fu;  // (positive floats order like their bits)
+        for (int c = 0; c < prev_items; ++c) m = min(m, chunk_min_prev[((int64_t)s * prev_items + c) * N + bin]);
+        const float mn = __uint_as_float(m);
         if (mn < 1.0e38f && mn == mn) th = snr * minsum_margin(L) * (mn / (float)L);
     }
     thr_bin[i] = th;
@@ -1621,6 +1696,41 @@ __global__ __launch_bounds__(256) void make_bin_thresholds_from_means(const floa
 __global__ __launch_bounds__(256) void check_bin_thresholds(const float *thr_nat, const float *psum, int n_streams, int N, int items_per_stream, int n_seg,
                                                            float snr, int32_t *stream_overflow, unsigned long long *counters, unsigned long long flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n_streams * N) return;
+    const float th = thr_nat[i];
+    if (!(th > 0.f)) return;
+    const int s = (int)(i / N), bin = (int)(i % N);
+    double sum = 0.0;
+    for (int c = 0; c < items_per_stream; ++c) sum += (double)psum[((int64_t)s * items_per_stream + c) * N + bin];
+    const float avg = (float)sum / (float)n_seg;
+    if (!(th <= snr * avg * (1.0f - 1.0e-6f))) {
+        stream_overflow[s] = 1;
+        atomicOr(counters + 2, flag);
+    }
+}
+
+// What stands between the exact pre-filter's first scan and its planning kernel, in ONE launch (round 5; before: max_abs_hot,
+// check_bin_thresholds and a memset, three launches of 5 - 8 us with their gaps on a stream that has nothing else to do):
+// the check above for every (stream, bin); the segment counters of the planner back to zero (words 0 .. n_streams of
+// `seg_count`); and, by workgroup 0, max_abs_hot's job.
+__global__ __launch_bounds__(256) void after_bit_scan(uint32_t *abs_hot, uint32_t *host_max, const float *thr_nat, const float *psum, int n_streams, int N,
+                                                     int items_per_stream, int n_seg, float snr, int32_t *stream_overflow, unsigned long long *counters,
+                                                     unsigned long long flag, int32_t *seg_count) {
+    __shared__ uint32_t wave_max[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i <= n_streams) seg_count[i] = 0;
+    if (blockIdx.x == 0) {
+        uint32_t m = 0;
+        for (int s = threadIdx.x; s < n_streams; s += 256) {
+            m = max(m, abs_hot[s]);
+            abs_hot[s] = 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) *host_max = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    }
     if (i >= (int64_t)n_streams * N) return;
     const float th = thr_nat[i];
     if (!(th > 0.f)) return;
@@ -1679,6 +1789,8 @@ struct DetectArgs {
     int32_t *stream_overflow;  // [S] (host-visible) set for a stream one of whose candidate lists overflowed
     int32_t *stream_incons;    // [S] (host-visible) set for a stream in which a run lacked its preceding cell: an internal error,
                                //     unless the stream overflowed (the scan stops emitting for such a stream, its other lists are torn)
+    const int32_t *seg_total;  // null, or the device word holding the number of segments the exact pre-filter's planner listed over the batch ...
+    int32_t *host_seg_total;   // ... and the pinned host word the call's last finalize_records workgroup copies it to (how selective the level was: AUTO)
     int32_t filtered;          // the candidate lists come from the run-length pre-filter (stft_scan MODE 5): a run whose
                                //     preceding cell is missing lies across the edge of the emitted chunks, is too short
                                //     to pass the duration gate and is dropped (without the filter that is an internal error)
@@ -2461,6 +2573,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
             a.host_counters[1] = __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.host_counters[2] = flags;
             a.host_counters[3] = (unsigned long long)gridDim.x;
+            if (a.seg_total) *a.host_seg_total = __hip_atomic_load(a.seg_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < 4; ++i) __hip_atomic_store(&a.counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

@@ -655,11 +655,12 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                 const rsrc_t rp = make_rsrc(p.psum + ((int64_t)s * p.blocks_per_stream + chunk) * N, (uint32_t)(N * sizeof(float)));
 #pragma unroll
                 for (int r = 0; r < 64; ++r) raw_buffer_store_f1(acc[r], rp, lane * 4, 256 * r, 0);
-                if (p.chunk_min && c_len == L && (c0 + L <= T)) {
-                    // the quietest complete chunk of the bin so far (positive floats order like their bits): make_bin_thresholds
-                    uint32_t *cm = p.chunk_min + (int64_t)s * N + lane;
+                if (p.chunk_min) {
+                    // the item's row of chunk minima (StftParams::chunk_min): this chunk's sums where it is a complete one of full length
+                    const bool whole = c_len == L && (c0 + L <= T);
+                    const rsrc_t rm = make_rsrc(p.chunk_min + ((int64_t)s * p.blocks_per_stream + chunk) * N, (uint32_t)(N * sizeof(float)));
 #pragma unroll
-                    for (int r = 0; r < 64; ++r) atomicMin(cm + 64 * r, __float_as_uint(acc[r]));
+                    for (int r = 0; r < 64; ++r) raw_buffer_store_f1(whole ? acc[r] : __uint_as_float(0x7f7f7f7fu), rm, lane * 4, 256 * r, 0);
                 }
             }
         } while (false);

@@ -125,3 +125,27 @@ def test_bench_refuses_more_gpus_than_the_box_has_within_seconds():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env, cwd=REPO)
     assert r.returncode != 0 and time.monotonic() - t0 < 60
     assert "GPU(s)" in r.stderr and not r.stdout.strip()
+
+
+def test_product_library_has_no_laboratory_hooks():
+    """The shipped library never consults the environment and carries none of the laboratory's switch names (VERDICT round 4,
+    item 7): csrc/rt_diag.h turns RT_DIAG_ENV into a null pointer unless the build has -DRT_DIAG, and refuses -D switches of
+    the laboratory in a product build."""
+    import subprocess
+
+    from pyradiotracking_amd import build
+
+    with open(build.LIB, "rb") as f:
+        blob = f.read()
+    for name in (b"RT_TEST_FAIL_LANE", b"RT_EXP_", b"RT_STAMPS", b"RT_ABLATE"):
+        assert name not in blob, name
+    nm = subprocess.run(["nm", "-D", build.LIB], capture_output=True, text=True)
+    assert nm.returncode == 0 and "getenv" not in nm.stdout
+    hdr = os.path.join(build.CSRC, "rt_diag.h")
+    ok = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", hdr], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    for switch in ("-DRT_STAMPS", "-DRT_ABLATE=3", "-DRT_EXP_NOBAR1", "-DRT_WAVE64_4096=0", "-DRT_PK_MAX_R3=0"):
+        bad = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", switch, hdr], capture_output=True, text=True)
+        assert bad.returncode != 0 and "laboratory switch" in bad.stderr, switch
+        lab = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-DRT_DIAG", switch, hdr], capture_output=True, text=True)
+        assert lab.returncode == 0, lab.stderr

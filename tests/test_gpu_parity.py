@@ -1707,38 +1707,72 @@ def test_lanes_stay_in_step_after_a_sparse_overflow_in_one_lane():
     assert got[got["stream"] >= 2].tobytes() == want2[want2["stream"] >= 2].tobytes()
 
 
-def test_lanes_stay_in_step_when_a_later_lane_refuses_an_enqueue(monkeypatch):
+_FAULT_INJECTION_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["RT_REPO"])
+from oracle import analyze_oracle as oracle
+from pyradiotracking_amd import _native, synth
+from pyradiotracking_amd.analyze import BatchSignalAnalyzer
+
+fs, nperseg, blen, S = 2048000, 256, 600 * 256, 4
+w = oracle.window_coefficients("hamming", nperseg)
+rng = np.random.default_rng(33)
+bufs = [np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 4, dur_ms=(9, 14), keep_clear_tail=0)), 500 + 10 * k + s)
+                  for s in range(S)]) for k in range(4)]
+make = lambda: BatchSignalAnalyzer([str(i) for i in range(S)], sdr_callback_length=blen, gpu=0, mode="sparse", lanes=2, sample_rate=fs)
+os.environ.pop("RT_TEST_FAIL_LANE", None)
+ref = make()
+want = {}
+for k in (0, 1, 3):  # the refused call (buffer 2) never happened
+    ref.enqueue(bufs[k])
+    want[k] = ref.fetch_records()
+os.environ["RT_TEST_FAIL_LANE"] = "1:3"  # (read once, when the handle is created: its lane 1 refuses its third enqueue)
+b = make()
+del os.environ["RT_TEST_FAIL_LANE"]
+b.enqueue(bufs[0])
+b.enqueue(bufs[1])
+try:
+    b.enqueue(bufs[2])
+    raise SystemExit("the third enqueue was not refused: is this the diagnostic library?")
+except _native.NativeError as e:
+    assert e.code == _native.RT_E_NOMEM, e
+assert b.fetch_records().tobytes() == want[1].tobytes()  # the one call both lanes still hold
+try:
+    b.fetch_records()  # nothing else is pending, in either lane
+    raise SystemExit("a call was still pending")
+except _native.NativeError:
+    pass
+b.enqueue(bufs[3])
+assert b.fetch_records().tobytes() == want[3].tobytes()  # look-back from buffer 1, as in the reference run
+assert len(want[1]) > 0 and len(want[3]) > 0
+print("fault injection ok")
+"""
+
+
+def test_lanes_stay_in_step_when_a_later_lane_refuses_an_enqueue():
     """Three rt_process calls without a fetch, the third refused by the SECOND lane (fault injection,
     RT_TEST_FAIL_LANE): the call the third one would have overwritten (the first, never fetched) is dropped in every lane
     before any lane starts, the first lane's new call is rolled back -- both lanes are left holding exactly the second
     call, the look-back state is the one after it, and the next buffer is analysed as if the refused call had never
-    been made (advisor finding, round 2: the lanes before the failing one had lost the old call, the others kept it)."""
+    been made (advisor finding, round 2: the lanes before the failing one had lost the old call, the others kept it).
+    The hook exists only in the DIAGNOSTIC build of the library (csrc/rt_diag.h; the product never reads the
+    environment), so the scenario runs in a child process that loads librt_analyze_diag.so."""
     _need_gpu()
-    fs, nperseg, blen, S = 2048000, 256, 600 * 256, 4
-    w = oracle.window_coefficients("hamming", nperseg)
-    rng = np.random.default_rng(33)
-    kw = dict(sample_rate=fs)
-    bufs = [np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 4, dur_ms=(9, 14), keep_clear_tail=0)), 500 + 10 * k + s)
-                      for s in range(S)]) for k in range(4)]
-    ref = _batch_for(kw, S, blen, "sparse", lanes=2)
-    want = {}
-    for k in (0, 1, 3):  # the refused call (buffer 2) never happened
-        ref.enqueue(bufs[k])
-        want[k] = ref.fetch_records()
-    monkeypatch.setenv("RT_TEST_FAIL_LANE", "1:3")  # (read once, when the handle is created: its lane 1 refuses its third enqueue)
-    b = _batch_for(kw, S, blen, "sparse", lanes=2)
-    monkeypatch.delenv("RT_TEST_FAIL_LANE")
-    b.enqueue(bufs[0])
-    b.enqueue(bufs[1])
-    with pytest.raises(_native.NativeError) as e:
-        b.enqueue(bufs[2])
-    assert e.value.code == _native.RT_E_NOMEM
-    assert b.fetch_records().tobytes() == want[1].tobytes()  # the one call both lanes still hold
-    with pytest.raises(_native.NativeError):
-        b.fetch_records()  # nothing else is pending, in either lane
-    b.enqueue(bufs[3])
-    assert b.fetch_records().tobytes() == want[3].tobytes()  # look-back from buffer 1, as in the reference run
-    assert len(want[1]) > 0 and len(want[3]) > 0
+    import subprocess
+    import sys
+
+    from pyradiotracking_amd import build
+
+    if not os.path.exists(build.LIB_DIAG):
+        build.build_library(diag=True)
+    env = dict(os.environ, RT_ANALYZE_LIB=build.LIB_DIAG, RT_REPO=build.REPO)
+    r = subprocess.run([sys.executable, "-c", _FAULT_INJECTION_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=build.REPO)
+    assert r.returncode == 0 and "fault injection ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    # ... and the product library has no such hook: not even the variable's name
+    with open(build.LIB, "rb") as f:
+        blob = f.read()
+    assert b"RT_TEST_FAIL_LANE" not in blob and b"RT_EXP_" not in blob and b"RT_STAMPS" not in blob
 
 
 def test_lanes_stay_in_step_after_a_fetch_with_a_short_buffer():
