@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "rt_kernels.h"
+#include "rt_general.h"
 
 using namespace rt;
 
@@ -122,6 +123,9 @@ struct rt_handle {
     hipStream_t s_detect = nullptr;  // the sparse detection's own (lower-priority) stream where the handle owns its streams, else = s_scan
     std::string err;
 
+    bool general = false;      // nperseg is a power of two the fused scans do not cover: stft_general + detect_dense (rt_general.h), dense path only
+    int log2n = 8;
+    cf *d_twg = nullptr;       // ... its twiddles W_N^m, m < N / 2
     int n_cu = 256;            // compute units of the device (the scan's grid: launch_stft_lin)
     uint32_t *d_work = nullptr;  // the scan kernels' item counters (StftParams::work), zero between launches
     float *d_window = nullptr;
@@ -267,6 +271,27 @@ void launch_stft(rt_handle *h, const StftParams &p, int blocks, hipStream_t st) 
     } else {
         launch_stft_lin<MODE, U8, false>(h, p, blocks, st);
     }
+}
+
+// the general transform (rt_general.h): the dense spectrogram of a power-of-two nperseg the fused scans do not cover
+void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_seg, float *spec, float *tail, bool u8) {
+    GeneralParams g{};
+    g.iq = iq;
+    g.stream_stride = stream_stride;
+    g.n_streams = h->cfg.n_streams;
+    g.n_seg = n_seg;
+    g.nperseg = h->N;
+    g.log2n = h->log2n;
+    g.segs_per_block = std::max(1, 512 / h->N);
+    g.tail_cols = h->K;
+    g.window = h->d_window;
+    g.tw = h->d_twg;
+    g.spec = spec;
+    g.tail = tail;
+    const int blocks = h->cfg.n_streams * ((n_seg + g.segs_per_block - 1) / g.segs_per_block);
+    const size_t lds = (size_t)g.segs_per_block * h->N * sizeof(cf);
+    if (u8) hipLaunchKernelGGL(stft_general<true>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+    else hipLaunchKernelGGL(stft_general<false>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
 }
 
 // cells a run must have to pass the duration gate unless it runs through t = 0 (see rt_create)
@@ -485,6 +510,25 @@ void launch_scan(rt_handle *h, const StftParams &sp, int blocks, bool u8, hipStr
 int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr, bool second_pass_only = false, bool own_means = false) {
     const CallCtx &c = sl.call;
     if (launched) *launched = false;
+    if (h->general) {
+        // any other power-of-two nperseg: the general transform into the dense map, then the dense extractor (which sums the rows itself)
+        int rc = ensure_dense_spec(h);
+        if (rc != RT_OK) return rc;
+        RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
+        if (launched) *launched = true;
+        launch_general(h, c.iq, c.stream_stride, c.n_seg, h->d_spec, h->d_tail[c.tail_write], c.u8);
+        RT_HIP(h, hipGetLastError());
+        RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
+        DetectArgs a = make_detect_args(h, sl, c.n_seg, h->N, c.n_seg_last);
+        a.prev = h->d_tail[c.tail_read];
+        a.prev_cols = h->K;
+        a.spec = h->d_spec;
+        a.psum = nullptr;
+        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
+        RT_HIP(h, hipGetLastError());
+        RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
+        return RT_OK;
+    }
     StftParams sp = make_stft_params(h, sl, c.iq, c.stream_stride, c.n_seg, c.tail_write);
     if (sp.chunks > h->max_chunks) {
         h->err = "internal: chunk count exceeds scratch";
@@ -869,6 +913,7 @@ void rt_destroy(rt_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_work);
+    (void)hipFree(h->d_twg);
     (void)hipFree(h->d_window);
     (void)hipFree(h->d_window_t);
     (void)hipFree(h->d_sub_first);
@@ -931,8 +976,19 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     int R3 = 0;
     for (int r : {1, 2, 4, 8, 16})
         if (cfg->nperseg == 256 * r) R3 = r;
-    if (!R3) return fail_create(RT_E_UNSUPPORTED, "nperseg must be one of 256, 512, 1024, 2048, 4096");
+    bool general = false;
+    if (!R3) {
+        // any other power of two from 8 to 16 384: the general transform on the dense path (rt_general.h)
+        const int n = cfg->nperseg;
+        if (n < 8 || n > kGeneralMaxN || (n & (n - 1)) != 0)
+            return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(n) + " is not supported: it must be a power of two from 8 to 16384 (256 ... 4096 run the "
+                                                 "fused scan kernels, the other powers of two a general transform on the dense path); the reference accepts any integer");
+        general = true;
+        R3 = 1;  // (sizes the scratch the general path does not use)
+    }
     if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_RUNFILTER) return fail_create(RT_E_INVALID, "bad mode");
+    if (general && cfg->mode != RT_MODE_AUTO && cfg->mode != RT_MODE_DENSE)
+        return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(cfg->nperseg) + " runs on the dense path only: mode must be RT_MODE_AUTO or RT_MODE_DENSE");
     if (cfg->lanes > 1 && cfg->n_streams > 1) {
         // stream groups on their own handles and HIP streams: the detection kernels, launch gaps and last
         // workgroup round of one group overlap the scan of another
@@ -981,6 +1037,12 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->R3 = R3;
+    h->general = general;
+    if (general) {
+        h->cfg.mode = RT_MODE_DENSE;
+        h->log2n = 0;
+        while ((1 << h->log2n) < cfg->nperseg) ++h->log2n;
+    }
     h->N = cfg->nperseg;
     h->LG = 16 * R3;
     h->GPW = scan_block(R3) / h->LG;
@@ -1003,7 +1065,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         // else holds -- (len + 1) * hop < signal_min_duration (analyze.py:427-430; rt_core.h: gate_run), with a margin of
         // 1e-9 for the rounding of the float64 expressions.  A run of >= 2 L - 1 cells covers an aligned chunk of L.
         const long long r_min = min_run_cells(h);
-        h->prefilter_ok = h->L >= 4 && 2ll * h->L - 1 <= r_min && h->max_seg >= 2 * h->L &&
+        h->prefilter_ok = !general && h->L >= 4 && 2ll * h->L - 1 <= r_min && h->max_seg >= 2 * h->L &&
                           h->max_chunks <= (1 << 18);  // (plan_pass_b keeps a bit per chunk in LDS)
         if (cfg->mode == RT_MODE_PREFILTER && !h->prefilter_ok) {
             delete h;
@@ -1020,7 +1082,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         // Exact run-length pre-filter: any chunk length, any plateau length the planner's counters hold (rt_kernels.h: plan_runs).
         // Built where it is asked for, and in AUTO mode.
         h->run_cells = (int)std::max<long long>(1, std::min<long long>(r_min, 1 << 20));
-        const bool fits = std::min<long long>(h->run_cells, (long long)h->max_seg + 1) <= kPlanMaxRun && h->max_seg >= 2;
+        const bool fits = !general && std::min<long long>(h->run_cells, (long long)h->max_seg + 1) <= kPlanMaxRun && h->max_seg >= 2;
         if (cfg->mode == RT_MODE_RUNFILTER && !fits) {
             delete h;
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length (in STFT hops) is beyond the planner's counters");
@@ -1037,14 +1099,15 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)kSlots * per_slot > free_b / (h->prefilter_ok ? 8 : 2)) h->runfilter_ok = false;
         }
     }
-    if (((long long)h->N << key_tbits(std::max(h->max_seg, 2))) > 0x100000000ll) {
+    if (!general && ((long long)h->N << key_tbits(std::max(h->max_seg, 2))) > 0x100000000ll) {
         delete h;
         return fail_create(RT_E_UNSUPPORTED, "max_samples too large for 32-bit cell keys");
     }
     // candidate cells per (stream, bucket): by default a full row of one bin fits, times nperseg / 1024 -- a bucket
     // holds nperseg / 16 bins, and with 256 of them (nperseg 4096) a dozen tags per stream put several active
     // bins into one bucket (config 5: up to ~1000 cells per bucket at 781 segments)
-    h->hot_cap = cfg->hot_capacity > 0
+    h->hot_cap = general ? 64  // (no candidate lists on the dense path: the smallest scratch)
+                 : cfg->hot_capacity > 0
                      ? cfg->hot_capacity
                      : std::min(8192, std::max(kSmallBucket, next_pow2(std::max(h->max_seg, 1)) * std::max(1, h->N / 1024)));
     h->lds_dense = rec_lds_bytes(h->rec_cap);
@@ -1103,6 +1166,17 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
 
     const int S = cfg->n_streams, N = h->N, LG = h->LG;
     h->reset_pending.assign((size_t)S, 0);
+    if (general) {
+        std::vector<cf> twg((size_t)N / 2);
+        for (int m = 0; m < N / 2; ++m) {
+            const double ang = -6.283185307179586476925286766559 * (double)m / (double)N;
+            twg[(size_t)m] = cf{(float)std::cos(ang), (float)std::sin(ang)};
+        }
+        RT_CREATE_HIP(hipMalloc(&h->d_twg, sizeof(cf) * twg.size()));
+        RT_CREATE_HIP(hipMemcpy(h->d_twg, twg.data(), sizeof(cf) * twg.size(), hipMemcpyHostToDevice));
+        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
+        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
+    }
     // window and twiddle tables (twiddles in double, rounded once to float32)
     std::vector<cf> tw1((size_t)LG * 16), tw2((size_t)R3 * 16);
     const double two_pi = 6.283185307179586476925286766559;
@@ -1922,6 +1996,12 @@ int rt_spectrogram(rt_handle *h, const void *iq_dev, int64_t n_samples, int64_t 
     const int T = (int)(n_samples / h->N);
     if (T == 0) return RT_OK;
     RT_HIP(h, hipDeviceSynchronize());
+    if (h->general) {
+        launch_general(h, iq_dev, stream_stride, T, spec_dev, nullptr, false);
+        RT_HIP(h, hipGetLastError());
+        RT_HIP(h, hipStreamSynchronize(h->s_scan));
+        return RT_OK;
+    }
     StftParams sp = make_stft_params(h, h->slot[0], iq_dev, stream_stride, T, 0);
     sp.spec = spec_dev;
     launch_stft<2>(h, sp, h->cfg.n_streams * sp.blocks_per_stream, h->s_scan);
@@ -1943,6 +2023,10 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
     const int T = (int)(n_samples / h->N);
+    if (h->general) {
+        h->err = "rt_calibrate_read: the load stream of the fused scans only (nperseg 256 ... 4096)";
+        return RT_E_UNSUPPORTED;
+    }
     if (T < 2) return RT_OK;
     RT_HIP(h, hipDeviceSynchronize());
     StftParams sp = make_stft_params(h, h->slot[0], iq_dev, stream_stride, T, 0);
