@@ -203,9 +203,9 @@ def scan_kernel_sha256(lib_path=None, symbol=SCAN_KERNEL_SYMBOL):
     return None
 
 
-def pmc_traffic(default_workload, lanes):
-    """HBM bytes per scan launch from the committed PMC passes -- only for the exact workload and the exact kernel
-    sources they were measured on; otherwise null with the reason."""
+def pmc_traffic(default_workload, lanes, segs_per_chunk=None):
+    """HBM bytes per scan launch from the committed PMC passes -- only for the exact workload, the exact kernel
+    machine code and the launch geometry (segments per chunk) they were measured on; otherwise null with the reason."""
     if not default_workload:
         return None, "PMC traffic is only on file for the default workload"
     try:
@@ -216,6 +216,9 @@ def pmc_traffic(default_workload, lanes):
     have = scan_kernel_sha256()
     if have is None or doc.get("scan_kernel_sha256") != have:
         return None, "the scan kernel's machine code differs from the one profiles/pmc_traffic.json was measured on (run tools/profile_round.sh)"
+    if doc.get("segs_per_chunk") is not None and segs_per_chunk is not None and int(doc["segs_per_chunk"]) != int(segs_per_chunk):
+        return None, (f"this run's chunk length ({segs_per_chunk} segments) differs from the one profiles/pmc_traffic.json was measured with "
+                      f"({doc['segs_per_chunk']}): host-side launch geometry changes bytes per launch (run tools/profile_round.sh)")
     return int(doc["bytes_per_launch_256_streams"]) // lanes, "bytes/launch: PMC FETCH_SIZE (calibrated on the kernel's own load stream) + WRITE_SIZE on one 256-stream launch; " + doc.get("source", "profiles/pmc_traffic.json")
 
 
@@ -508,7 +511,7 @@ def main():
 
     default_workload = (wl["name"], S, args.segs_per_chunk, args.mode, args.input, args.threshold_dbw, args.noise_dbw, args.hot_capacity) == ("config2", 256, 0, "auto", "c64", None, None, 0)
     n_dense_streams = int(info.n_dense_streams)
-    traffic, traffic_note = pmc_traffic(default_workload, 1)  # per launch over all 256 streams, like kernel_ms
+    traffic, traffic_note = pmc_traffic(default_workload, 1, int(getattr(info, "segs_per_chunk", 0)) or None)  # per launch over all 256 streams, like kernel_ms
 
     # parity + CPU baseline (untimed).  N = 1: the oracle on the host cores over a bounded sample (the baseline) and the
     # records of >= 16 sampled streams against it; N > 1: every rank checks the first and last stream of its shard.

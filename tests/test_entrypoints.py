@@ -108,6 +108,11 @@ def test_pmc_traffic_is_only_quoted_for_the_kernel_it_was_measured_on(tmp_path, 
     f.write_text(json.dumps({"scan_kernel_sha256": have, "bytes_per_launch_256_streams": 4456600000}))
     assert bench.pmc_traffic(True, 2)[0] == 2228300000
     assert bench.pmc_traffic(False, 2)[0] is None  # another workload
+    # ... and host-side launch geometry is part of the key (advisor, round 4): another chunk length, another byte count
+    f.write_text(json.dumps({"scan_kernel_sha256": have, "bytes_per_launch_256_streams": 4456600000, "segs_per_chunk": 32}))
+    assert bench.pmc_traffic(True, 2, 32)[0] == 2228300000
+    got, why = bench.pmc_traffic(True, 2, 25)
+    assert got is None and "chunk length" in why
 
 
 def test_bench_refuses_more_gpus_than_the_box_has_within_seconds():

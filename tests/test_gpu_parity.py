@@ -853,7 +853,26 @@ def test_pinned_deviation_std_of_a_plateau_holding_a_round_off_cell(wire):
             if np.isnan(float(v.std)):
                 assert np.isnan(float(g.std)), (mode, v.fi)
             elif holds_round_off and v.fi not in (ka - 1, ka, ka + 1):
-                assert np.isfinite(float(g.std)) and float(g.std) > 40.0  # the one unbounded figure: tens of dB either way (finite here: with noise in the input the cell is not exactly zero; the exact-zero case: the next test)
+                # The one figure without a 0.1 dB bound against the reference -- but not without ANY bound (round 5): the plateau's
+                # first cell is the transform's round-off under the strong tone of its segment, and how far under is a property of
+                # the kernels that must not regress.  (a) that cell, in the kernels' own spectrogram, lies >= 120 dB under the
+                # segment's strongest bin (SciPy's float32 transform: ~130; a float64 transform of the same samples: the noise,
+                # ~190); (b) `std` is the population std of the dB of the kernels' own two cells, to 0.01 dB; (c) and so it lies
+                # between what a cell exactly 120 dB under the tone would give and what the float64 transform's cell gives.
+                assert np.isfinite(float(g.std))
+                if v.fi == kb:
+                    own = _gpu_spectrogram(x, fs, nperseg, window)[0]                     # [T, F], the scan's transform
+                    _, _, sp64 = oracle.stft_power(x.astype(np.complex128), fs, window, nperseg)  # [F, T] float64
+                    strong = float(sp64[ka, t - 1])
+                    cell, nxt = float(own[t - 1, kb]), float(own[t, kb])
+                    assert 0.0 < cell <= strong * 1e-12, (mode, cell / strong)
+                    own_std = float(np.std(10 * np.log10(np.array([cell, nxt], dtype=np.float64))))
+                    assert abs(float(g.std) - own_std) < STD_TOL_DB, (mode, float(g.std), own_std)
+                    std_f64 = float(np.std(10 * np.log10(np.array([float(sp64[kb, t - 1]), float(sp64[kb, t])]))))
+                    std_floor = float(np.std(10 * np.log10(np.array([strong * 1e-12, float(sp64[kb, t])]))))
+                    assert std_floor - 0.1 <= float(g.std) <= std_f64 + 0.1, (mode, std_floor, float(g.std), std_f64)
+                else:
+                    assert float(g.std) > 40.0
             else:
                 assert abs(float(g.std) - float(v.std)) < STD_TOL_DB, (mode, v.fi)
         b.close()

@@ -48,6 +48,11 @@ def main():
         "workload": f"config2: {exact['streams']} streams x {exact['segments'] * exact['nperseg']} samples, nperseg {exact['nperseg']}, one launch",
         "scan_kernel": "rt::stft_scan<1, 0, false, true>",
         "scan_kernel_sha256": bench.scan_kernel_sha256(),
+        # host-side launch geometry changes bytes per launch too (chunk length -> halo segments and workgroups): the bench compares
+        # these with what its own handle reports (rt_call_info.segs_per_chunk) besides the machine-code hash
+        "segs_per_chunk": exact.get("segs_per_chunk"),
+        "streams": exact["streams"],
+        "segments": exact["segments"],
         "bytes_per_launch_256_streams": int(round(read_b + write_b)),
         "read_bytes": int(round(read_b)),
         "write_bytes": int(round(write_b)),

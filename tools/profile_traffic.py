@@ -55,7 +55,7 @@ def main():
         rec = an.fetch_records()
         n_hot, n_rec = an.native.call_info().n_hot, len(rec)
     T = blen // nperseg
-    L = 32  # default segs_per_chunk for this size
+    L = int(an.native.call_info().segs_per_chunk)  # the handle's own choice (rt_call_info): part of what the traffic figure is keyed on
     print(json.dumps({
         "streams": S, "segments": T, "nperseg": nperseg, "segs_per_chunk": L,
         "algorithmic_bytes": S * T * nperseg * 8,
