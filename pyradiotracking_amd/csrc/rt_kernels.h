@@ -2319,7 +2319,12 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
 #ifndef RT_DETECT_ABLATE
 #define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort, 4 = no run statistics, 5 = no hand-over of the records, 6 = stop before the runs are gated
 #endif
-    for (int r = lane; r < F / kBuckets && (!LARGE || wave == 0); r += 64) {
+    // Where a bucket holds many bins (nperseg >= 512: 32 ... 256 of them, each a sum over the stream's partial rows -- 11 at BASELINE
+    // config 5, 19 at config 3) only the bins that OCCUR in the list get their mean, after the sort below (a dozen of 256 at config 5,
+    // where the full table was four dependent rounds of loads per lane: detect_bucket 310 -> 228 us on the config-5 share, 345 -> 305
+    // at config 3, profiles/r05_h_*).  The same sums, bit for bit.
+    const bool lazy_means = !LARGE && F / kBuckets > 16;
+    for (int r = lane; r < F / kBuckets && (!LARGE || wave == 0) && !lazy_means; r += 64) {
         const int bin = bkt + kBuckets * r;
         if (RT_DETECT_ABLATE == 1) { avg[r] = 1e-20f; continue; }
         avg[r] = (float)row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + bin, a.chunks, F) / (float)T;
@@ -2351,6 +2356,19 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
         }
         wave_sync();
         if (RT_DETECT_ABLATE == 3) return;
+        if (lazy_means) {
+            // the list is in (bin, t) order: the first cell of every bin computes that bin's mean -- all of a step's bins at once
+            for (int base_i = 0; base_i < n; base_i += 64) {
+                const int i = base_i + lane;
+                if (i < n) {
+                    const int bin = (int)(keys[i] >> a.tbits);
+                    if (i == 0 || (int)(keys[i - 1] >> a.tbits) != bin)
+                        avg[bin / kBuckets] = (RT_DETECT_ABLATE == 1) ? 1e-20f
+                                                                      : (float)row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + bin, a.chunks, F) / (float)T;
+                }
+            }
+            wave_sync();
+        }
     } else {
         const int tid = threadIdx.x;
         for (int i = tid; i < n2; i += 256) {
