@@ -65,7 +65,6 @@ struct CallCtx {
     bool level_settled = false;  // AUTO's level bookkeeping for this call is done (fetch_one passes over a call twice: size query / peek, then delivery)
     bool ran_lin = false;     // its scans detrended by linearity (fetch_one: analysed again if the guard marks a stream)
     uint64_t sub_epoch = 0;   // rt_handle::sub_epoch when its kernels were enqueued
-    int min_items = 0;        // rows per stream of the chunk minima its scan left in the slot's d_chunk_min (= its work items per stream)
     // handle state before this call (restored when the call is rolled back: a later lane failed to enqueue)
     int prev_tail_cur = 0, prev_n_seg_last = -1, prev_dense_sticky = 0, prev_minsum_slot = -1;
 };
@@ -83,6 +82,8 @@ struct Slot {
     uint32_t *h_abs_hot = nullptr;    // pinned: their maximum over the streams, of this slot's latest MODE 4 / 6 scan
     float *d_thr_bin = nullptr, *d_thr_nat = nullptr;  // [S][N] per-bin thresholds of the exact pre-filter for this slot's call, lane order / bin order
                                       // (make_bin_thresholds; per slot: the check of call k reads them beside the scan of call k + 1)
+    int min_items = 0;                // rows per stream of the minima d_chunk_min holds (= the work items per stream of the scan that wrote them; 0: none)
+    uint64_t min_seq = 0;             // ... and the number of the call they are of
     uint32_t *d_chunk_min = nullptr;  // [S][items][N] float bits: per work item and bin the smallest complete-chunk sum of this slot's latest call (StftParams::chunk_min)
     int32_t *d_seg_list = nullptr;    // [S][max_seg] segments holding such cells, then [S] their number per stream and [1] the batch's total
     int32_t *h_seg_total = nullptr;   // pinned: that total, copied behind plan_runs
@@ -415,7 +416,7 @@ StftParams make_stft_params(rt_handle *h, Slot &sl, const void *iq, int64_t stre
     p.first = sl.d_full ? sl.d_full + (size_t)h->cfg.n_streams * h->max_chunks * h->LG : nullptr;
     p.item_chunks = sl.d_items;
     p.item_count = sl.d_items ? sl.d_items + (size_t)h->cfg.n_streams * h->max_blocks * h->GPW : nullptr;
-    p.chunk_min = sl.d_chunk_min;
+    p.chunk_min = nullptr;  // (only the exact pre-filter's own scans keep chunk minima: enqueue_analysis)
     p.abs_hot = nullptr;
     p.thr_bin = nullptr;
     p.cell_hot = sl.d_cell_hot;
@@ -560,23 +561,29 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
             hipLaunchKernelGGL(make_bin_thresholds_from_means, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, sl.d_psum, sp.blocks_per_stream,
                                c.n_seg, sl.d_thr_bin, sl.d_thr_nat, S, h->R3, h->cfg.snr_threshold);
         } else {
-        if (h->minsum_slot < 0) {
-            // the handle's very first call: no chunk minima yet.  A scan of this buffer provides them (its bits, taken with
-            // the absolute threshold alone, are overwritten by the scan proper below) -- once per handle.
+        // Chunk minima are kept by this level's own scans only (round 5: the sparse scans of an AUTO handle paid for them in every
+        // item's epilogue -- config 3 +1.8 % per launch -- for the one call in thousands that climbs here).  None on hand -- the handle's
+        // first call on this level, or the first after calls on other levels: a scan of this buffer provides them (its bits, taken
+        // with the absolute threshold alone, are overwritten by the scan proper below).
+        sp.chunk_min = sl.d_chunk_min;
+        if (h->minsum_slot < 0 || h->slot[h->minsum_slot].min_items <= 0) {
             launch_scan<6>(h, sp, blocks, c.u8);
             h->minsum_slot = slot_index;
-            sl.call.min_items = sp.blocks_per_stream;
+            sl.min_items = sp.blocks_per_stream;
+            sl.min_seq = sl.call.seq;
         }
         const Slot &ps = h->slot[h->minsum_slot];
-        hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, ps.d_chunk_min, ps.call.min_items, sl.d_thr_bin,
+        hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, ps.d_chunk_min, ps.min_items, sl.d_thr_bin,
                            sl.d_thr_nat, S, h->R3, h->L * minsum_group(h->L, h->GPW), h->cfg.snr_threshold);
         }
     }
-    if (sl.d_chunk_min && !second_pass_only) {
-        sl.call.min_items = sp.blocks_per_stream;  // (every item of the scan below writes its row of minima: nothing to reset)
+    if (mode == RT_MODE_RUNFILTER && !second_pass_only) {
+        sp.chunk_min = sl.d_chunk_min;
+        sl.min_items = sp.blocks_per_stream;  // (every item of the scan below writes its row of minima: nothing to reset)
+        sl.min_seq = sl.call.seq;
         // the LATEST buffer's minima set the next call's thresholds: a call analysed again from rt_fetch (level-up, stale
         // thresholds, pool growth, the detrend guard) while a later one is in flight must not take that place back
-        if (h->minsum_slot < 0 || sl.call.seq >= h->slot[h->minsum_slot].call.seq) h->minsum_slot = slot_index;
+        if (h->minsum_slot < 0 || sl.min_seq >= h->slot[h->minsum_slot].min_seq) h->minsum_slot = slot_index;
     }
     // `sd`: the stream of the call's detection (and, experimentally, of more of what follows its first scan).  Where the handle has
     // a second stream (rt_create: nperseg <= 512 without lanes) the first scan of the NEXT call, ready at the same moment on s_scan,
@@ -821,6 +828,7 @@ void rollback_newest(rt_handle *h) {
         h->n_seg_last = c.prev_n_seg_last;
         h->dense_sticky = c.prev_dense_sticky;
         h->minsum_slot = c.prev_minsum_slot;  // (the chunk minima of the dropped buffer must not set the next call's thresholds)
+        if (best->min_seq == c.seq) best->min_items = 0;  // (... nor stand in for the slot's older ones, which they have overwritten)
         if (c.no_last) {
             for (int s = 0; s < h->cfg.n_streams; ++s)
                 if (best->h_no_last[s]) h->reset_pending[(size_t)s] = 1;
