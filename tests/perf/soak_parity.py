@@ -44,6 +44,22 @@ while time.time() < t_end:
     snr = float(rng.choice([5.0, 0.0, 8.0]))
     cal = [float(c) for c in rng.uniform(-6, 6, n_streams)] if rng.random() < 0.5 else 0.0
     mode = str(rng.choice(["sparse", "dense", "auto", "auto", "prefilter", "runfilter"]))  # prefilter: refused where the minimum duration is too short; runfilter: where it does not fit the planning tiles
+    # round 5 (SOAK_GENERAL=1, its own random stream so that the cases of earlier rounds stay what they were): a third of the cases at
+    # a power of two the fused scans do not cover -- the general transform on the dense path (AUTO / dense only)
+    if os.environ.get("SOAK_GENERAL") == "1" and not BIG:
+        rng_g = np.random.default_rng([seed0, case, 11])
+        if rng_g.random() < 0.34:
+            nperseg = int(rng_g.choice([8, 32, 64, 128, 128, 8192, 8192, 16384]))
+            n_seg = int(rng_g.integers(2, 400 if nperseg <= 128 else 60))
+            blen = n_seg * nperseg + int(rng_g.integers(0, nperseg))
+            hop = nperseg / fs
+            min_ms = float(rng_g.choice([0.0, 2 * hop * 1e3, 8.0, 5.0]))
+            max_ms = float(max(min_ms + 3 * hop * 1e3, rng_g.choice([10.0, 40.0, 80.0])))
+            mode = "auto" if mode != "dense" else "dense"
+            if nperseg >= 8192:
+                n_streams = min(n_streams, 6)
+                if isinstance(cal, list):
+                    cal = cal[:n_streams]
     subtract_first = bool(rng.random() < 0.3)  # SciPy's order of the constant detrend instead of the linearity form
     # round 2: a quarter of the cases with the noise floor around the absolute threshold (8 dB under .. 2 dB over): the
     # sparse path overflows, AUTO climbs to the run-length pre-filter or the dense path; decisions then sit on the noise
