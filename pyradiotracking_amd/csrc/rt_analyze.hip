@@ -283,7 +283,7 @@ void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_s
     g.n_seg = n_seg;
     g.nperseg = h->N;
     g.log2n = h->log2n;
-    g.segs_per_block = std::max(1, 512 / h->N);
+    g.segs_per_block = std::min(64, std::max(1, 1024 / h->N));  // (N / 4 four-element groups per segment and double stage: every thread has one at N <= 1024)
     g.tail_cols = h->K;
     g.window = h->d_window;
     g.tw = h->d_twg;
@@ -518,13 +518,18 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
         if (launched) *launched = true;
         launch_general(h, c.iq, c.stream_stride, c.n_seg, h->d_spec, h->d_tail[c.tail_write], c.u8);
+        {
+            const int64_t cells = (int64_t)h->cfg.n_streams * h->N;
+            hipLaunchKernelGGL(row_sums_dense, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, h->d_spec, sl.d_psum, h->cfg.n_streams, c.n_seg, h->N);
+        }
         RT_HIP(h, hipGetLastError());
         RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
         DetectArgs a = make_detect_args(h, sl, c.n_seg, h->N, c.n_seg_last);
         a.prev = h->d_tail[c.tail_read];
         a.prev_cols = h->K;
         a.spec = h->d_spec;
-        a.psum = nullptr;
+        a.psum = sl.d_psum;  // one partial row per stream (row_sums_dense)
+        a.chunks = 1;
         hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
         RT_HIP(h, hipGetLastError());
         RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));

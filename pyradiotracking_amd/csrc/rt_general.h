@@ -8,9 +8,9 @@
 // followed by detect_dense (the extractor on a dense map, any number of bins).  Two passes over 4 bytes per cell like every
 // dense call: bound by its 16 bytes per sample, not a path the roofline is quoted on.
 //
-// Transform: radix-2 decimation in time inside LDS.  A workgroup of 256 threads holds SPB = max(1, 512 / N) segments;
-// samples are stored at bit-reversed places, log2 N butterfly passes follow in place (twiddles W_N^m, m < N / 2, from a
-// table made in double precision), natural order comes out.  One barrier per pass.
+// Transform: radix-2 decimation in time inside LDS.  A workgroup of 256 threads holds SPB = max(1, 1024 / N) segments (at most 64);
+// samples are stored at bit-reversed places, log2 N butterfly stages follow in place, two per barrier (twiddles W_N^m,
+// m < N / 2, from a table made in double precision), natural order comes out.
 #ifndef RT_GENERAL_H
 #define RT_GENERAL_H
 
@@ -35,6 +35,8 @@ struct GeneralParams {
 
 constexpr int kGeneralBlock = 256;
 constexpr int kGeneralMaxN = 16384;  // 128 KiB of LDS for one segment
+// (Measured and dropped, round 5: workgroups of 1 024 threads beyond nperseg 1024 and W_(2 h)^k as the square of W_(4 h)^k instead of a
+// second table load -- nperseg 8192 72 k -> 45 k MS/s, 128 150 k -> 128 k, only 16 384 gained, 50 k -> 55 k.)
 
 template <bool U8>
 __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParams p) {
@@ -88,18 +90,38 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
         }
     }
     __syncthreads();
-    // log2 N butterfly passes
-    for (int st = 1; st <= LOG; ++st) {
-        const int half = 1 << (st - 1);
-        const int tw_step = N >> st;  // W_(2 half)^k = W_N^(k N / (2 half))
+    // log2 N butterfly stages, two per barrier: a thread takes the four elements base + {0, h, 2 h, 3 h} (h = the first stage's
+    // half-span) through both -- half the LDS traffic and barriers of a stage at a time.  An odd log2 N starts with one stage alone
+    // (span 2: no twiddle).
+    int st = 1;
+    if (LOG & 1) {
         if (live) {
             for (int b = lt; b < N / 2; b += TPS) {
-                const int k = b & (half - 1);
-                const int i = ((b >> (st - 1)) << st) | k;
-                const cf u = xs[i];
-                const cf v = cmul(xs[i + half], p.tw[k * tw_step]);
-                xs[i] = cadd(u, v);
-                xs[i + half] = csub(u, v);
+                const cf u = xs[2 * b], v = xs[2 * b + 1];
+                xs[2 * b] = cadd(u, v);
+                xs[2 * b + 1] = csub(u, v);
+            }
+        }
+        __syncthreads();
+        st = 2;
+    }
+    for (; st < LOG; st += 2) {
+        const int h = 1 << (st - 1);
+        const int step1 = N >> st;        // W_(2 h)^k = W_N^(k N / (2 h))
+        const int step2 = N >> (st + 1);  // W_(4 h)^k = W_N^(k N / (4 h))
+        if (live) {
+            for (int g = lt; g < N / 4; g += TPS) {
+                const int k = g & (h - 1);
+                const int i0 = ((g >> (st - 1)) << (st + 1)) | k;
+                const cf w1 = p.tw[k * step1], w2 = p.tw[k * step2];
+                const cf a0 = xs[i0], a1 = cmul(xs[i0 + h], w1), a2 = xs[i0 + 2 * h], a3 = cmul(xs[i0 + 3 * h], w1);
+                const cf b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);  // stage st: pairs (0, h), (2 h, 3 h)
+                const cf c2 = cmul(b2, w2);
+                const cf c3 = mul_mi(cmul(b3, w2));  // W_(4 h)^(k + h) = -i W_(4 h)^k
+                xs[i0] = cadd(b0, c2);               // stage st + 1: pairs (0, 2 h), (h, 3 h)
+                xs[i0 + 2 * h] = csub(b0, c2);
+                xs[i0 + h] = cadd(b1, c3);
+                xs[i0 + 3 * h] = csub(b1, c3);
             }
         }
         __syncthreads();
@@ -117,6 +139,28 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
             if (tdst) tdst[k] = pw;
         }
     }
+}
+
+// Row sums of the dense map the general transform wrote, one partial row per stream (DetectArgs::psum with chunks = 1): a thread per
+// (stream, bin) adds its T cells in float64 (neighbouring threads read neighbouring bins: whole lines) and rounds once -- np.mean's
+// float32 pairwise sum is the exact sum to a few 1e-8.  With the sums on hand detect_dense splits a row's time axis over its threads;
+// without them (rt_extract: the caller's spectrogram) every thread first walks its whole row (17.6 ms against 1.5 at nperseg 128).
+__global__ __launch_bounds__(256) void row_sums_dense(const float *spec, float *psum, int n_streams, int n_seg, int n_bins) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n_streams * n_bins) return;
+    const int s = (int)(i / n_bins), bin = (int)(i % n_bins);
+    const float *row = spec + (int64_t)s * n_seg * n_bins + bin;
+    double acc = 0.0;
+    int t = 0;
+    for (; t + 8 <= n_seg; t += 8) {  // eight loads in flight
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row[(int64_t)(t + j) * n_bins];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += (double)v[j];
+    }
+    for (; t < n_seg; ++t) acc += (double)row[(int64_t)t * n_bins];
+    psum[i] = (float)acc;
 }
 
 }  // namespace rt
