@@ -465,9 +465,12 @@ template <int R3, int MODE, bool U8 = false, bool LIN = false>
 #ifndef RT_WG4_MAX_R3
 #define RT_WG4_MAX_R3 0
 #endif
-// Packed float32 butterflies (rt_fft.h: cfv) in the complex64 kernels up to this R3 (1 = nperseg 256; 0 = nowhere).
-#ifndef RT_PK_MAX_R3
-#define RT_PK_MAX_R3 1
+// Packed float32 butterflies (rt_fft.h: cfv) in the complex64 kernels of the R3 named by this mask (R3 is a power of two: bit R3;
+// 0 = nowhere).  nperseg 256 (round 3: 164 VGPRs, no spill, +1.3 %) and 1024 (round 5: 168 VGPRs and 39 spilled ones, all of
+// them lane constants of the rare tail-column block, +1 ... +2 % at BASELINE config 3 on two boxes, profiles/r05_l_*); NOT 512
+// (12 spilled registers inside the step: -12 %) and not 2048 (spills).
+#ifndef RT_PK_R3_MASK
+#define RT_PK_R3_MASK (1 | 4)
 #endif
 __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     const int L = p.segs_per_chunk;
 
     // the transform's arithmetic form: packed pairs where the registers are free (rt_fft.h), else scalar -- same results
-    constexpr bool PK = (R3 <= RT_PK_MAX_R3) && !U8;
+    constexpr bool PK = ((RT_PK_R3_MASK & R3) != 0) && !U8;
     using C = typename std::conditional<PK, cfv, cf>::type;
     C *gx = reinterpret_cast<C *>(xch + g * LG * kRowF2);  // this group's exchange rows
 

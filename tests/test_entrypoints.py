@@ -149,7 +149,7 @@ def test_product_library_has_no_laboratory_hooks():
     hdr = os.path.join(build.CSRC, "rt_diag.h")
     ok = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", hdr], capture_output=True, text=True)
     assert ok.returncode == 0, ok.stderr
-    for switch in ("-DRT_STAMPS", "-DRT_ABLATE=3", "-DRT_EXP_NOBAR1", "-DRT_WAVE64_4096=0", "-DRT_PK_MAX_R3=0"):
+    for switch in ("-DRT_STAMPS", "-DRT_ABLATE=3", "-DRT_EXP_NOBAR1", "-DRT_WAVE64_4096=0", "-DRT_PK_R3_MASK=0"):
         bad = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", switch, hdr], capture_output=True, text=True)
         assert bad.returncode != 0 and "laboratory switch" in bad.stderr, switch
         lab = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-DRT_DIAG", switch, hdr], capture_output=True, text=True)
