@@ -39,7 +39,7 @@ extern "C" {
 typedef enum rt_status {
     RT_OK = 0,
     RT_E_INVALID = -1,      /* bad argument / configuration                     */
-    RT_E_UNSUPPORTED = -2,  /* e.g. nperseg not a power of two in 8 .. 16384    */
+    RT_E_UNSUPPORTED = -2,  /* e.g. nperseg < 8, > 8192 and not a power of two  */
     RT_E_NO_DEVICE = -3,    /* no usable GPU / HIP failure at create            */
     RT_E_HIP = -4,          /* HIP runtime error (see rt_last_error)            */
     RT_E_CAPACITY = -5,     /* record capacity exceeded (results truncated, never dropped: rt_fetch) */
@@ -85,9 +85,10 @@ typedef struct rt_config {
     int32_t device;             /* HIP device ordinal                                    */
     int32_t n_streams;          /* S: independent streams analysed per call              */
     int32_t nperseg;            /* fft_nperseg (analyze.py:111; the reference passes any integer on to SciPy, __main__.py:59):
-                                   a power of two from 8 to 16384.  256 ... 4096 run the fused scan kernels (every rt_mode);
-                                   the other powers of two run a general transform on the dense path (RT_MODE_AUTO or
-                                   RT_MODE_DENSE only, 16 bytes of traffic per sample); anything else: RT_E_UNSUPPORTED */
+                                   any size from 8 to 8192, or a power of two up to 16384.  The powers of two 256 ... 4096 run the
+                                   fused scan kernels (every rt_mode); every other size runs a general transform on the dense path
+                                   (other powers of two: radix-2 in LDS; the rest: Bluestein's algorithm on it) -- RT_MODE_AUTO or
+                                   RT_MODE_DENSE only, 16 bytes of traffic per sample; anything else: RT_E_UNSUPPORTED */
     int32_t mode;               /* rt_mode                                               */
     int64_t max_samples;        /* largest per-stream buffer length B accepted           */
     double sample_rate;         /* fs (analyze.py:101)                                   */

@@ -124,9 +124,13 @@ struct rt_handle {
     hipStream_t s_detect = nullptr;  // the sparse detection's own (lower-priority) stream where the handle owns its streams, else = s_scan
     std::string err;
 
-    bool general = false;      // nperseg is a power of two the fused scans do not cover: stft_general + detect_dense (rt_general.h), dense path only
-    int log2n = 8;
-    cf *d_twg = nullptr;       // ... its twiddles W_N^m, m < N / 2
+    bool general = false;      // nperseg is not one the fused scans cover: stft_general / stft_bluestein + detect_dense (rt_general.h), dense path only
+    int log2n = 8;             // log2 of the LDS transform's length: nperseg (a power of two), or Bluestein's M
+    cf *d_twg = nullptr;       // ... its twiddles W_M^j, j < M / 2
+    bool bluestein = false;    // nperseg is not a power of two: Bluestein's algorithm with transforms of length gen_m >= 2 nperseg - 1
+    int gen_m = 0;
+    cf *d_cwin = nullptr;      // [nperseg] window * sqrt(scale) * exp(-i pi n^2 / nperseg)
+    cf *d_bfilt = nullptr;     // [gen_m] transform of the chirp filter, divided by gen_m
     int n_cu = 256;            // compute units of the device (the scan's grid: launch_stft_lin)
     uint32_t *d_work = nullptr;  // the scan kernels' item counters (StftParams::work), zero between launches
     float *d_window = nullptr;
@@ -276,6 +280,27 @@ void launch_stft(rt_handle *h, const StftParams &p, int blocks, hipStream_t st) 
 
 // the general transform (rt_general.h): the dense spectrogram of a power-of-two nperseg the fused scans do not cover
 void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_seg, float *spec, float *tail, bool u8) {
+    if (h->bluestein) {
+        BluesteinParams b{};
+        b.iq = iq;
+        b.stream_stride = stream_stride;
+        b.n_streams = h->cfg.n_streams;
+        b.n_seg = n_seg;
+        b.nperseg = h->N;
+        b.m = h->gen_m;
+        b.log2m = h->log2n;
+        b.tail_cols = h->K;
+        b.cwin = h->d_cwin;
+        b.bfilt = h->d_bfilt;
+        b.tw = h->d_twg;
+        b.spec = spec;
+        b.tail = tail;
+        const int blocks = h->cfg.n_streams * n_seg;
+        const size_t lds = (size_t)h->gen_m * sizeof(cf);
+        if (u8) hipLaunchKernelGGL(stft_bluestein<true>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+        else hipLaunchKernelGGL(stft_bluestein<false>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+        return;
+    }
     GeneralParams g{};
     g.iq = iq;
     g.stream_stride = stream_stride;
@@ -927,6 +952,8 @@ void rt_destroy(rt_handle *h) {
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_work);
     (void)hipFree(h->d_twg);
+    (void)hipFree(h->d_cwin);
+    (void)hipFree(h->d_bfilt);
     (void)hipFree(h->d_window);
     (void)hipFree(h->d_window_t);
     (void)hipFree(h->d_sub_first);
@@ -989,14 +1016,17 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     int R3 = 0;
     for (int r : {1, 2, 4, 8, 16})
         if (cfg->nperseg == 256 * r) R3 = r;
-    bool general = false;
+    bool general = false, bluestein = false;
     if (!R3) {
-        // any other power of two from 8 to 16 384: the general transform on the dense path (rt_general.h)
+        // every other size the reference may be given (it passes any integer on to SciPy): the other powers of two from 8 to 16 384 by a
+        // general LDS transform, everything else from 8 to 8 192 by Bluestein's algorithm on it -- both on the dense path (rt_general.h)
         const int n = cfg->nperseg;
-        if (n < 8 || n > kGeneralMaxN || (n & (n - 1)) != 0)
-            return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(n) + " is not supported: it must be a power of two from 8 to 16384 (256 ... 4096 run the "
-                                                 "fused scan kernels, the other powers of two a general transform on the dense path); the reference accepts any integer");
+        const bool pow2 = n > 0 && (n & (n - 1)) == 0;
+        if (n < 8 || (pow2 && n > kGeneralMaxN) || (!pow2 && n > kGeneralMaxN / 2))
+            return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(n) + " is not supported: 8 ... 8192, or a power of two up to 16384 (256 ... 4096 powers of "
+                                                 "two run the fused scan kernels, every other size a general transform on the dense path)");
         general = true;
+        bluestein = !pow2;
         R3 = 1;  // (sizes the scratch the general path does not use)
     }
     if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_RUNFILTER) return fail_create(RT_E_INVALID, "bad mode");
@@ -1053,8 +1083,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->general = general;
     if (general) {
         h->cfg.mode = RT_MODE_DENSE;
+        h->bluestein = bluestein;
+        h->gen_m = 1;
+        while (h->gen_m < (bluestein ? 2 * cfg->nperseg - 1 : cfg->nperseg)) h->gen_m <<= 1;
         h->log2n = 0;
-        while ((1 << h->log2n) < cfg->nperseg) ++h->log2n;
+        while ((1 << h->log2n) < h->gen_m) ++h->log2n;
     }
     h->N = cfg->nperseg;
     h->LG = 16 * R3;
@@ -1180,15 +1213,78 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     const int S = cfg->n_streams, N = h->N, LG = h->LG;
     h->reset_pending.assign((size_t)S, 0);
     if (general) {
-        std::vector<cf> twg((size_t)N / 2);
-        for (int m = 0; m < N / 2; ++m) {
-            const double ang = -6.283185307179586476925286766559 * (double)m / (double)N;
+        const int M = h->gen_m;
+        std::vector<cf> twg((size_t)M / 2);
+        for (int m = 0; m < M / 2; ++m) {
+            const double ang = -6.283185307179586476925286766559 * (double)m / (double)M;
             twg[(size_t)m] = cf{(float)std::cos(ang), (float)std::sin(ang)};
         }
         RT_CREATE_HIP(hipMalloc(&h->d_twg, sizeof(cf) * twg.size()));
         RT_CREATE_HIP(hipMemcpy(h->d_twg, twg.data(), sizeof(cf) * twg.size(), hipMemcpyHostToDevice));
         RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
         RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
+        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bluestein<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
+        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bluestein<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
+        if (h->bluestein) {
+            // chirp w[n] = exp(-i pi n^2 / N) (the exponent reduced mod 2 N in integers); the window (times sqrt(scale), as every scan
+            // takes it) times the chirp; the filter conj(w) on -N < m < N, wrapped to length M, its transform in double precision
+            const double pi = 3.14159265358979323846264338327950288;
+            auto chirp = [&](long long n, double sign, double *re, double *im) {
+                const long long e = (n * n) % (2ll * N);
+                const double ang = sign * pi * (double)e / (double)N;
+                *re = std::cos(ang);
+                *im = std::sin(ang);
+            };
+            std::vector<cf> cwin((size_t)N);
+            const double root = std::sqrt((double)cfg->scale);
+            for (int n = 0; n < N; ++n) {
+                double cr, ci;
+                chirp(n, -1.0, &cr, &ci);
+                const double wv = (double)cfg->window[n] * root;
+                cwin[(size_t)n] = cf{(float)(wv * cr), (float)(wv * ci)};
+            }
+            std::vector<double> br((size_t)M, 0.0), bi((size_t)M, 0.0);
+            for (int m = 0; m < N; ++m) {
+                double cr, ci;
+                chirp(m, +1.0, &cr, &ci);
+                br[(size_t)m] = cr;
+                bi[(size_t)m] = ci;
+                if (m) {
+                    br[(size_t)(M - m)] = cr;
+                    bi[(size_t)(M - m)] = ci;
+                }
+            }
+            {  // in-place radix-2 transform of the filter, float64 (bit reversal, then log2 M stages)
+                for (int i = 1, j = 0; i < M; ++i) {
+                    int bit = M >> 1;
+                    for (; j & bit; bit >>= 1) j ^= bit;
+                    j ^= bit;
+                    if (i < j) {
+                        std::swap(br[(size_t)i], br[(size_t)j]);
+                        std::swap(bi[(size_t)i], bi[(size_t)j]);
+                    }
+                }
+                for (int len = 2; len <= M; len <<= 1) {
+                    for (int i = 0; i < M; i += len)
+                        for (int k = 0; k < len / 2; ++k) {
+                            const double ang = -2.0 * pi * (double)k / (double)len;
+                            const double wr = std::cos(ang), wi = std::sin(ang);
+                            const size_t a = (size_t)(i + k), b = (size_t)(i + k + len / 2);
+                            const double xr = br[b] * wr - bi[b] * wi, xi = br[b] * wi + bi[b] * wr;
+                            br[b] = br[a] - xr;
+                            bi[b] = bi[a] - xi;
+                            br[a] += xr;
+                            bi[a] += xi;
+                        }
+                }
+            }
+            std::vector<cf> bf((size_t)M);
+            for (int m = 0; m < M; ++m) bf[(size_t)m] = cf{(float)(br[(size_t)m] / M), (float)(bi[(size_t)m] / M)};
+            RT_CREATE_HIP(hipMalloc(&h->d_cwin, sizeof(cf) * cwin.size()));
+            RT_CREATE_HIP(hipMemcpy(h->d_cwin, cwin.data(), sizeof(cf) * cwin.size(), hipMemcpyHostToDevice));
+            RT_CREATE_HIP(hipMalloc(&h->d_bfilt, sizeof(cf) * bf.size()));
+            RT_CREATE_HIP(hipMemcpy(h->d_bfilt, bf.data(), sizeof(cf) * bf.size(), hipMemcpyHostToDevice));
+        }
     }
     // window and twiddle tables (twiddles in double, rounded once to float32)
     std::vector<cf> tw1((size_t)LG * 16), tw2((size_t)R3 * 16);

@@ -1,4 +1,5 @@
-// rt_general.h -- the spectrogram for any power-of-two nperseg the fused scans do not cover.
+// rt_general.h -- the spectrogram for every nperseg the fused scans do not cover: the other powers of two (stft_general) and,
+// by Bluestein's algorithm, everything else (stft_bluestein).
 //
 // The reference hands `fft_nperseg` straight to scipy.signal.spectrogram (radiotracking/__main__.py:59,
 // analyze.py:234-241): any integer.  The fused scans (rt_kernels.h, rt_scan64.h) exist for 256 .. 4096; every other
@@ -37,6 +38,46 @@ constexpr int kGeneralBlock = 256;
 constexpr int kGeneralMaxN = 16384;  // 128 KiB of LDS for one segment
 // (Measured and dropped, round 5: workgroups of 1 024 threads beyond nperseg 1024 and W_(2 h)^k as the square of W_(4 h)^k instead of a
 // second table load -- nperseg 8192 72 k -> 45 k MS/s, 128 150 k -> 128 k, only 16 384 gained, 50 k -> 55 k.)
+
+// log2 N butterfly stages of a decimation-in-time transform on `xs` (N complex values in LDS, input at bit-reversed places,
+// natural order out), two stages per barrier: a thread takes the four elements base + {0, h, 2 h, 3 h} (h = the first stage's
+// half-span) through both -- half the LDS traffic and barriers of a stage at a time.  An odd log2 N starts with one stage alone
+// (span 2: no twiddle).  Called by all threads of the workgroup (barriers inside); `live` threads (lt of TPS per segment) work.
+__device__ __forceinline__ void lds_fft_stages(cf *xs, int N, int LOG, const cf *tw, int lt, int TPS, bool live) {
+    int st = 1;
+    if (LOG & 1) {
+        if (live) {
+            for (int b = lt; b < N / 2; b += TPS) {
+                const cf u = xs[2 * b], v = xs[2 * b + 1];
+                xs[2 * b] = cadd(u, v);
+                xs[2 * b + 1] = csub(u, v);
+            }
+        }
+        __syncthreads();
+        st = 2;
+    }
+    for (; st < LOG; st += 2) {
+        const int h = 1 << (st - 1);
+        const int step1 = N >> st;        // W_(2 h)^k = W_N^(k N / (2 h))
+        const int step2 = N >> (st + 1);  // W_(4 h)^k = W_N^(k N / (4 h))
+        if (live) {
+            for (int g = lt; g < N / 4; g += TPS) {
+                const int k = g & (h - 1);
+                const int i0 = ((g >> (st - 1)) << (st + 1)) | k;
+                const cf w1 = tw[k * step1], w2 = tw[k * step2];
+                const cf a0 = xs[i0], a1 = cmul(xs[i0 + h], w1), a2 = xs[i0 + 2 * h], a3 = cmul(xs[i0 + 3 * h], w1);
+                const cf b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);  // stage st: pairs (0, h), (2 h, 3 h)
+                const cf c2 = cmul(b2, w2);
+                const cf c3 = mul_mi(cmul(b3, w2));  // W_(4 h)^(k + h) = -i W_(4 h)^k
+                xs[i0] = cadd(b0, c2);               // stage st + 1: pairs (0, 2 h), (h, 3 h)
+                xs[i0 + 2 * h] = csub(b0, c2);
+                xs[i0 + h] = cadd(b1, c3);
+                xs[i0 + 3 * h] = csub(b1, c3);
+            }
+        }
+        __syncthreads();
+    }
+}
 
 template <bool U8>
 __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParams p) {
@@ -90,42 +131,7 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
         }
     }
     __syncthreads();
-    // log2 N butterfly stages, two per barrier: a thread takes the four elements base + {0, h, 2 h, 3 h} (h = the first stage's
-    // half-span) through both -- half the LDS traffic and barriers of a stage at a time.  An odd log2 N starts with one stage alone
-    // (span 2: no twiddle).
-    int st = 1;
-    if (LOG & 1) {
-        if (live) {
-            for (int b = lt; b < N / 2; b += TPS) {
-                const cf u = xs[2 * b], v = xs[2 * b + 1];
-                xs[2 * b] = cadd(u, v);
-                xs[2 * b + 1] = csub(u, v);
-            }
-        }
-        __syncthreads();
-        st = 2;
-    }
-    for (; st < LOG; st += 2) {
-        const int h = 1 << (st - 1);
-        const int step1 = N >> st;        // W_(2 h)^k = W_N^(k N / (2 h))
-        const int step2 = N >> (st + 1);  // W_(4 h)^k = W_N^(k N / (4 h))
-        if (live) {
-            for (int g = lt; g < N / 4; g += TPS) {
-                const int k = g & (h - 1);
-                const int i0 = ((g >> (st - 1)) << (st + 1)) | k;
-                const cf w1 = p.tw[k * step1], w2 = p.tw[k * step2];
-                const cf a0 = xs[i0], a1 = cmul(xs[i0 + h], w1), a2 = xs[i0 + 2 * h], a3 = cmul(xs[i0 + 3 * h], w1);
-                const cf b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);  // stage st: pairs (0, h), (2 h, 3 h)
-                const cf c2 = cmul(b2, w2);
-                const cf c3 = mul_mi(cmul(b3, w2));  // W_(4 h)^(k + h) = -i W_(4 h)^k
-                xs[i0] = cadd(b0, c2);               // stage st + 1: pairs (0, 2 h), (h, 3 h)
-                xs[i0 + 2 * h] = csub(b0, c2);
-                xs[i0 + h] = cadd(b1, c3);
-                xs[i0 + 3 * h] = csub(b1, c3);
-            }
-        }
-        __syncthreads();
-    }
+    lds_fft_stages(xs, N, LOG, p.tw, lt, TPS, live);
     // |X|^2 (scipy _spectral_py.py:2126-2128) -> the dense map and, for the last K segments, the look-back tail
     if (live) {
         const int seg = seg0 + q;
@@ -138,6 +144,89 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
             dst[k] = pw;
             if (tdst) tdst[k] = pw;
         }
+    }
+}
+
+// Any OTHER nperseg (8 ... 8192, not a power of two -- the reference takes any integer, radiotracking/__main__.py:59): Bluestein's
+// algorithm on the same LDS transform.  With w[n] = exp(-i pi n^2 / N),
+//     X[k] = w[k] * sum_n (x[n] w[n]) conj(w[k - n]),
+// a circular convolution of length M = the power of two >= 2 N - 1 with a fixed filter: A = FFT_M(x w, zero-padded),
+// C = A * B (B = FFT_M of the filter, made on the host in double precision, 1 / M folded in), c = IFFT_M(C) = conj(FFT_M(conj(C))),
+// X[k] = w[k] c[k] -- and since |w[k]| = 1 the power is |FFT_M(conj(C))[k]|^2 for k < N.  Detrend and window are folded into the
+// first multiplication: the table `cwin` holds window[n] * sqrt(scale) * w[n].  One segment per workgroup, M complex values
+// of LDS (up to 128 KiB).  Two transforms of length M >= 2 N per segment and float32 throughout: the round-off of the strongest
+// bin sits 110 - 120 dB under it in every bin (SciPy's mixed-radix float32 transform: ~130 dB) -- decisions and the dB figures of
+// the records are unaffected (tests: 0.01 dB), `std` over a cell that far under a tone follows the rule of DESIGN section 2 (3).
+struct BluesteinParams {
+    const void *iq;
+    int64_t stream_stride;
+    int32_t n_streams, n_seg, nperseg, m, log2m, tail_cols;
+    const cf *cwin;   // [N] window * sqrt(scale) * w[n]
+    const cf *bfilt;  // [M] FFT_M of the filter, divided by M
+    const cf *tw;     // [M / 2] W_M^j
+    float *spec, *tail;
+};
+
+template <bool U8>
+__global__ __launch_bounds__(kGeneralBlock) void stft_bluestein(const BluesteinParams p) {
+    using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char blu_smem[];
+    cf *const xs = reinterpret_cast<cf *>(blu_smem);  // [M]
+    __shared__ double red[2 * kGeneralBlock];
+    const int N = p.nperseg, M = p.m, LOG = p.log2m, T = p.n_seg;
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x / T, seg = blockIdx.x % T;
+    if (s >= p.n_streams) return;
+    const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride + (int64_t)seg * N;
+    // zero padding, then the samples (bit-reversed places of the length-M transform) and their sum
+    for (int j = tid; j < M; j += kGeneralBlock) xs[j] = cf{0.f, 0.f};
+    __syncthreads();
+    double sx = 0.0, sy = 0.0;
+    for (int n = tid; n < N; n += kGeneralBlock) {
+        const cf v = to_cf(load_iq(src + n));
+        sx += (double)v.x;
+        sy += (double)v.y;
+        xs[__brev((unsigned)n) >> (32 - LOG)] = v;
+    }
+    red[2 * tid] = sx;
+    red[2 * tid + 1] = sy;
+    __syncthreads();
+    double mxd = 0.0, myd = 0.0;
+    for (int j = 0; j < kGeneralBlock; ++j) {
+        mxd += red[2 * j];
+        myd += red[2 * j + 1];
+    }
+    const float mx = (float)(mxd / (double)N), my = (float)(myd / (double)N);
+    // (x - mean) * window * sqrt(scale) * w[n]
+    for (int n = tid; n < N; n += kGeneralBlock) {
+        const int at = (int)(__brev((unsigned)n) >> (32 - LOG));
+        const cf v = xs[at];
+        xs[at] = cmul(cf{v.x - mx, v.y - my}, p.cwin[n]);
+    }
+    __syncthreads();
+    lds_fft_stages(xs, M, LOG, p.tw, tid, kGeneralBlock, true);  // A, natural order
+    // conj(A * B) to bit-reversed places, in place: the pair (j, rev j) is one thread's
+    for (int j = tid; j < M; j += kGeneralBlock) {
+        const int r = (int)(__brev((unsigned)j) >> (32 - LOG));
+        if (j < r) {
+            const cf cj = cmul(xs[j], p.bfilt[j]), cr = cmul(xs[r], p.bfilt[r]);
+            xs[j] = cf{cr.x, -cr.y};
+            xs[r] = cf{cj.x, -cj.y};
+        } else if (j == r) {
+            const cf cj = cmul(xs[j], p.bfilt[j]);
+            xs[j] = cf{cj.x, -cj.y};
+        }
+    }
+    __syncthreads();
+    lds_fft_stages(xs, M, LOG, p.tw, tid, kGeneralBlock, true);  // FFT(conj(C)): its first N values have the spectrum's magnitudes
+    float *dst = p.spec + ((int64_t)s * T + seg) * N;
+    const int col = seg - (T - p.tail_cols);
+    float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
+    for (int k = tid; k < N; k += kGeneralBlock) {
+        const cf v = xs[k];
+        const float pw = __builtin_fmaf(v.x, v.x, v.y * v.y);
+        dst[k] = pw;
+        if (tdst) tdst[k] = pw;
     }
 }
 

@@ -49,14 +49,14 @@ while time.time() < t_end:
     if os.environ.get("SOAK_GENERAL") == "1" and not BIG:
         rng_g = np.random.default_rng([seed0, case, 11])
         if rng_g.random() < 0.34:
-            nperseg = int(rng_g.choice([8, 32, 64, 128, 128, 8192, 8192, 16384]))
+            nperseg = int(rng_g.choice([8, 32, 64, 128, 128, 8192, 8192, 16384, 12, 100, 300, 300, 1000, 1000, 1500, 4099, 6000]))  # (not powers of two: Bluestein)
             n_seg = int(rng_g.integers(2, 400 if nperseg <= 128 else 60))
             blen = n_seg * nperseg + int(rng_g.integers(0, nperseg))
             hop = nperseg / fs
             min_ms = float(rng_g.choice([0.0, 2 * hop * 1e3, 8.0, 5.0]))
             max_ms = float(max(min_ms + 3 * hop * 1e3, rng_g.choice([10.0, 40.0, 80.0])))
             mode = "auto" if mode != "dense" else "dense"
-            if nperseg >= 8192:
+            if nperseg >= 4099:
                 n_streams = min(n_streams, 6)
                 if isinstance(cal, list):
                     cal = cal[:n_streams]

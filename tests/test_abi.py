@@ -88,8 +88,8 @@ def test_argument_validation_happens_before_device_use(lib):
     cfg = _native.RtConfig()
     h = C.c_void_p()
     assert lib.rt_create(C.byref(cfg), C.byref(h)) == _native.RT_E_INVALID
-    w = np.ones(300, dtype=np.float32)
-    cfg.n_streams, cfg.nperseg, cfg.max_samples, cfg.sample_rate = 1, 300, 3000, 1e6
+    w = np.ones(9000, dtype=np.float32)
+    cfg.n_streams, cfg.nperseg, cfg.max_samples, cfg.sample_rate = 1, 9000, 90000, 1e6  # (not a power of two and over 8192)
     cfg.window = w.ctypes.data_as(C.POINTER(C.c_float))
     assert lib.rt_create(C.byref(cfg), C.byref(h)) == _native.RT_E_UNSUPPORTED
     assert b"nperseg" in lib.rt_last_error(None)

@@ -82,7 +82,8 @@ def _batch_for(kwargs, n_streams, max_samples, mode, **extra):
 # STFT power kernel
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (512, "hann"), (1024, "hann"), (2048, "hamming"), (4096, "hamming"),
-                                            (8, "hamming"), (16, "hann"), (64, "hamming"), (128, "hamming"), (8192, "hann"), (16384, "hamming")])
+                                            (8, "hamming"), (16, "hann"), (64, "hamming"), (128, "hamming"), (8192, "hann"), (16384, "hamming"),
+                                            (12, "hann"), (300, "hann"), (1000, "hamming"), (4099, "hamming"), (8191, "hann")])  # (not powers of two: Bluestein)
 def test_spectrogram_matches_oracle(nperseg, window):
     _need_gpu()
     fs = 2048000
@@ -136,7 +137,7 @@ def test_spectrogram_matches_oracle(nperseg, window):
 # pre-filter take its place there -- the reference's own output is the yardstick on every level)
 # (nperseg 128 / 8192 -- n128_short, n8192_short -- run the general transform, which lives on the dense path: AUTO goes there by itself)
 _IQ_CASE_MODES = [(n, m) for n in gu.iq_case_names()
-                  for m in (("auto", "runfilter", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith(("n128", "n8192")) else ("sparse", "dense"))]
+                  for m in (("auto", "runfilter", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith(("n128", "n8192", "n300")) else ("sparse", "dense"))]
 
 
 @pytest.mark.parametrize("name,mode", _IQ_CASE_MODES)
@@ -1861,14 +1862,14 @@ def test_misaligned_device_pointers_are_refused():
 
 
 def test_unsupported_nperseg_is_refused():
-    """The reference takes any integer (radiotracking/__main__.py:59 -> scipy, analyze.py:238); here every power of two from 8 to
-    16 384 runs, anything else is refused with a message that says so -- and the fused-scan-only modes are refused at the sizes
-    the general transform serves"""
+    """The reference takes any integer (radiotracking/__main__.py:59 -> scipy, analyze.py:238); here every size from 8 to 8 192 and
+    the powers of two up to 16 384 run, anything else is refused with a message that says so -- and the fused-scan-only modes are
+    refused at the sizes the general transforms serve"""
     _need_gpu()
-    for n in (300, 4, 32768, 255):
+    for n in (4, 7, 32768, 8193, 12000):
         with pytest.raises(_native.NativeError) as ei:
             SignalAnalyzer("0", fft_nperseg=n, fft_window="hann")
-        assert ei.value.code == _native.RT_E_UNSUPPORTED and "power of two from 8 to 16384" in str(ei.value)
+        assert ei.value.code == _native.RT_E_UNSUPPORTED and "8 ... 8192, or a power of two up to 16384" in str(ei.value)
     for mode in ("sparse", "runfilter", "prefilter"):
         with pytest.raises(_native.NativeError) as ei:
             _batch_for(dict(sample_rate=300000, fft_nperseg=128), 2, 128 * 100, mode)
@@ -1876,7 +1877,8 @@ def test_unsupported_nperseg_is_refused():
 
 
 @pytest.mark.parametrize("lanes,wire", [(1, "complex64"), (2, "complex64"), (1, "uint8")])
-@pytest.mark.parametrize("nperseg,window,fs", [(64, "hann", 300000), (128, "hamming", 300000), (8192, "hamming", 3200000)])
+@pytest.mark.parametrize("nperseg,window,fs", [(64, "hann", 300000), (128, "hamming", 300000), (8192, "hamming", 3200000),
+                                               (300, "hann", 300000), (1000, "hamming", 2400000), (37, "hann", 300000)])
 def test_other_powers_of_two_match_oracle(nperseg, window, fs, lanes, wire):
     """fft_nperseg outside 256 ... 4096 (128 and 8192 are plausible station settings): the general transform + the dense
     extractor, three consecutive buffers with the look-back live, AUTO mode, with lanes and from the uint8 wire format --
