@@ -127,6 +127,9 @@ struct rt_handle {
     bool general = false;      // nperseg is not one the fused scans cover: stft_general / stft_bluestein + detect_dense (rt_general.h), dense path only
     int log2n = 8;             // log2 of the LDS transform's length: nperseg (a power of two), or Bluestein's M
     cf *d_twg = nullptr;       // ... its twiddles W_M^j, j < M / 2
+    int small_q = 0;           // nperseg 32 / 64 / 128: nperseg / 16, served by stft_small (registers + one wave-private exchange)
+    int small_steps = 1;       // ... steps of a wave there (fixed per handle: the order of the row sums' partial sums)
+    cf *d_tws = nullptr;       // ... its pass twiddles W_N^(a k1), [small_q][16]
     bool bluestein = false;    // nperseg is not a power of two: Bluestein's algorithm with transforms of length gen_m >= 2 nperseg - 1
     int gen_m = 0;
     cf *d_cwin = nullptr;      // [nperseg] window * sqrt(scale) * exp(-i pi n^2 / nperseg)
@@ -279,7 +282,9 @@ void launch_stft(rt_handle *h, const StftParams &p, int blocks, hipStream_t st) 
 }
 
 // the general transform (rt_general.h): the dense spectrogram of a power-of-two nperseg the fused scans do not cover
-void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_seg, float *spec, float *tail, bool u8) {
+// `psum` (or null): where stft_small leaves the row sums of its workgroups.  Returns the number of partial rows per stream it wrote
+// there; 0: none (the caller runs row_sums_dense over the map).
+int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_seg, float *spec, float *tail, bool u8, float *psum = nullptr) {
     if (h->bluestein) {
         BluesteinParams b{};
         b.iq = iq;
@@ -299,7 +304,35 @@ void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_s
         const size_t lds = (size_t)h->gen_m * sizeof(cf);
         if (u8) hipLaunchKernelGGL(stft_bluestein<true>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
         else hipLaunchKernelGGL(stft_bluestein<false>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-        return;
+        return 0;
+    }
+    // (its stores are 8 / 16 bytes wide: a caller's map that is only float-aligned -- rt_spectrogram allows it -- takes the radix-2 kernel)
+    if (h->small_q && reinterpret_cast<uintptr_t>(spec) % 16u == 0 && reinterpret_cast<uintptr_t>(tail) % 16u == 0) {
+        SmallParams m{};
+        m.iq = iq;
+        m.stream_stride = stream_stride;
+        m.n_streams = h->cfg.n_streams;
+        m.n_seg = n_seg;
+        m.tail_cols = h->K;
+        m.window = h->d_window;
+        m.tws = h->d_tws;
+        m.spec = spec;
+        m.tail = tail;
+        m.psum = psum;
+        m.steps = h->small_steps;
+        const int per_block = 4 * (64 / h->small_q) * h->small_steps;
+        const int rows = (n_seg + per_block - 1) / per_block;
+        const unsigned blocks = (unsigned)(h->cfg.n_streams * rows);
+        if (blocks == 0) return 0;
+        switch (h->small_q * 2 + (u8 ? 1 : 0)) {
+        case 4: hipLaunchKernelGGL((stft_small<2, false>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
+        case 5: hipLaunchKernelGGL((stft_small<2, true>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
+        case 8: hipLaunchKernelGGL((stft_small<4, false>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
+        case 9: hipLaunchKernelGGL((stft_small<4, true>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
+        case 16: hipLaunchKernelGGL((stft_small<8, false>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
+        default: hipLaunchKernelGGL((stft_small<8, true>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
+        }
+        return psum ? rows : 0;
     }
     GeneralParams g{};
     g.iq = iq;
@@ -318,6 +351,7 @@ void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_s
     const size_t lds = (size_t)g.segs_per_block * h->N * sizeof(cf);
     if (u8) hipLaunchKernelGGL(stft_general<true>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
     else hipLaunchKernelGGL(stft_general<false>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+    return 0;
 }
 
 // cells a run must have to pass the duration gate unless it runs through t = 0 (see rt_create)
@@ -542,8 +576,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
         if (launched) *launched = true;
-        launch_general(h, c.iq, c.stream_stride, c.n_seg, h->d_spec, h->d_tail[c.tail_write], c.u8);
-        {
+        const int rows = launch_general(h, c.iq, c.stream_stride, c.n_seg, h->d_spec, h->d_tail[c.tail_write], c.u8, sl.d_psum);
+        if (rows == 0) {
             const int64_t cells = (int64_t)h->cfg.n_streams * h->N;
             hipLaunchKernelGGL(row_sums_dense, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, h->d_spec, sl.d_psum, h->cfg.n_streams, c.n_seg, h->N);
         }
@@ -553,8 +587,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         a.prev = h->d_tail[c.tail_read];
         a.prev_cols = h->K;
         a.spec = h->d_spec;
-        a.psum = sl.d_psum;  // one partial row per stream (row_sums_dense)
-        a.chunks = 1;
+        a.psum = sl.d_psum;  // one partial row per stream (row_sums_dense), or one per workgroup of stft_small
+        a.chunks = rows ? rows : 1;
         hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
         RT_HIP(h, hipGetLastError());
         RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
@@ -952,6 +986,7 @@ void rt_destroy(rt_handle *h) {
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_work);
     (void)hipFree(h->d_twg);
+    (void)hipFree(h->d_tws);
     (void)hipFree(h->d_cwin);
     (void)hipFree(h->d_bfilt);
     (void)hipFree(h->d_window);
@@ -1105,6 +1140,15 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->L = choose_chunk(*cfg, R3, cfg->n_streams, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
     int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
+    if (general && !bluestein && (h->N == 32 || h->N == 64 || h->N == 128)) {
+        // stft_small: a workgroup walks 4 waves x (64 / Q) segments x steps of one stream and leaves one partial row of sums.  Eight
+        // steps where the batch fills the chip several times, fewer for small ones -- by the chunk length, which the lanes of a
+        // handle take from the parent: however a batch is split into lanes, a stream's sums are added in the same order.
+        h->small_q = h->N / 16;
+        h->small_steps = std::max(1, std::min(8, h->L / 4));
+        const int per_block = 4 * (64 / h->small_q) * h->small_steps;
+        max_blocks_per_stream = std::max(max_blocks_per_stream, (h->max_seg + per_block - 1) / per_block);
+    }
     h->max_blocks = max_blocks_per_stream;
     {
         // Run-length pre-filter: a run shorter than r_min cells (and not through t = 0) fails the duration gate whatever
@@ -1221,6 +1265,16 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         }
         RT_CREATE_HIP(hipMalloc(&h->d_twg, sizeof(cf) * twg.size()));
         RT_CREATE_HIP(hipMemcpy(h->d_twg, twg.data(), sizeof(cf) * twg.size(), hipMemcpyHostToDevice));
+        if (h->small_q) {
+            std::vector<cf> tws((size_t)N);
+            for (int a = 0; a < h->small_q; ++a)
+                for (int k1 = 0; k1 < 16; ++k1) {
+                    const double ang = -6.283185307179586476925286766559 * (double)((a * k1) % N) / (double)N;
+                    tws[(size_t)a * 16 + k1] = cf{(float)std::cos(ang), (float)std::sin(ang)};
+                }
+            RT_CREATE_HIP(hipMalloc(&h->d_tws, sizeof(cf) * tws.size()));
+            RT_CREATE_HIP(hipMemcpy(h->d_tws, tws.data(), sizeof(cf) * tws.size(), hipMemcpyHostToDevice));
+        }
         RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
         RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
         RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bluestein<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));

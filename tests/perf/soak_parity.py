@@ -48,8 +48,9 @@ while time.time() < t_end:
     # a power of two the fused scans do not cover -- the general transform on the dense path (AUTO / dense only)
     if os.environ.get("SOAK_GENERAL") == "1" and not BIG:
         rng_g = np.random.default_rng([seed0, case, 11])
-        if rng_g.random() < 0.34:
-            nperseg = int(rng_g.choice([8, 32, 64, 128, 128, 8192, 8192, 16384, 12, 100, 300, 300, 1000, 1000, 1500, 4099, 6000]))  # (not powers of two: Bluestein)
+        only = [int(v) for v in os.environ.get("SOAK_GENERAL_SIZES", "").split(",") if v]  # (e.g. "32,64,128": every case at one of these)
+        if only or rng_g.random() < 0.34:
+            nperseg = int(rng_g.choice(only or [8, 32, 64, 128, 128, 8192, 8192, 16384, 12, 100, 300, 300, 1000, 1000, 1500, 4099, 6000]))  # (not powers of two: Bluestein)
             n_seg = int(rng_g.integers(2, 400 if nperseg <= 128 else 60))
             blen = n_seg * nperseg + int(rng_g.integers(0, nperseg))
             hop = nperseg / fs

@@ -82,7 +82,7 @@ def _batch_for(kwargs, n_streams, max_samples, mode, **extra):
 # STFT power kernel
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (512, "hann"), (1024, "hann"), (2048, "hamming"), (4096, "hamming"),
-                                            (8, "hamming"), (16, "hann"), (64, "hamming"), (128, "hamming"), (8192, "hann"), (16384, "hamming"),
+                                            (8, "hamming"), (16, "hann"), (32, "hann"), (64, "hamming"), (128, "hamming"), (128, "blackmanharris"), (8192, "hann"), (16384, "hamming"),
                                             (12, "hann"), (300, "hann"), (1000, "hamming"), (4099, "hamming"), (8191, "hann")])  # (not powers of two: Bluestein)
 def test_spectrogram_matches_oracle(nperseg, window):
     _need_gpu()
@@ -1928,7 +1928,7 @@ def test_unsupported_nperseg_is_refused():
 
 
 @pytest.mark.parametrize("lanes,wire", [(1, "complex64"), (2, "complex64"), (1, "uint8")])
-@pytest.mark.parametrize("nperseg,window,fs", [(64, "hann", 300000), (128, "hamming", 300000), (8192, "hamming", 3200000),
+@pytest.mark.parametrize("nperseg,window,fs", [(32, "hamming", 300000), (64, "hann", 300000), (128, "hamming", 300000), (8192, "hamming", 3200000),
                                                (300, "hann", 300000), (1000, "hamming", 2400000), (37, "hann", 300000)])
 def test_other_powers_of_two_match_oracle(nperseg, window, fs, lanes, wire):
     """fft_nperseg outside 256 ... 4096 (128 and 8192 are plausible station settings): the general transform + the dense
@@ -1973,7 +1973,7 @@ def test_other_powers_of_two_match_oracle(nperseg, window, fs, lanes, wire):
                 for name in ("max", "avg", "noise", "snr", "std"):
                     assert abs(getattr(g, name) - getattr(x, name)) < POWER_TOL_DB, (name, getattr(g, name), getattr(x, name))
             total += len(mine)
-    assert total > 10
+    assert total > (5 if nperseg == 32 else 10)
 
 
 # ---------------------------------------------------------------------------
