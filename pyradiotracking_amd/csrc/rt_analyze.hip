@@ -302,8 +302,24 @@ int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_se
         b.tail = tail;
         const int blocks = h->cfg.n_streams * n_seg;
         const size_t lds = (size_t)h->gen_m * sizeof(cf);
-        if (u8) hipLaunchKernelGGL(stft_bluestein<true>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-        else hipLaunchKernelGGL(stft_bluestein<false>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+        // (groups of a thread per trip of a double stage: rt_general.h, lds_fft_stages -- M / 4 a multiple of 256 U)
+        switch (std::min(8, h->gen_m / 1024)) {
+        case 8:
+            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 8>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+            else hipLaunchKernelGGL((stft_bluestein<false, 8>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+            break;
+        case 4:
+            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 4>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+            else hipLaunchKernelGGL((stft_bluestein<false, 4>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+            break;
+        case 2:
+            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 2>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+            else hipLaunchKernelGGL((stft_bluestein<false, 2>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+            break;
+        default:
+            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+            else hipLaunchKernelGGL((stft_bluestein<false, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
+        }
         return 0;
     }
     // (its stores are 8 / 16 bytes wide: a caller's map that is only float-aligned -- rt_spectrogram allows it -- takes the radix-2 kernel)
@@ -349,8 +365,20 @@ int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_se
     g.tail = tail;
     const int blocks = h->cfg.n_streams * ((n_seg + g.segs_per_block - 1) / g.segs_per_block);
     const size_t lds = (size_t)g.segs_per_block * h->N * sizeof(cf);
-    if (u8) hipLaunchKernelGGL(stft_general<true>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
-    else hipLaunchKernelGGL(stft_general<false>, dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+    if (h->N >= 8192) {  // (stft_big: a segment per workgroup, samples in registers until the mean is known, padded LDS)
+        const unsigned nb = (unsigned)(h->cfg.n_streams * n_seg);
+        const size_t big_lds = (size_t)padded_len(h->N, h->log2n) * sizeof(cf);
+        if (h->N == 8192) {
+            if (u8) hipLaunchKernelGGL((stft_big<true, 32>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
+            else hipLaunchKernelGGL((stft_big<false, 32>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
+        } else {
+            if (u8) hipLaunchKernelGGL((stft_big<true, 64>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
+            else hipLaunchKernelGGL((stft_big<false, 64>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
+        }
+    } else {
+        if (u8) hipLaunchKernelGGL((stft_general<true, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+        else hipLaunchKernelGGL((stft_general<false, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+    }
     return 0;
 }
 
@@ -1275,10 +1303,16 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             RT_CREATE_HIP(hipMalloc(&h->d_tws, sizeof(cf) * tws.size()));
             RT_CREATE_HIP(hipMemcpy(h->d_tws, tws.data(), sizeof(cf) * tws.size(), hipMemcpyHostToDevice));
         }
-        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
-        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_general<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
-        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bluestein<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
-        RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bluestein<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralMaxN * (int)sizeof(cf)));
+        {
+            const void *big_lds[] = {reinterpret_cast<const void *>(stft_general<false, 1>), reinterpret_cast<const void *>(stft_general<true, 1>),
+                                     reinterpret_cast<const void *>(stft_big<false, 32>), reinterpret_cast<const void *>(stft_big<true, 32>),
+                                     reinterpret_cast<const void *>(stft_big<false, 64>), reinterpret_cast<const void *>(stft_big<true, 64>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 1>), reinterpret_cast<const void *>(stft_bluestein<true, 1>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 2>), reinterpret_cast<const void *>(stft_bluestein<true, 2>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 4>), reinterpret_cast<const void *>(stft_bluestein<true, 4>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 8>), reinterpret_cast<const void *>(stft_bluestein<true, 8>)};
+            for (const void *f : big_lds) RT_CREATE_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, padded_len(kGeneralMaxN, 14) * (int)sizeof(cf)));
+        }
         if (h->bluestein) {
             // chirp w[n] = exp(-i pi n^2 / N) (the exponent reduced mod 2 N in integers); the window (times sqrt(scale), as every scan
             // takes it) times the chirp; the filter conj(w) on -N < m < N, wrapped to length M, its transform in double precision
@@ -1332,8 +1366,13 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                         }
                 }
             }
+            // kept in bit-reversed order: the kernel's first transform (decimation in frequency) leaves its values in that order
             std::vector<cf> bf((size_t)M);
-            for (int m = 0; m < M; ++m) bf[(size_t)m] = cf{(float)(br[(size_t)m] / M), (float)(bi[(size_t)m] / M)};
+            for (int i = 0; i < M; ++i) {
+                unsigned r = 0;
+                for (int b = 0; b < h->log2n; ++b) r |= ((unsigned)(i >> b) & 1u) << (h->log2n - 1 - b);
+                bf[(size_t)i] = cf{(float)(br[(size_t)r] / M), (float)(bi[(size_t)r] / M)};
+            }
             RT_CREATE_HIP(hipMalloc(&h->d_cwin, sizeof(cf) * cwin.size()));
             RT_CREATE_HIP(hipMemcpy(h->d_cwin, cwin.data(), sizeof(cf) * cwin.size(), hipMemcpyHostToDevice));
             RT_CREATE_HIP(hipMalloc(&h->d_bfilt, sizeof(cf) * bf.size()));

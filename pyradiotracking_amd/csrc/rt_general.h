@@ -43,14 +43,46 @@ constexpr int kGeneralMaxN = 16384;  // 128 KiB of LDS for one segment
 // natural order out), two stages per barrier: a thread takes the four elements base + {0, h, 2 h, 3 h} (h = the first stage's
 // half-span) through both -- half the LDS traffic and barriers of a stage at a time.  An odd log2 N starts with one stage alone
 // (span 2: no twiddle).  Called by all threads of the workgroup (barriers inside); `live` threads (lt of TPS per segment) work.
-__device__ __forceinline__ void lds_fft_stages(cf *xs, int N, int LOG, const cf *tw, int lt, int TPS, bool live) {
+// U: groups a thread takes through a double stage AT ONCE -- their twiddle loads (global memory), their LDS reads, then the arithmetic
+// and the writes: with one group per trip (the first version) the eight to sixteen trips of a thread at nperseg 8192 / 16 384 each waited
+// for their own table loads and LDS reads, one latency after the other with two waves per SIMD to hide it.  N / 4 must be a multiple
+// of TPS * U (the host picks U = min(8, N / 1024) where a workgroup holds one segment, 1 otherwise).
+// U > 1 (N >= 2048): the twiddles come from two small LDS tables the caller stages once (fft_stage_tables: W_N^(64 j) and W_N^j, j < 64)
+// -- W_N^m = hi[m / 64] * lo[m % 64], one more rounding of ~6e-8 where m is not a multiple of 64 (the late stages), none where it is.
+// Read from the global table, every double stage was sixteen gathers per thread with a cache line per lane: the address path of the CU
+// took longer than the butterflies (nperseg 8192: 72 k -> 88 k MS/s with the batching alone, -> see EXPERIMENTS.md with the tables).
+constexpr int kTwSplit = 64;
+__device__ __forceinline__ void fft_stage_tables(cf *hi, cf *lo, const cf *tw, int N, int tid, int nthreads) {
+    for (int j = tid; j < N / 2 / kTwSplit; j += nthreads) hi[j] = tw[j * kTwSplit];
+    for (int j = tid; j < kTwSplit; j += nthreads) lo[j] = tw[j];
+}
+// Padding: element i lives at pad_at(i, ps) = i + (i >> ps) with ps = log2 N - 6 (pad_shift) -- one spare place per N / 64 elements.  At
+// bit-reversed places the 64 lanes of a wave, neighbours in the segment, lie N / 64 elements apart: unpadded, every ds_write / ds_read of
+// the input scatter met in ONE bank pair, 64 cycles each; padded, neighbouring lanes land 8 bytes further on and a half-wave covers the
+// 64 banks.  N + N / 2^ps + 1 places.  ps = 31: no padding (stft_general's small sizes, several segments per workgroup).
+__device__ __forceinline__ int pad_at(int i, int ps) { return i + (i >> ps); }
+__host__ __device__ constexpr int pad_shift(int log2n) { return log2n - 6 < 2 ? 2 : log2n - 6; }
+__host__ __device__ constexpr int padded_len(int n, int log2n) { return n + (n >> pad_shift(log2n)) + 1; }
+template <int U>
+__device__ __forceinline__ void lds_fft_stages(cf *xs, int N, int LOG, const cf *tw, int lt, int TPS, bool live, const cf *hi = nullptr, const cf *lo = nullptr, int ps = 31) {
+    auto at = [ps](int i) { return pad_at(i, ps); };
     int st = 1;
     if (LOG & 1) {
         if (live) {
-            for (int b = lt; b < N / 2; b += TPS) {
-                const cf u = xs[2 * b], v = xs[2 * b + 1];
-                xs[2 * b] = cadd(u, v);
-                xs[2 * b + 1] = csub(u, v);
+            for (int b0 = lt; b0 < N / 2; b0 += TPS * U) {
+                cf u[U], v[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int b = b0 + j * TPS;
+                    u[j] = xs[at(2 * b)];
+                    v[j] = xs[at(2 * b + 1)];
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int b = b0 + j * TPS;
+                    xs[at(2 * b)] = cadd(u[j], v[j]);
+                    xs[at(2 * b + 1)] = csub(u[j], v[j]);
+                }
             }
         }
         __syncthreads();
@@ -61,32 +93,123 @@ __device__ __forceinline__ void lds_fft_stages(cf *xs, int N, int LOG, const cf 
         const int step1 = N >> st;        // W_(2 h)^k = W_N^(k N / (2 h))
         const int step2 = N >> (st + 1);  // W_(4 h)^k = W_N^(k N / (4 h))
         if (live) {
-            for (int g = lt; g < N / 4; g += TPS) {
-                const int k = g & (h - 1);
-                const int i0 = ((g >> (st - 1)) << (st + 1)) | k;
-                const cf w1 = tw[k * step1], w2 = tw[k * step2];
-                const cf a0 = xs[i0], a1 = cmul(xs[i0 + h], w1), a2 = xs[i0 + 2 * h], a3 = cmul(xs[i0 + 3 * h], w1);
-                const cf b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);  // stage st: pairs (0, h), (2 h, 3 h)
-                const cf c2 = cmul(b2, w2);
-                const cf c3 = mul_mi(cmul(b3, w2));  // W_(4 h)^(k + h) = -i W_(4 h)^k
-                xs[i0] = cadd(b0, c2);               // stage st + 1: pairs (0, 2 h), (h, 3 h)
-                xs[i0 + 2 * h] = csub(b0, c2);
-                xs[i0 + h] = cadd(b1, c3);
-                xs[i0 + 3 * h] = csub(b1, c3);
+            for (int g0 = lt; g0 < N / 4; g0 += TPS * U) {
+                int i0[U];
+                cf w1[U], w2[U], x0[U], x1[U], x2[U], x3[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int g = g0 + j * TPS;
+                    const int k = g & (h - 1);
+                    i0[j] = ((g >> (st - 1)) << (st + 1)) | k;
+                    if constexpr (U == 1) {
+                        w1[j] = tw[k * step1];
+                        w2[j] = tw[k * step2];
+                    } else {
+                        const int m1 = k * step1, m2 = k * step2;
+                        w1[j] = hi[m1 / kTwSplit];
+                        w2[j] = hi[m2 / kTwSplit];
+                        if (step1 % kTwSplit) w1[j] = cmul(w1[j], lo[m1 % kTwSplit]);  // (uniform: the late stages)
+                        if (step2 % kTwSplit) w2[j] = cmul(w2[j], lo[m2 % kTwSplit]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    x0[j] = xs[at(i0[j])];
+                    x1[j] = xs[at(i0[j] + h)];
+                    x2[j] = xs[at(i0[j] + 2 * h)];
+                    x3[j] = xs[at(i0[j] + 3 * h)];
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const cf a0 = x0[j], a1 = cmul(x1[j], w1[j]), a2 = x2[j], a3 = cmul(x3[j], w1[j]);
+                    const cf b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);  // stage st: pairs (0, h), (2 h, 3 h)
+                    const cf c2 = cmul(b2, w2[j]);
+                    const cf c3 = mul_mi(cmul(b3, w2[j]));  // W_(4 h)^(k + h) = -i W_(4 h)^k
+                    xs[at(i0[j])] = cadd(b0, c2);               // stage st + 1: pairs (0, 2 h), (h, 3 h)
+                    xs[at(i0[j] + 2 * h)] = csub(b0, c2);
+                    xs[at(i0[j] + h)] = cadd(b1, c3);
+                    xs[at(i0[j] + 3 * h)] = csub(b1, c3);
+                }
             }
         }
         __syncthreads();
     }
 }
 
-template <bool U8>
+// The same transform by decimation in FREQUENCY: natural order in, bit-reversed order out -- the mirror image of lds_fft_stages (the
+// double stages in descending order, half-spans 2 h then h, twiddles behind the differences; an odd log2 N ends with the span-2 stage).
+// A forward DIF transform, a pointwise product with a table kept in bit-reversed order and the DIT transform above make a circular
+// convolution without a single access at bit-reversed places (stft_bluestein).
+template <int U>
+__device__ __forceinline__ void lds_fft_stages_dif(cf *xs, int N, int LOG, const cf *tw, int lt, int TPS, const cf *hi, const cf *lo) {
+    const int first = (LOG & 1) ? 2 : 1;
+    int st = first;
+    while (st + 2 < LOG) st += 2;  // the DIT loop's last double stage
+    for (; st >= first; st -= 2) {
+        const int h = 1 << (st - 1);
+        const int step1 = N >> st;        // W_(2 h)^k
+        const int step2 = N >> (st + 1);  // W_(4 h)^k
+        for (int g0 = lt; g0 < N / 4; g0 += TPS * U) {
+            int i0[U];
+            cf w1[U], w2[U], x0[U], x1[U], x2[U], x3[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int g = g0 + j * TPS;
+                const int k = g & (h - 1);
+                i0[j] = ((g >> (st - 1)) << (st + 1)) | k;
+                if constexpr (U == 1) {
+                    w1[j] = tw[k * step1];
+                    w2[j] = tw[k * step2];
+                } else {
+                    const int m1 = k * step1, m2 = k * step2;
+                    w1[j] = hi[m1 / kTwSplit];
+                    w2[j] = hi[m2 / kTwSplit];
+                    if (step1 % kTwSplit) w1[j] = cmul(w1[j], lo[m1 % kTwSplit]);
+                    if (step2 % kTwSplit) w2[j] = cmul(w2[j], lo[m2 % kTwSplit]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                x0[j] = xs[i0[j]];
+                x1[j] = xs[i0[j] + h];
+                x2[j] = xs[i0[j] + 2 * h];
+                x3[j] = xs[i0[j] + 3 * h];
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                // half-span 2 h: pairs (0, 2 h), (h, 3 h); W_(4 h)^(k + h) = -i W_(4 h)^k
+                const cf y0 = cadd(x0[j], x2[j]), y2 = cmul(csub(x0[j], x2[j]), w2[j]);
+                const cf y1 = cadd(x1[j], x3[j]), y3 = cmul(mul_mi(csub(x1[j], x3[j])), w2[j]);
+                // half-span h: pairs (0, h), (2 h, 3 h)
+                xs[i0[j]] = cadd(y0, y1);
+                xs[i0[j] + h] = cmul(csub(y0, y1), w1[j]);
+                xs[i0[j] + 2 * h] = cadd(y2, y3);
+                xs[i0[j] + 3 * h] = cmul(csub(y2, y3), w1[j]);
+            }
+        }
+        __syncthreads();
+    }
+    if (LOG & 1) {
+        for (int b = lt; b < N / 2; b += TPS) {
+            const cf u = xs[2 * b], v = xs[2 * b + 1];
+            xs[2 * b] = cadd(u, v);
+            xs[2 * b + 1] = csub(u, v);
+        }
+        __syncthreads();
+    }
+}
+
+template <bool U8, int U = 1>
 __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParams p) {
+    constexpr int LB = (U == 1) ? 1 : 4 * U;  // elements of a thread per trip of the element-wise loops (N / TPS is a multiple of 4 U)
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
     cf *const x = reinterpret_cast<cf *>(gen_smem);                       // [SPB][N]
     __shared__ double red[2 * kGeneralBlock];                              // partial sums of the segment means
+    __shared__ cf tw_hi[U > 1 ? kGeneralMaxN / 2 / kTwSplit : 1], tw_lo[U > 1 ? kTwSplit : 1];
     const int N = p.nperseg, LOG = p.log2n, SPB = p.segs_per_block, T = p.n_seg;
     const int tid = threadIdx.x;
+    if constexpr (U > 1) fft_stage_tables(tw_hi, tw_lo, p.tw, N, tid, kGeneralBlock);  // (read behind the barriers below)
     const int blocks_per_stream = (T + SPB - 1) / SPB;
     const int s = blockIdx.x / blocks_per_stream;
     const int seg0 = (blockIdx.x % blocks_per_stream) * SPB;
@@ -104,11 +227,17 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
     // percent of what the detrend leaves in bin 0 -- the exact sum, rounded once, stays within NumPy's own error)
     double sx = 0.0, sy = 0.0;
     if (live) {
-        for (int n = lt; n < N; n += TPS) {
-            const cf v = to_cf(load_iq(src + (int64_t)q * N + n));
-            sx += (double)v.x;
-            sy += (double)v.y;
-            xs[__brev((unsigned)n) >> (32 - LOG)] = v;
+        for (int n0 = lt; n0 < N; n0 += TPS * LB) {
+            raw_t raw[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) raw[j] = load_iq(src + (int64_t)q * N + n0 + j * TPS);
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const cf v = to_cf(raw[j]);
+                sx += (double)v.x;
+                sy += (double)v.y;
+                xs[__brev((unsigned)(n0 + j * TPS)) >> (32 - LOG)] = v;
+            }
         }
     }
     red[2 * tid] = sx;
@@ -123,26 +252,109 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
     const float mx = (float)(mxd / (double)N), my = (float)(myd / (double)N);
     // detrend='constant' (scipy _signaltools.py:3926), then the window (times sqrt(scale): the power needs no further factor)
     if (live) {
-        for (int n = lt; n < N; n += TPS) {
-            const int at = (int)(__brev((unsigned)n) >> (32 - LOG));
-            const cf v = xs[at];
-            const float w = p.window[n];
-            xs[at] = cf{(v.x - mx) * w, (v.y - my) * w};
+        for (int n0 = lt; n0 < N; n0 += TPS * LB) {
+            float w[LB];
+            cf v[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) w[j] = p.window[n0 + j * TPS];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) v[j] = xs[__brev((unsigned)(n0 + j * TPS)) >> (32 - LOG)];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) xs[__brev((unsigned)(n0 + j * TPS)) >> (32 - LOG)] = cf{(v[j].x - mx) * w[j], (v[j].y - my) * w[j]};
         }
     }
     __syncthreads();
-    lds_fft_stages(xs, N, LOG, p.tw, lt, TPS, live);
+    lds_fft_stages<U>(xs, N, LOG, p.tw, lt, TPS, live, tw_hi, tw_lo);
     // |X|^2 (scipy _spectral_py.py:2126-2128) -> the dense map and, for the last K segments, the look-back tail
     if (live) {
         const int seg = seg0 + q;
         float *dst = p.spec + ((int64_t)s * T + seg) * N;
         const int col = seg - (T - p.tail_cols);
         float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
-        for (int k = lt; k < N; k += TPS) {
-            const cf v = xs[k];
-            const float pw = __builtin_fmaf(v.x, v.x, v.y * v.y);
-            dst[k] = pw;
-            if (tdst) tdst[k] = pw;
+        for (int k0 = lt; k0 < N; k0 += TPS * LB) {
+            cf v[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) v[j] = xs[k0 + j * TPS];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const float pw = __builtin_fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
+                dst[k0 + j * TPS] = pw;
+                if (tdst) tdst[k0 + j * TPS] = pw;
+            }
+        }
+    }
+}
+
+// nperseg 8192 / 16 384 (N = 256 PT, PT = 32 / 64): one segment per workgroup, like stft_general at these sizes, without its three
+// passes over bit-reversed places.  There a thread's samples went to LDS raw, came back for detrend and window and went out again --
+// and at bit-reversed places the 64 lanes of a wave, neighbours in the segment, lie N / 64 elements apart: every one of those
+// ds_write / ds_read instructions met in ONE bank pair, 64 cycles each, more than half of the kernel's LDS time (the butterflies'
+// seven double stages are the rest).  Here the samples stay in registers (PT per thread) until the mean is known, detrend and window
+// happen there, and the single scatter goes to padded places (pad_at).
+template <bool U8, int PT>
+__global__ __launch_bounds__(kGeneralBlock) void stft_big(const GeneralParams p) {
+    using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
+    constexpr int N = 256 * PT, LOG = (PT == 32) ? 13 : 14, U = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    cf *const xs = reinterpret_cast<cf *>(big_smem);  // [padded_len(N, LOG)]
+    constexpr int PS = pad_shift(LOG);
+    __shared__ double red[2 * 4];
+    __shared__ cf tw_hi[N / 2 / kTwSplit], tw_lo[kTwSplit];
+    const int T = p.n_seg, tid = threadIdx.x;
+    fft_stage_tables(tw_hi, tw_lo, p.tw, N, tid, kGeneralBlock);
+    const int s = blockIdx.x / T, seg = blockIdx.x % T;
+    if (s >= p.n_streams) return;
+    const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride + (int64_t)seg * N;
+    raw_t raw[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) raw[j] = load_iq(src + tid + 256 * j);
+    // the segment's mean from a float64 sum (stft_general: why), in a fixed order: a thread's samples, the wave's lanes by
+    // butterflies, the four waves
+    double sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const cf v = to_cf(raw[j]);
+        sx += (double)v.x;
+        sy += (double)v.y;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        sx += __shfl_xor(sx, d);
+        sy += __shfl_xor(sy, d);
+    }
+    if ((tid & 63) == 0) {
+        red[2 * (tid >> 6)] = sx;
+        red[2 * (tid >> 6) + 1] = sy;
+    }
+    __syncthreads();
+    const float mx = (float)((((red[0] + red[2]) + red[4]) + red[6]) / (double)N), my = (float)((((red[1] + red[3]) + red[5]) + red[7]) / (double)N);
+    // detrend='constant' (scipy _signaltools.py:3926), window (times sqrt(scale)), to the bit-reversed place
+#pragma unroll
+    for (int j0 = 0; j0 < PT; j0 += 16) {
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = p.window[tid + 256 * (j0 + j)];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const cf v = to_cf(raw[j0 + j]);
+            xs[pad_at((int)(__brev((unsigned)(tid + 256 * (j0 + j))) >> (32 - LOG)), PS)] = cf{(v.x - mx) * w[j], (v.y - my) * w[j]};
+        }
+    }
+    __syncthreads();
+    lds_fft_stages<U>(xs, N, LOG, p.tw, tid, kGeneralBlock, true, tw_hi, tw_lo, PS);
+    float *dst = p.spec + ((int64_t)s * T + seg) * N;
+    const int col = seg - (T - p.tail_cols);
+    float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
+#pragma unroll
+    for (int j0 = 0; j0 < PT; j0 += 16) {
+        cf v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = xs[pad_at(tid + 256 * (j0 + j), PS)];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float pw = __builtin_fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
+            dst[tid + 256 * (j0 + j)] = pw;
+            if (tdst) tdst[tid + 256 * (j0 + j)] = pw;
         }
     }
 }
@@ -315,63 +527,60 @@ struct BluesteinParams {
     int64_t stream_stride;
     int32_t n_streams, n_seg, nperseg, m, log2m, tail_cols;
     const cf *cwin;   // [N] window * sqrt(scale) * w[n]
-    const cf *bfilt;  // [M] FFT_M of the filter, divided by M
+    const cf *bfilt;  // [M] FFT_M of the filter, divided by M, in BIT-REVERSED order (entry i = the transform's value at rev i)
     const cf *tw;     // [M / 2] W_M^j
     float *spec, *tail;
 };
 
-template <bool U8>
+template <bool U8, int U = 1>
 __global__ __launch_bounds__(kGeneralBlock) void stft_bluestein(const BluesteinParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char blu_smem[];
     cf *const xs = reinterpret_cast<cf *>(blu_smem);  // [M]
-    __shared__ double red[2 * kGeneralBlock];
+    __shared__ double red[2 * 4];
+    __shared__ cf tw_hi[U > 1 ? kGeneralMaxN / 2 / kTwSplit : 1], tw_lo[U > 1 ? kTwSplit : 1];
     const int N = p.nperseg, M = p.m, LOG = p.log2m, T = p.n_seg;
     const int tid = threadIdx.x;
+    if constexpr (U > 1) fft_stage_tables(tw_hi, tw_lo, p.tw, M, tid, kGeneralBlock);
     const int s = blockIdx.x / T, seg = blockIdx.x % T;
     if (s >= p.n_streams) return;
     const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride + (int64_t)seg * N;
-    // zero padding, then the samples (bit-reversed places of the length-M transform) and their sum
-    for (int j = tid; j < M; j += kGeneralBlock) xs[j] = cf{0.f, 0.f};
-    __syncthreads();
+    // the samples' sum (float64, a fixed order: a thread's samples, the wave's lanes by butterflies, the four waves); zero padding
+    for (int j = N + tid; j < M; j += kGeneralBlock) xs[j] = cf{0.f, 0.f};
     double sx = 0.0, sy = 0.0;
     for (int n = tid; n < N; n += kGeneralBlock) {
         const cf v = to_cf(load_iq(src + n));
         sx += (double)v.x;
         sy += (double)v.y;
-        xs[__brev((unsigned)n) >> (32 - LOG)] = v;
     }
-    red[2 * tid] = sx;
-    red[2 * tid + 1] = sy;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        sx += __shfl_xor(sx, d);
+        sy += __shfl_xor(sy, d);
+    }
+    if ((tid & 63) == 0) {
+        red[2 * (tid >> 6)] = sx;
+        red[2 * (tid >> 6) + 1] = sy;
+    }
     __syncthreads();
-    double mxd = 0.0, myd = 0.0;
-    for (int j = 0; j < kGeneralBlock; ++j) {
-        mxd += red[2 * j];
-        myd += red[2 * j + 1];
-    }
-    const float mx = (float)(mxd / (double)N), my = (float)(myd / (double)N);
-    // (x - mean) * window * sqrt(scale) * w[n]
+    const float mx = (float)((((red[0] + red[2]) + red[4]) + red[6]) / (double)N), my = (float)((((red[1] + red[3]) + red[5]) + red[7]) / (double)N);
+    // (x - mean) * window * sqrt(scale) * w[n], natural order (the samples a second time, from L2)
     for (int n = tid; n < N; n += kGeneralBlock) {
-        const int at = (int)(__brev((unsigned)n) >> (32 - LOG));
-        const cf v = xs[at];
-        xs[at] = cmul(cf{v.x - mx, v.y - my}, p.cwin[n]);
+        const cf v = to_cf(load_iq(src + n));
+        xs[n] = cmul(cf{v.x - mx, v.y - my}, p.cwin[n]);
     }
     __syncthreads();
-    lds_fft_stages(xs, M, LOG, p.tw, tid, kGeneralBlock, true);  // A, natural order
-    // conj(A * B) to bit-reversed places, in place: the pair (j, rev j) is one thread's
+    // No access at bit-reversed places anywhere (the first version scattered the samples there, came back for the window, and swapped
+    // pairs (j, rev j) between the transforms: at those places the 64 lanes of a wave meet in one LDS bank pair -- more than half of the
+    // kernel's LDS time): A by decimation in frequency, natural order in, bit-reversed out; the filter's transform is kept in that
+    // order; conj(A * B) in place; decimation in time takes bit-reversed input back to natural order.
+    lds_fft_stages_dif<U>(xs, M, LOG, p.tw, tid, kGeneralBlock, tw_hi, tw_lo);
     for (int j = tid; j < M; j += kGeneralBlock) {
-        const int r = (int)(__brev((unsigned)j) >> (32 - LOG));
-        if (j < r) {
-            const cf cj = cmul(xs[j], p.bfilt[j]), cr = cmul(xs[r], p.bfilt[r]);
-            xs[j] = cf{cr.x, -cr.y};
-            xs[r] = cf{cj.x, -cj.y};
-        } else if (j == r) {
-            const cf cj = cmul(xs[j], p.bfilt[j]);
-            xs[j] = cf{cj.x, -cj.y};
-        }
+        const cf c = cmul(xs[j], p.bfilt[j]);
+        xs[j] = cf{c.x, -c.y};
     }
     __syncthreads();
-    lds_fft_stages(xs, M, LOG, p.tw, tid, kGeneralBlock, true);  // FFT(conj(C)): its first N values have the spectrum's magnitudes
+    lds_fft_stages<U>(xs, M, LOG, p.tw, tid, kGeneralBlock, true, tw_hi, tw_lo);  // FFT(conj(C)): its first N values have the spectrum's magnitudes
     float *dst = p.spec + ((int64_t)s * T + seg) * N;
     const int col = seg - (T - p.tail_cols);
     float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
