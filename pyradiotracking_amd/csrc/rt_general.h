@@ -1,5 +1,5 @@
 // rt_general.h -- the spectrogram for every nperseg the fused scans do not cover: 32 / 64 / 128 in registers (stft_small), the other
-// powers of two in LDS (stft_general) and, by Bluestein's algorithm, everything else (stft_bluestein).
+// powers of two in LDS (stft_general: 8 and 16; stft_big: 8192 and 16 384) and, by Bluestein's algorithm, everything else (stft_bluestein).
 //
 // The reference hands `fft_nperseg` straight to scipy.signal.spectrogram (radiotracking/__main__.py:59,
 // analyze.py:234-241): any integer.  The fused scans (rt_kernels.h, rt_scan64.h) exist for 256 .. 4096; every other
