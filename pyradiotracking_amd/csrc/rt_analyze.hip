@@ -303,23 +303,20 @@ int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_se
         const int blocks = h->cfg.n_streams * n_seg;
         const size_t lds = (size_t)h->gen_m * sizeof(cf);
         // (groups of a thread per trip of a double stage: rt_general.h, lds_fft_stages -- M / 4 a multiple of 256 U)
-        switch (std::min(8, h->gen_m / 1024)) {
-        case 8:
-            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 8>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-            else hipLaunchKernelGGL((stft_bluestein<false, 8>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-            break;
-        case 4:
-            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 4>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-            else hipLaunchKernelGGL((stft_bluestein<false, 4>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-            break;
-        case 2:
-            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 2>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-            else hipLaunchKernelGGL((stft_bluestein<false, 2>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-            break;
-        default:
-            if (u8) hipLaunchKernelGGL((stft_bluestein<true, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-            else hipLaunchKernelGGL((stft_bluestein<false, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, b);
-        }
+        // threads per workgroup and groups of a thread per trip of a double stage (rt_general.h, lds_fft_stages: M / 4 a multiple of threads x U).
+        // From M = 4096 on 512 threads, at 16 384 (one workgroup per CU) 1 024: more waves to cover the LDS latency of the stages
+        // where LDS leaves room for one or two workgroups per CU (16 384: 512 threads 27.4 k MS/s at nperseg 6000, 1 024 34 k).
+#define RT_BLU(U_, B_)                                                                                                            \
+    do {                                                                                                                          \
+        if (u8) hipLaunchKernelGGL((stft_bluestein<true, U_, B_>), dim3(blocks), dim3(B_), lds, h->s_scan, b);                     \
+        else hipLaunchKernelGGL((stft_bluestein<false, U_, B_>), dim3(blocks), dim3(B_), lds, h->s_scan, b);                       \
+    } while (0)
+        if (h->gen_m >= 16384) RT_BLU(4, 1024);
+        else if (h->gen_m >= 8192) RT_BLU(4, 512);  // (8 groups x 256 threads: 31.8 k MS/s at nperseg 3000, this 41.6 k)
+        else if (h->gen_m >= 4096) RT_BLU(2, 512);  // (4 x 256: 47.9 k at nperseg 1500, this 51.2 k)
+        else if (h->gen_m >= 2048) RT_BLU(2, 256);  // (1 x 512: 56.7 k at nperseg 1000, this 72 k -- enough workgroups per CU as it is)
+        else RT_BLU(1, 256);
+#undef RT_BLU
         return 0;
     }
     // (its stores are 8 / 16 bytes wide: a caller's map that is only float-aligned -- rt_spectrogram allows it -- takes the radix-2 kernel)
@@ -369,11 +366,12 @@ int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_se
         const unsigned nb = (unsigned)(h->cfg.n_streams * n_seg);
         const size_t big_lds = (size_t)padded_len(h->N, h->log2n) * sizeof(cf);
         if (h->N == 8192) {
-            if (u8) hipLaunchKernelGGL((stft_big<true, 32>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
-            else hipLaunchKernelGGL((stft_big<false, 32>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
+            if (u8) hipLaunchKernelGGL((stft_big<true, 16, 512>), dim3(nb), dim3(512), big_lds, h->s_scan, g);
+            else hipLaunchKernelGGL((stft_big<false, 16, 512>), dim3(nb), dim3(512), big_lds, h->s_scan, g);
         } else {
-            if (u8) hipLaunchKernelGGL((stft_big<true, 64>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
-            else hipLaunchKernelGGL((stft_big<false, 64>), dim3(nb), dim3(kGeneralBlock), big_lds, h->s_scan, g);
+            // (one workgroup per CU at 128 KiB of LDS: eight waves rather than four to cover the LDS latency of the double stages)
+            if (u8) hipLaunchKernelGGL((stft_big<true, 16, 1024>), dim3(nb), dim3(1024), big_lds, h->s_scan, g);
+            else hipLaunchKernelGGL((stft_big<false, 16, 1024>), dim3(nb), dim3(1024), big_lds, h->s_scan, g);
         }
     } else {
         if (u8) hipLaunchKernelGGL((stft_general<true, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
@@ -1305,12 +1303,13 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         }
         {
             const void *big_lds[] = {reinterpret_cast<const void *>(stft_general<false, 1>), reinterpret_cast<const void *>(stft_general<true, 1>),
-                                     reinterpret_cast<const void *>(stft_big<false, 32>), reinterpret_cast<const void *>(stft_big<true, 32>),
-                                     reinterpret_cast<const void *>(stft_big<false, 64>), reinterpret_cast<const void *>(stft_big<true, 64>),
-                                     reinterpret_cast<const void *>(stft_bluestein<false, 1>), reinterpret_cast<const void *>(stft_bluestein<true, 1>),
-                                     reinterpret_cast<const void *>(stft_bluestein<false, 2>), reinterpret_cast<const void *>(stft_bluestein<true, 2>),
-                                     reinterpret_cast<const void *>(stft_bluestein<false, 4>), reinterpret_cast<const void *>(stft_bluestein<true, 4>),
-                                     reinterpret_cast<const void *>(stft_bluestein<false, 8>), reinterpret_cast<const void *>(stft_bluestein<true, 8>)};
+                                     reinterpret_cast<const void *>(stft_big<false, 16, 512>), reinterpret_cast<const void *>(stft_big<true, 16, 512>),
+                                     reinterpret_cast<const void *>(stft_big<false, 16, 1024>), reinterpret_cast<const void *>(stft_big<true, 16, 1024>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 1, 256>), reinterpret_cast<const void *>(stft_bluestein<true, 1, 256>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 2, 256>), reinterpret_cast<const void *>(stft_bluestein<true, 2, 256>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 2, 512>), reinterpret_cast<const void *>(stft_bluestein<true, 2, 512>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 4, 512>), reinterpret_cast<const void *>(stft_bluestein<true, 4, 512>),
+                                     reinterpret_cast<const void *>(stft_bluestein<false, 4, 1024>), reinterpret_cast<const void *>(stft_bluestein<true, 4, 1024>)};
             for (const void *f : big_lds) RT_CREATE_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, padded_len(kGeneralMaxN, 14) * (int)sizeof(cf)));
         }
         if (h->bluestein) {

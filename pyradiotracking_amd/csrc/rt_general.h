@@ -291,23 +291,24 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
 // ds_write / ds_read instructions met in ONE bank pair, 64 cycles each, more than half of the kernel's LDS time (the butterflies'
 // seven double stages are the rest).  Here the samples stay in registers (PT per thread) until the mean is known, detrend and window
 // happen there, and the single scatter goes to padded places (pad_at).
-template <bool U8, int PT>
-__global__ __launch_bounds__(kGeneralBlock) void stft_big(const GeneralParams p) {
+template <bool U8, int PT, int BLK = kGeneralBlock>
+__global__ __launch_bounds__(BLK) void stft_big(const GeneralParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
-    constexpr int N = 256 * PT, LOG = (PT == 32) ? 13 : 14, U = 8;
+    constexpr int N = BLK * PT, LOG = (N == 8192) ? 13 : 14, U = (N / 4 / BLK < 8) ? N / 4 / BLK : 8, NW = BLK / 64;
+    static_assert(N == 8192 || N == 16384, "stft_big: nperseg 8192 or 16384");
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
     cf *const xs = reinterpret_cast<cf *>(big_smem);  // [padded_len(N, LOG)]
     constexpr int PS = pad_shift(LOG);
-    __shared__ double red[2 * 4];
+    __shared__ double red[2 * NW];
     __shared__ cf tw_hi[N / 2 / kTwSplit], tw_lo[kTwSplit];
     const int T = p.n_seg, tid = threadIdx.x;
-    fft_stage_tables(tw_hi, tw_lo, p.tw, N, tid, kGeneralBlock);
+    fft_stage_tables(tw_hi, tw_lo, p.tw, N, tid, BLK);
     const int s = blockIdx.x / T, seg = blockIdx.x % T;
     if (s >= p.n_streams) return;
     const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride + (int64_t)seg * N;
     raw_t raw[PT];
 #pragma unroll
-    for (int j = 0; j < PT; ++j) raw[j] = load_iq(src + tid + 256 * j);
+    for (int j = 0; j < PT; ++j) raw[j] = load_iq(src + tid + BLK * j);
     // the segment's mean from a float64 sum (stft_general: why), in a fixed order: a thread's samples, the wave's lanes by
     // butterflies, the four waves
     double sx = 0.0, sy = 0.0;
@@ -327,21 +328,27 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_big(const GeneralParams p)
         red[2 * (tid >> 6) + 1] = sy;
     }
     __syncthreads();
-    const float mx = (float)((((red[0] + red[2]) + red[4]) + red[6]) / (double)N), my = (float)((((red[1] + red[3]) + red[5]) + red[7]) / (double)N);
+    double tx = 0.0, ty = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) {
+        tx += red[2 * wv];
+        ty += red[2 * wv + 1];
+    }
+    const float mx = (float)(tx / (double)N), my = (float)(ty / (double)N);
     // detrend='constant' (scipy _signaltools.py:3926), window (times sqrt(scale)), to the bit-reversed place
 #pragma unroll
     for (int j0 = 0; j0 < PT; j0 += 16) {
         float w[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = p.window[tid + 256 * (j0 + j)];
+        for (int j = 0; j < 16; ++j) w[j] = p.window[tid + BLK * (j0 + j)];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const cf v = to_cf(raw[j0 + j]);
-            xs[pad_at((int)(__brev((unsigned)(tid + 256 * (j0 + j))) >> (32 - LOG)), PS)] = cf{(v.x - mx) * w[j], (v.y - my) * w[j]};
+            xs[pad_at((int)(__brev((unsigned)(tid + BLK * (j0 + j))) >> (32 - LOG)), PS)] = cf{(v.x - mx) * w[j], (v.y - my) * w[j]};
         }
     }
     __syncthreads();
-    lds_fft_stages<U>(xs, N, LOG, p.tw, tid, kGeneralBlock, true, tw_hi, tw_lo, PS);
+    lds_fft_stages<U>(xs, N, LOG, p.tw, tid, BLK, true, tw_hi, tw_lo, PS);
     float *dst = p.spec + ((int64_t)s * T + seg) * N;
     const int col = seg - (T - p.tail_cols);
     float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
@@ -349,12 +356,12 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_big(const GeneralParams p)
     for (int j0 = 0; j0 < PT; j0 += 16) {
         cf v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = xs[pad_at(tid + 256 * (j0 + j), PS)];
+        for (int j = 0; j < 16; ++j) v[j] = xs[pad_at(tid + BLK * (j0 + j), PS)];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float pw = __builtin_fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
-            dst[tid + 256 * (j0 + j)] = pw;
-            if (tdst) tdst[tid + 256 * (j0 + j)] = pw;
+            dst[tid + BLK * (j0 + j)] = pw;
+            if (tdst) tdst[tid + BLK * (j0 + j)] = pw;
         }
     }
 }
@@ -532,23 +539,24 @@ struct BluesteinParams {
     float *spec, *tail;
 };
 
-template <bool U8, int U = 1>
-__global__ __launch_bounds__(kGeneralBlock) void stft_bluestein(const BluesteinParams p) {
+template <bool U8, int U = 1, int BLK = kGeneralBlock>
+__global__ __launch_bounds__(BLK) void stft_bluestein(const BluesteinParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char blu_smem[];
     cf *const xs = reinterpret_cast<cf *>(blu_smem);  // [M]
-    __shared__ double red[2 * 4];
+    constexpr int NW = BLK / 64;
+    __shared__ double red[2 * NW];
     __shared__ cf tw_hi[U > 1 ? kGeneralMaxN / 2 / kTwSplit : 1], tw_lo[U > 1 ? kTwSplit : 1];
     const int N = p.nperseg, M = p.m, LOG = p.log2m, T = p.n_seg;
     const int tid = threadIdx.x;
-    if constexpr (U > 1) fft_stage_tables(tw_hi, tw_lo, p.tw, M, tid, kGeneralBlock);
+    if constexpr (U > 1) fft_stage_tables(tw_hi, tw_lo, p.tw, M, tid, BLK);
     const int s = blockIdx.x / T, seg = blockIdx.x % T;
     if (s >= p.n_streams) return;
     const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride + (int64_t)seg * N;
     // the samples' sum (float64, a fixed order: a thread's samples, the wave's lanes by butterflies, the four waves); zero padding
-    for (int j = N + tid; j < M; j += kGeneralBlock) xs[j] = cf{0.f, 0.f};
+    for (int j = N + tid; j < M; j += BLK) xs[j] = cf{0.f, 0.f};
     double sx = 0.0, sy = 0.0;
-    for (int n = tid; n < N; n += kGeneralBlock) {
+    for (int n = tid; n < N; n += BLK) {
         const cf v = to_cf(load_iq(src + n));
         sx += (double)v.x;
         sy += (double)v.y;
@@ -563,9 +571,15 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_bluestein(const BluesteinP
         red[2 * (tid >> 6) + 1] = sy;
     }
     __syncthreads();
-    const float mx = (float)((((red[0] + red[2]) + red[4]) + red[6]) / (double)N), my = (float)((((red[1] + red[3]) + red[5]) + red[7]) / (double)N);
+    double tx = 0.0, ty = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) {
+        tx += red[2 * wv];
+        ty += red[2 * wv + 1];
+    }
+    const float mx = (float)(tx / (double)N), my = (float)(ty / (double)N);
     // (x - mean) * window * sqrt(scale) * w[n], natural order (the samples a second time, from L2)
-    for (int n = tid; n < N; n += kGeneralBlock) {
+    for (int n = tid; n < N; n += BLK) {
         const cf v = to_cf(load_iq(src + n));
         xs[n] = cmul(cf{v.x - mx, v.y - my}, p.cwin[n]);
     }
@@ -574,17 +588,17 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_bluestein(const BluesteinP
     // pairs (j, rev j) between the transforms: at those places the 64 lanes of a wave meet in one LDS bank pair -- more than half of the
     // kernel's LDS time): A by decimation in frequency, natural order in, bit-reversed out; the filter's transform is kept in that
     // order; conj(A * B) in place; decimation in time takes bit-reversed input back to natural order.
-    lds_fft_stages_dif<U>(xs, M, LOG, p.tw, tid, kGeneralBlock, tw_hi, tw_lo);
-    for (int j = tid; j < M; j += kGeneralBlock) {
+    lds_fft_stages_dif<U>(xs, M, LOG, p.tw, tid, BLK, tw_hi, tw_lo);
+    for (int j = tid; j < M; j += BLK) {
         const cf c = cmul(xs[j], p.bfilt[j]);
         xs[j] = cf{c.x, -c.y};
     }
     __syncthreads();
-    lds_fft_stages<U>(xs, M, LOG, p.tw, tid, kGeneralBlock, true, tw_hi, tw_lo);  // FFT(conj(C)): its first N values have the spectrum's magnitudes
+    lds_fft_stages<U>(xs, M, LOG, p.tw, tid, BLK, true, tw_hi, tw_lo);  // FFT(conj(C)): its first N values have the spectrum's magnitudes
     float *dst = p.spec + ((int64_t)s * T + seg) * N;
     const int col = seg - (T - p.tail_cols);
     float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
-    for (int k = tid; k < N; k += kGeneralBlock) {
+    for (int k = tid; k < N; k += BLK) {
         const cf v = xs[k];
         const float pw = __builtin_fmaf(v.x, v.x, v.y * v.y);
         dst[k] = pw;

@@ -10,4 +10,6 @@ python3 bench.py $common --workload config5 --total-streams 512 --nperseg 8192 2
 python3 bench.py $common --workload config5 --total-streams 512 --nperseg 16384 2>/dev/null | line "3.2 MS/s nperseg 16384" | tee -a $out/bench.txt
 python3 bench.py $common --sample-rate 300000 --streams 4096 --nperseg 300 2>/dev/null | line "defaults nperseg 300 (Bluestein, M 1024)" | tee -a $out/bench.txt
 python3 bench.py $common --sample-rate 2400000 --streams 512 --nperseg 1000 2>/dev/null | line "2.4 MS/s nperseg 1000 (Bluestein, M 2048)" | tee -a $out/bench.txt
+python3 bench.py $common --sample-rate 2400000 --streams 512 --nperseg 1500 2>/dev/null | line "2.4 MS/s nperseg 1500 (Bluestein, M 4096)" | tee -a $out/bench.txt
+python3 bench.py $common --workload config5 --total-streams 256 --nperseg 3000 2>/dev/null | line "3.2 MS/s nperseg 3000 (Bluestein, M 8192)" | tee -a $out/bench.txt
 python3 bench.py $common --workload config5 --total-streams 256 --nperseg 6000 2>/dev/null | line "3.2 MS/s nperseg 6000 (Bluestein, M 16384)" | tee -a $out/bench.txt
