@@ -69,6 +69,11 @@ OTHER_CONFIGS = [
                                           noise_dbw=-88.0, settle=20,
                                           what="the reference's defaults (300 kS/s, nperseg 256, -90 dBW, 8-40 ms) with the noise floor at -88 dBW, 2 dB OVER "
                                                "the threshold (a real RTL-SDR): AUTO reaches the exact run-length pre-filter")),
+    # sizes outside the fused scans' 256 ... 4096 (csrc/rt_general.h; dense path: transform + detect_dense, 16 bytes per sample)
+    ("nperseg128_defaults", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=128, window="hamming", trains=False, lanes=1,
+                                 what="the reference's defaults at fft_nperseg 128: stft_small (registers, one wave-private exchange) on the dense path")),
+    ("nperseg8192", dict(streams=512, sample_rate=3200000, samples=3200000, nperseg=8192, window="hamming", trains=False, lanes=1,
+                         what="fft_nperseg 8192 at 3.2 MS/s: stft_big (radix-2 in LDS, one segment per workgroup) on the dense path")),
 ]
 
 
@@ -914,7 +919,10 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
     torch.cuda.empty_cache()
     kernel_ms = ms1 / iso
     two_scans = mode_used in ("prefilter", "runfilter")
-    scan_name = "stft_scan64" if nperseg == 4096 else "stft_scan"
+    scan_name = ("stft_scan64" if nperseg == 4096 else "stft_scan" if nperseg in (256, 512, 1024, 2048)
+                 else "stft_small (+ the dense map's round trip: frac is quoted against 8 B per sample like the rest)" if nperseg in (32, 64, 128)
+                 else "stft_big (+ the dense map's round trip: frac is quoted against 8 B per sample like the rest)" if nperseg in (8192, 16384)
+                 else "general transform")
     return {
         "name": name,
         "workload": f"{S} streams x {fs} SPS x {blen} samples complex64, nperseg {nperseg} {spec['window']}, "
