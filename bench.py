@@ -65,7 +65,7 @@ OTHER_CONFIGS = [
                      what="BASELINE config 4, all 32 768 streams on one GPU at B = 524 288 (137 GB resident): the N = 1 point of north_star's sharded curve")),
     ("config5_share", dict(streams=1024, sample_rate=3200000, samples=3200000, nperseg=4096, window="hamming", trains=True, lanes=1,
                            what="BASELINE config 5, the 1 024-stream share one GPU of eight analyses (tag trains)")),
-    ("default_geometry_noise_floor", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=256, window="hamming", trains=False, lanes=2,
+    ("default_geometry_noise_floor", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=256, window="hamming", trains=False, lanes=3,
                                           noise_dbw=-88.0, settle=20,
                                           what="the reference's defaults (300 kS/s, nperseg 256, -90 dBW, 8-40 ms) with the noise floor at -88 dBW, 2 dB OVER "
                                                "the threshold (a real RTL-SDR): AUTO reaches the exact run-length pre-filter")),
@@ -114,7 +114,7 @@ def parse():
                          "launches after idle to settle (0.85 -> 0.77 ms per scan launch), whatever W the caller picks")
     ap.add_argument("--lanes", type=int, default=None,
                     help="stream groups per GPU, each on its own handle / HIP stream (detect of one group overlaps the "
-                         "scan of the other); 1 = one launch sequence per step.  Default: 2 up to nperseg 512 (1 from 16 384 streams per GPU on), 1 from "
+                         "scan of the other); 1 = one launch sequence per step.  Default: 3 up to nperseg 512 (1 from 16 384 streams per GPU on), 1 from "
                          "nperseg 1024 on (those scans are chip-filling grids of persistent workgroups: a second lane's "
                          "kernels wait behind them -- config 3: 650 k with two lanes, 676 k with one)")
     ap.add_argument("--isolated-steps", type=int, default=50,
@@ -157,10 +157,12 @@ def resolve_workload(args, world):
     by_geometry = {(v["sample_rate"], v["nperseg"], v["window"], v["samples"], v["trains"]): k for k, v in WORKLOADS.items()}
     w["name"] = by_geometry.get((w["sample_rate"], w["nperseg"], w["window"], w["samples"], w["trains"]), "custom")
     if getattr(args, "lanes", 0) is None:
-        # two lanes up to nperseg 512 -- while a rank's launches are small enough to have ends worth filling: at config-4 geometry
-        # +2 ... +3 % up to 8 192 streams, equal at 16 384, -3 % with all 32 768 on one GPU (profiles/r05_n_lanes_by_batch_size.txt)
+        # three lanes up to nperseg 512 -- while a rank's launches are small enough to have ends worth filling: at config-4 geometry
+        # two lanes +2 ... +3 % over one up to 8 192 streams, equal at 16 384, -3 % with all 32 768 on one GPU; three over two +1.5 %
+        # at config 2, +3 ... 5 % at 1 024 streams, -0.7 ... +2 % at 4 096, +1 % at 8 192, and +3 ... 4 % on the reference's defaults
+        # under a noise floor; four lanes -16 % at config 2 (profiles/r05_n_lanes_by_batch_size.txt)
         per_rank = w["streams"] if "streams" in w else -(-w["total"] // max(1, world))
-        args.lanes = 2 if (w["nperseg"] <= 512 and per_rank < 16384) else 1
+        args.lanes = 3 if (w["nperseg"] <= 512 and per_rank < 16384) else 1
     return w
 
 

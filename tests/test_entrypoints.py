@@ -79,9 +79,9 @@ def test_bench_workloads_follow_baseline_configs():
     assert (w["name"], w["samples"]) == ("config4", 524288)
     w = bench.resolve_workload(ns(nperseg=512), 1)
     assert w["name"] == "custom"
-    # lanes per GPU when the caller does not say: two up to nperseg 512 while a rank holds fewer than 16 384 streams (config 4: all
-    # 32 768 on one GPU -> one lane, an eighth of them -> two), one where the scans are persistent grids
-    for workload, world, want in (("config2", 1, 2), ("config4", 1, 1), ("config4", 4, 2), ("config3", 1, 1), ("config5", 1, 1)):
+    # lanes per GPU when the caller does not say: three up to nperseg 512 while a rank holds fewer than 16 384 streams (config 4: all
+    # 32 768 on one GPU -> one lane, an eighth of them -> three), one where the scans are persistent grids
+    for workload, world, want in (("config2", 1, 3), ("config4", 1, 1), ("config4", 4, 3), ("config3", 1, 1), ("config5", 1, 1)):
         a = ns(workload=workload, lanes=None)
         bench.resolve_workload(a, world)
         assert a.lanes == want, (workload, world, a.lanes)
