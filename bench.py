@@ -161,8 +161,11 @@ def resolve_workload(args, world):
         # two lanes +2 ... +3 % over one up to 8 192 streams, equal at 16 384, -3 % with all 32 768 on one GPU; three over two +1.5 %
         # at config 2, +3 ... 5 % at 1 024 streams, -0.7 ... +2 % at 4 096, +1 % at 8 192, and +3 ... 4 % on the reference's defaults
         # under a noise floor; four lanes -16 % at config 2 (profiles/r05_n_lanes_by_batch_size.txt)
+        # (the rule itself: pyradiotracking_amd.analyze.default_lanes, what BatchSignalAnalyzer(lanes="auto") takes)
+        from pyradiotracking_amd.analyze import default_lanes
+
         per_rank = w["streams"] if "streams" in w else -(-w["total"] // max(1, world))
-        args.lanes = 3 if (w["nperseg"] <= 512 and per_rank < 16384) else 1
+        args.lanes = default_lanes(w["nperseg"], per_rank)
     return w
 
 

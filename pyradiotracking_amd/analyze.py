@@ -190,6 +190,15 @@ class SignalBatch(collections.abc.Sequence):
         return sig
 
 
+def default_lanes(fft_nperseg: int, n_streams: int) -> int:
+    """Stream groups per GPU (``rt_config.lanes``) that measured best: three up to nperseg 512 while the launches of a group are
+    small enough to have ends worth filling by another group's kernels (fewer than 16 384 streams on the GPU) -- config 2 +14 % with
+    two lanes and another +1.5 % with three, the reference's defaults under a noise floor +3 ... 4 % over two, four lanes -16 % at
+    config 2; one lane from nperseg 1024 on, where the scans are chip-filling grids of persistent workgroups (config 3: 676 k
+    MSamples/s with one lane, 650 k with two).  ``profiles/r05_n_lanes_by_batch_size.txt``; ``bench.py`` uses the same rule."""
+    return 3 if (fft_nperseg <= 512 and 3 <= n_streams < 16384) else 1
+
+
 class BatchSignalAnalyzer:
     """``S`` independent analyzers sharing one configuration, one GPU.
 
@@ -219,7 +228,7 @@ class BatchSignalAnalyzer:
         segs_per_chunk: int = 0,
         timing: bool = False,
         hip_stream: Optional[int] = None,
-        lanes: int = 1,
+        lanes: Union[int, str] = 1,
         subtract_first: bool = False,
         record_pool: int = 0,
         **kwargs,
@@ -241,6 +250,8 @@ class BatchSignalAnalyzer:
         analysed on its own HIP stream: the detection kernels and launch gaps of one group then overlap the
         scan of another (config 2: +14 % whole-path throughput with two lanes).  Streams are independent,
         so the records are the same; ``rt_fetch`` returns them in stream order.  Needs ``hip_stream=None``.
+        ``lanes="auto"`` takes what the sweeps of round 5 found best (``default_lanes``: three up to nperseg 512 while the
+        batch holds fewer than 16 384 streams, one otherwise and whenever a ``hip_stream`` is given).
 
         ``calibration_db`` may be a sequence with one value per stream: every SDR of the reference has its own
         analyzer and calibration (``__main__.py:140-141``), and with it its own absolute threshold
@@ -266,6 +277,8 @@ class BatchSignalAnalyzer:
         self.snr_threshold = from_dB(snr_threshold_db)  # :116
 
         win32, scale32 = stft_constants(fft_window, fft_nperseg, sample_rate)
+        if lanes == "auto":
+            lanes = 1 if hip_stream is not None else default_lanes(fft_nperseg, len(self.devices))
         if int(lanes) > 1 and hip_stream is not None:
             raise ValueError("lanes > 1 run on their own HIP streams: pass hip_stream=None")
         self._native = _native.NativeAnalyzer(

@@ -2227,6 +2227,16 @@ def test_lanes_give_the_same_records():
     assert outs[0].tobytes() == outs[1].tobytes()
     with pytest.raises(ValueError):
         _batch_for(kw, 4, blen, "sparse", lanes=2, hip_stream=torch.cuda.current_stream().cuda_stream)
+    # lanes="auto": the measured rule (analyze.default_lanes) -- three here, one on a caller's HIP stream or from nperseg 1024 on
+    from pyradiotracking_amd.analyze import default_lanes
+
+    assert (default_lanes(256, 7), default_lanes(256, 32768), default_lanes(1024, 4096), default_lanes(256, 1)) == (3, 1, 1, 1)
+    auto = _batch_for(kw, n_streams, blen, "sparse", lanes="auto")
+    auto.enqueue(chunk)
+    assert auto.fetch_records().tobytes() == want.tobytes()
+    on_stream = _batch_for(kw, n_streams, blen, "sparse", lanes="auto", hip_stream=torch.cuda.current_stream().cuda_stream)
+    on_stream.enqueue(chunk)
+    assert on_stream.fetch_records().tobytes() == want.tobytes()
 
 
 def test_buckets_ordered_by_bitmap_equal_the_dense_path():
