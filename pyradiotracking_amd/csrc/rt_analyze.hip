@@ -374,8 +374,8 @@ int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_se
             else hipLaunchKernelGGL((stft_big<false, 16, 1024>), dim3(nb), dim3(1024), big_lds, h->s_scan, g);
         }
     } else {
-        if (u8) hipLaunchKernelGGL((stft_general<true, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
-        else hipLaunchKernelGGL((stft_general<false, 1>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+        if (u8) hipLaunchKernelGGL((stft_general<true>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+        else hipLaunchKernelGGL((stft_general<false>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
     }
     return 0;
 }
@@ -1302,7 +1302,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             RT_CREATE_HIP(hipMemcpy(h->d_tws, tws.data(), sizeof(cf) * tws.size(), hipMemcpyHostToDevice));
         }
         {
-            const void *big_lds[] = {reinterpret_cast<const void *>(stft_general<false, 1>), reinterpret_cast<const void *>(stft_general<true, 1>),
+            const void *big_lds[] = {reinterpret_cast<const void *>(stft_general<false>), reinterpret_cast<const void *>(stft_general<true>),
                                      reinterpret_cast<const void *>(stft_big<false, 16, 512>), reinterpret_cast<const void *>(stft_big<true, 16, 512>),
                                      reinterpret_cast<const void *>(stft_big<false, 16, 1024>), reinterpret_cast<const void *>(stft_big<true, 16, 1024>),
                                      reinterpret_cast<const void *>(stft_bluestein<false, 1, 256>), reinterpret_cast<const void *>(stft_bluestein<true, 1, 256>),

@@ -36,8 +36,10 @@ struct GeneralParams {
 
 constexpr int kGeneralBlock = 256;
 constexpr int kGeneralMaxN = 16384;  // 128 KiB of LDS for one segment
-// (Measured and dropped, round 5: workgroups of 1 024 threads beyond nperseg 1024 and W_(2 h)^k as the square of W_(4 h)^k instead of a
-// second table load -- nperseg 8192 72 k -> 45 k MS/s, 128 150 k -> 128 k, only 16 384 gained, 50 k -> 55 k.)
+// (Measured and dropped early in round 5, while the accesses at bit-reversed places still bounded these kernels: workgroups of 1 024
+// threads beyond nperseg 1024 and W_(2 h)^k as the square of W_(4 h)^k instead of a second table load -- nperseg 8192 72 k -> 45 k
+// MS/s, 128 150 k -> 128 k, only 16 384 gained, 50 k -> 55 k.  With those accesses gone, 512 / 1 024 threads are what stft_big and the
+// long Bluestein transforms run on: rt_analyze.hip, launch_general.)
 
 // log2 N butterfly stages of a decimation-in-time transform on `xs` (N complex values in LDS, input at bit-reversed places,
 // natural order out), two stages per barrier: a thread takes the four elements base + {0, h, 2 h, 3 h} (h = the first stage's
@@ -199,17 +201,16 @@ __device__ __forceinline__ void lds_fft_stages_dif(cf *xs, int N, int LOG, const
     }
 }
 
-template <bool U8, int U = 1>
+// nperseg 8 and 16 -- and 32 / 64 / 128 into a map that is only float-aligned (stft_small stores 8 / 16 bytes at a time): up to 64
+// segments per workgroup.  Every other power of two has a kernel of its own below.
+template <bool U8>
 __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParams p) {
-    constexpr int LB = (U == 1) ? 1 : 4 * U;  // elements of a thread per trip of the element-wise loops (N / TPS is a multiple of 4 U)
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
     cf *const x = reinterpret_cast<cf *>(gen_smem);                       // [SPB][N]
     __shared__ double red[2 * kGeneralBlock];                              // partial sums of the segment means
-    __shared__ cf tw_hi[U > 1 ? kGeneralMaxN / 2 / kTwSplit : 1], tw_lo[U > 1 ? kTwSplit : 1];
     const int N = p.nperseg, LOG = p.log2n, SPB = p.segs_per_block, T = p.n_seg;
     const int tid = threadIdx.x;
-    if constexpr (U > 1) fft_stage_tables(tw_hi, tw_lo, p.tw, N, tid, kGeneralBlock);  // (read behind the barriers below)
     const int blocks_per_stream = (T + SPB - 1) / SPB;
     const int s = blockIdx.x / blocks_per_stream;
     const int seg0 = (blockIdx.x % blocks_per_stream) * SPB;
@@ -227,17 +228,11 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
     // percent of what the detrend leaves in bin 0 -- the exact sum, rounded once, stays within NumPy's own error)
     double sx = 0.0, sy = 0.0;
     if (live) {
-        for (int n0 = lt; n0 < N; n0 += TPS * LB) {
-            raw_t raw[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) raw[j] = load_iq(src + (int64_t)q * N + n0 + j * TPS);
-#pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                const cf v = to_cf(raw[j]);
-                sx += (double)v.x;
-                sy += (double)v.y;
-                xs[__brev((unsigned)(n0 + j * TPS)) >> (32 - LOG)] = v;
-            }
+        for (int n = lt; n < N; n += TPS) {
+            const cf v = to_cf(load_iq(src + (int64_t)q * N + n));
+            sx += (double)v.x;
+            sy += (double)v.y;
+            xs[__brev((unsigned)n) >> (32 - LOG)] = v;
         }
     }
     red[2 * tid] = sx;
@@ -252,35 +247,26 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
     const float mx = (float)(mxd / (double)N), my = (float)(myd / (double)N);
     // detrend='constant' (scipy _signaltools.py:3926), then the window (times sqrt(scale): the power needs no further factor)
     if (live) {
-        for (int n0 = lt; n0 < N; n0 += TPS * LB) {
-            float w[LB];
-            cf v[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) w[j] = p.window[n0 + j * TPS];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) v[j] = xs[__brev((unsigned)(n0 + j * TPS)) >> (32 - LOG)];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) xs[__brev((unsigned)(n0 + j * TPS)) >> (32 - LOG)] = cf{(v[j].x - mx) * w[j], (v[j].y - my) * w[j]};
+        for (int n = lt; n < N; n += TPS) {
+            const int at = (int)(__brev((unsigned)n) >> (32 - LOG));
+            const cf v = xs[at];
+            const float w = p.window[n];
+            xs[at] = cf{(v.x - mx) * w, (v.y - my) * w};
         }
     }
     __syncthreads();
-    lds_fft_stages<U>(xs, N, LOG, p.tw, lt, TPS, live, tw_hi, tw_lo);
+    lds_fft_stages<1>(xs, N, LOG, p.tw, lt, TPS, live);
     // |X|^2 (scipy _spectral_py.py:2126-2128) -> the dense map and, for the last K segments, the look-back tail
     if (live) {
         const int seg = seg0 + q;
         float *dst = p.spec + ((int64_t)s * T + seg) * N;
         const int col = seg - (T - p.tail_cols);
         float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
-        for (int k0 = lt; k0 < N; k0 += TPS * LB) {
-            cf v[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) v[j] = xs[k0 + j * TPS];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                const float pw = __builtin_fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
-                dst[k0 + j * TPS] = pw;
-                if (tdst) tdst[k0 + j * TPS] = pw;
-            }
+        for (int k = lt; k < N; k += TPS) {
+            const cf v = xs[k];
+            const float pw = __builtin_fmaf(v.x, v.x, v.y * v.y);
+            dst[k] = pw;
+            if (tdst) tdst[k] = pw;
         }
     }
 }

@@ -130,6 +130,32 @@ def test_spectrogram_matches_oracle(nperseg, window):
                 assert np.abs(db).max() < 2e-2, f"stream {s} bin {f}: {np.abs(db).max()} dB"
 
 
+def test_spectrogram_into_a_map_that_is_only_float_aligned():
+    """rt_spectrogram asks for a 4-byte aligned map.  nperseg 32 / 64 / 128 normally run stft_small, whose stores are 8 / 16 bytes
+    wide: a map at an odd float offset takes the radix-2 kernel instead -- the same spectrogram within the float32 round-off of two
+    different transforms."""
+    _need_gpu()
+    fs, nperseg, n_seg = 300000, 128, 53
+    n = n_seg * nperseg + 5
+    rng = np.random.default_rng(77)
+    w = oracle.window_coefficients("hamming", nperseg)
+    iq = np.stack([synth.make_stream(synth.StreamSpec(n, fs, synth.random_pulses(rng, n, fs, w, 3, dur_ms=(2, 6)), dc=complex(1e-3, 2e-3)), 40 + s) for s in range(2)])
+    b = _batch_for(dict(sample_rate=fs, fft_nperseg=nperseg, fft_window="hamming"), 2, n, "dense")
+    d_iq = _native.DeviceBuffer(0, iq.nbytes)
+    d_iq.upload(iq)
+    cells = 2 * n_seg * nperseg
+    d_out = _native.DeviceBuffer(0, cells * 4 + 64)
+    b.native.spectrogram_device(d_iq.ptr, n, n, d_out.ptr)
+    aligned = d_out.download(np.float32, cells + 16)[:cells].copy()
+    b.native.spectrogram_device(d_iq.ptr, n, n, d_out.ptr + 4)
+    shifted = d_out.download(np.float32, cells + 16)[1:cells + 1].copy()
+    med = np.median(aligned)
+    assert np.all(np.abs(shifted - aligned) <= 2e-4 * aligned + 1e-2 * med), float(np.max(np.abs(shifted - aligned) / (aligned + 1e-2 * med)))
+    with pytest.raises(_native.NativeError):
+        b.native.spectrogram_device(d_iq.ptr, n, n, d_out.ptr + 2)
+    b.close()
+
+
 # ---------------------------------------------------------------------------
 # whole path on the golden IQ cases
 # ---------------------------------------------------------------------------
