@@ -69,6 +69,10 @@ OTHER_CONFIGS = [
                                           noise_dbw=-88.0, settle=20,
                                           what="the reference's defaults (300 kS/s, nperseg 256, -90 dBW, 8-40 ms) with the noise floor at -88 dBW, 2 dB OVER "
                                                "the threshold (a real RTL-SDR): AUTO reaches the exact run-length pre-filter")),
+    ("config2_uint8", dict(streams=256, sample_rate=2048000, samples=2048000, nperseg=256, window="hamming", trains=False, lanes=3, input="u8",
+                           steps=200, settle=30,  # (half-millisecond steps: ten of them end before the clocks have settled)
+                           what="config 2's geometry from the RTL-SDR wire format (interleaved uint8 I/Q, converted in the scan's load): a quarter of the bytes, "
+                                "the same arithmetic -- bound by the step's instructions, not by HBM")),
     # sizes outside the fused scans' 256 ... 4096 (csrc/rt_general.h; dense path: transform + detect_dense, 16 bytes per sample)
     ("nperseg128_defaults", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=128, window="hamming", trains=False, lanes=1,
                                  what="the reference's defaults at fft_nperseg 128: stft_small (registers, one wave-private exchange) on the dense path")),
@@ -740,6 +744,10 @@ def cpu_baseline(args, an, iq, rec, kw, blen, n_seg, nperseg, timed, spread=0):
         n = len(parity_ids)
     rows = list(parity_ids) + [i for i in range(S) if i not in set(parity_ids)][: max(0, n - len(parity_ids))]
     host = iq[rows].cpu().numpy()
+    if host.dtype == np.uint8:  # the RTL-SDR wire format: the oracle gets what the scan kernel makes of the bytes (fma(byte, 1/127.5, -1), float32)
+        from pyradiotracking_amd import synth
+
+        host = synth.u8_to_complex64_like_kernel(host)
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(tmpdir, f"rt_bench_iq_{os.getpid()}.npy")
     np.save(path, host)
@@ -872,10 +880,18 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
     extra = {}
     if spec.get("noise_dbw") is not None:
         extra["noise_sigma"] = float(np.sqrt(10.0 ** (spec["noise_dbw"] / 10.0) * fs / 2.0))
-    iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=spec["trains"], first_stream=0, **extra)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=spec["window"])
+    u8 = spec.get("input") == "u8"
+    if u8:
+        # 8-bit front end, as `--input u8`: noise ~1.5 LSB rms, pulses 18..32 dB above a -80 dBW threshold, converted inside the scan's load
+        kw["signal_threshold_dbw"] = -80.0
+        iq_c = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, noise_sigma=0.012, peak_dbw=(-62.0, -48.0), first_stream=0)
+        iq = synth.quantize_u8_device(iq_c)
+        del iq_c
+    else:
+        iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=spec["trains"], first_stream=0, **extra)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_begin
-    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=spec["window"])
     names = [str(i) for i in range(S)]
     stream = torch.cuda.current_stream()
 
@@ -886,11 +902,12 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
     def run(an, n_steps, serial=False):
         acc = [0.0, 0.0, 0]
         rec = info = None
+        enq = an.enqueue_bytes if u8 else an.enqueue
         if n_steps and not serial:
-            an.enqueue(iq)
+            enq(iq)
         for i in range(n_steps):
             if serial or i + 1 < n_steps:
-                an.enqueue(iq)
+                enq(iq)
             rec = an.fetch_records()
             info = an.call_info()
             acc[0] += info.ms_stft
@@ -930,7 +947,7 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
                  else "general transform")
     return {
         "name": name,
-        "workload": f"{S} streams x {fs} SPS x {blen} samples complex64, nperseg {nperseg} {spec['window']}, "
+        "workload": f"{S} streams x {fs} SPS x {blen} samples {'uint8 I/Q (2 B per sample)' if u8 else 'complex64'}, nperseg {nperseg} {spec['window']}, "
                     + ("tag trains, 8-16 tags/stream" if spec["trains"] else "4-8 sparse 15 ms pulses/stream")
                     + (f", noise floor {spec['noise_dbw']} dBW" if spec.get("noise_dbw") is not None else "") + f" -- {spec['what']}",
         "value": round(value, 1),
@@ -945,9 +962,9 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
         "kernel": (f"{scan_name}: threshold-bit scan + planning + listed scan of a step (first launch to scan event)" if two_scans else scan_name),
         "kernel_ms": round(kernel_ms, 4),
         "kernel_ms_note": f"one lane, one call in flight, HIP events on its stream, mean of {iso} steps after the timed ones",
-        "algorithmic_bytes_per_launch": samples * BYTES_PER_SAMPLE,
-        "frac": round(samples * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms > 0 else None,
-        "whole_path_frac": round(value * 1e6 * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
+        "algorithmic_bytes_per_launch": samples * (2 if u8 else BYTES_PER_SAMPLE),
+        "frac": round(samples * (2 if u8 else BYTES_PER_SAMPLE) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms > 0 else None,
+        "whole_path_frac": round(value * 1e6 * (2 if u8 else BYTES_PER_SAMPLE) / 1e9 / HBM_PEAK_GBS, 4),
         "detect_kernel_ms": round(ms_detect / max(1, steps) / max(1, lanes), 4),
         "parity_streams_checked": parity["streams_checked"],
         "parity_streams_mismatched": parity["streams_mismatched"],
@@ -972,7 +989,7 @@ def other_configs(torch, args, local_rank):
             out.append({"name": name, "skipped": f"the block's budget of {args.other_budget_s:.0f} s was spent ({spent:.0f} s) before this configuration"})
             continue
         try:
-            out.append(measure_other(torch, name, spec, local_rank, args.other_steps))
+            out.append(measure_other(torch, name, spec, local_rank, max(args.other_steps, int(spec.get("steps", 0)))))
         except Exception as e:  # a configuration that fails (e.g. no memory for 137 GB on a shared GPU) must not take the headline with it
             out.append({"name": name, "failed": f"{type(e).__name__}: {e}"[:500]})
             torch.cuda.empty_cache()
