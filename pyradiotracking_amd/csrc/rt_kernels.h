@@ -472,7 +472,12 @@ template <int R3, int MODE, bool U8 = false, bool LIN = false>
 #ifndef RT_PK_R3_MASK
 #define RT_PK_R3_MASK (1 | 4)
 #endif
-__global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
+// diagnostic builds only: -DRT_EXP_U8_PK=1 gives the uint8 kernels of nperseg 256 the packed butterflies too, at three workgroups per CU
+// instead of four (the registers of the pairs) -- measured in round 5, EXPERIMENTS.md
+#ifndef RT_EXP_U8_PK
+#define RT_EXP_U8_PK 0
+#endif
+__global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     constexpr int N = 256 * R3;
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // (uint8 input at nperseg 256 does run at four workgroups per CU: 106 VGPRs, +3 %)
     // (nperseg 2048: 96 -- with 128 the block is 54 576 B, and LDS is handed out in 512-byte pieces: three workgroups
     // would need 164 352 of the CU's 163 840 B, so the kernel ran at two; profiles/r03_d_stage_stamps.txt)
-    constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1)) ? 32 : (R3 == 8) ? 96 : kStageCap;  // candidate cells staged per wave before a flush
+    constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 32 : (R3 == 8) ? 96 : kStageCap;  // candidate cells staged per wave before a flush
     constexpr size_t kXchB = sizeof(cf) * BLK * kRowF2;
     constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (BLK / 64) + 16 : 0;  // + the three tail_any words
     constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     const int L = p.segs_per_chunk;
 
     // the transform's arithmetic form: packed pairs where the registers are free (rt_fft.h), else scalar -- same results
-    constexpr bool PK = ((RT_PK_R3_MASK & R3) != 0) && !U8;
+    constexpr bool PK = ((RT_PK_R3_MASK & R3) != 0) && (!U8 || (RT_EXP_U8_PK && R3 == 1));
     using C = typename std::conditional<PK, cfv, cf>::type;
     C *gx = reinterpret_cast<C *>(xch + g * LG * kRowF2);  // this group's exchange rows
 
