@@ -193,8 +193,8 @@ class SignalBatch(collections.abc.Sequence):
 def default_lanes(fft_nperseg: int, n_streams: int) -> int:
     """Stream groups per GPU (``rt_config.lanes``) that measured best: three up to nperseg 512 while the launches of a group are
     small enough to have ends worth filling by another group's kernels (fewer than 16 384 streams on the GPU) -- config 2 +14 % with
-    two lanes and another +1.5 % with three, the reference's defaults under a noise floor +3 ... 4 % over two, four lanes -16 % at
-    config 2; one lane from nperseg 1024 on, where the scans are chip-filling grids of persistent workgroups (config 3: 676 k
+    two lanes and another +1.5 % with three, the reference's defaults under a noise floor +3 ... 4 % over two; four lanes -16 % at
+    config 2 (the HIP runtime's four hardware queues: with GPU_MAX_HW_QUEUES=8 four lanes equal three, six lose); one lane from nperseg 1024 on, where the scans are chip-filling grids of persistent workgroups (config 3: 676 k
     MSamples/s with one lane, 650 k with two).  ``profiles/r05_n_lanes_by_batch_size.txt``; ``bench.py`` uses the same rule."""
     return 3 if (fft_nperseg <= 512 and 3 <= n_streams < 16384) else 1
 
