@@ -389,7 +389,12 @@ def main():
     if os.environ.get("RT_BENCH_NO_PIN") == "1":
         cpu_plan = {"cpus": _ORIG_AFFINITY or [], "numa_node": None, "pci": None, "how": "not pinned (RT_BENCH_NO_PIN=1)", "pinned": False}
     else:
-        cpu_plan = affinity.pin_rank(rank, [0] * world if share_gpu else list(range(world)))
+        # the plan is per NODE: this rank's place among the ranks of its own node (a second node's ranks 8 .. 15 drive its GPUs 0 .. 7)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) if launched else 1
+        local_index = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+        if not 0 <= local_index < local_world:
+            local_index, local_world = rank, world
+        cpu_plan = affinity.pin_rank(local_index, [0] * local_world if share_gpu else list(range(local_world)))
     if world != args.gpus and rank == 0:
         # a launcher's WORLD_SIZE is what actually runs; the JSON line reports it as n_gpus
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); running {world}", file=sys.stderr)

@@ -70,10 +70,13 @@ def gpu_pci_addresses(root: str = "/") -> List[str]:
 
 
 def visible_ordinals(n_gpus: int, env=os.environ) -> List[int]:
-    """Topology indices behind HIP ordinals 0 .. under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES lists of plain
-    indices (UUID entries or anything else unparsable: identity)."""
+    """Topology indices behind HIP ordinals 0 .. under ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES lists of plain
+    indices (UUID entries or anything else unparsable: identity).  ROCR_VISIBLE_DEVICES re-indexes what the runtime
+    below HIP sees; HIP then applies ONE further list -- HIP_VISIBLE_DEVICES, or its alias CUDA_VISIBLE_DEVICES where
+    that is unset: the two are never composed (a launcher that sets both to "1,0" means one swap, not two)."""
     order = list(range(n_gpus))
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    hip_var = "HIP_VISIBLE_DEVICES" if env.get("HIP_VISIBLE_DEVICES") else "CUDA_VISIBLE_DEVICES"
+    for var in ("ROCR_VISIBLE_DEVICES", hip_var):
         val = env.get(var)
         if not val:
             continue
@@ -100,17 +103,39 @@ def node_cpus(node: int, root: str = "/") -> List[int]:
     return parse_cpulist(text) if text else []
 
 
-def _split(cpus: Sequence[int], parts: int, which: int) -> List[int]:
-    """The `which`-th of `parts` contiguous, disjoint shares of `cpus` (sizes differ by at most one; a share is never
+def core_groups(cpus: Sequence[int], root: str = "/") -> List[List[int]]:
+    """`cpus` grouped by physical core (``topology/thread_siblings_list``): a core's hardware threads stay together, the
+    groups in the order of their lowest thread.  Without that file every thread is a core of its own."""
+    left = set(cpus)
+    groups: List[List[int]] = []
+    for c in sorted(left):
+        if c not in left:
+            continue
+        text = _read(os.path.join(root, f"sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list"))
+        try:
+            sib = [x for x in parse_cpulist(text) if x in left] if text else []
+        except ValueError:
+            sib = []
+        if c not in sib:
+            sib = [c]
+        groups.append(sorted(sib))
+        left -= set(sib)
+    return groups
+
+
+def _split(cpus: Sequence[int], parts: int, which: int, root: str = "/") -> List[int]:
+    """The `which`-th of `parts` disjoint shares of `cpus`, dealt by PHYSICAL core -- a core goes to one rank together with
+    its SMT sibling (a contiguous split of "0-47,96-143" gave rank 0 the cores 0-23 and rank 2 their siblings 96-119:
+    two ranks on the same physical cores).  Shares are contiguous runs of cores (sizes differ by at most one core; never
     empty while there are at least as many cores as parts -- with fewer, shares wrap around and overlap)."""
-    cpus = list(cpus)
-    if not cpus:
+    groups = core_groups(cpus, root)
+    if not groups:
         return []
-    if len(cpus) < parts:
-        return [cpus[which % len(cpus)]]
-    base, extra = divmod(len(cpus), parts)
+    if len(groups) < parts:
+        return list(groups[which % len(groups)])
+    base, extra = divmod(len(groups), parts)
     lo = which * base + min(which, extra)
-    return cpus[lo:lo + base + (1 if which < extra else 0)]
+    return sorted(c for g in groups[lo:lo + base + (1 if which < extra else 0)] for c in g)
 
 
 def plan(gpu_of_rank: Sequence[int], allowed: Sequence[int], root: str = "/", env=os.environ) -> List[dict]:
@@ -132,14 +157,14 @@ def plan(gpu_of_rank: Sequence[int], allowed: Sequence[int], root: str = "/", en
         if cpus:
             # ranks on the same node (several GPUs per socket, or several ranks on one GPU) share its cores evenly
             same = [q for q, (_, n2, c2) in enumerate(info) if n2 == node and c2]
-            mine = _split(cpus, len(same), same.index(r))
+            mine = _split(cpus, len(same), same.index(r), root)
             out.append({"cpus": mine, "numa_node": node, "pci": pci, "how": f"cores of NUMA node {node} (GPU {pci}), share {same.index(r) + 1} of {len(same)}"})
         else:
             # no NUMA information (a VM without it, numa_node = -1, sysfs hidden): an even split of what the job may use
             loose = [q for q, (_, _, c2) in enumerate(info) if not c2]
             taken = set(c for q, (_, _, c2) in enumerate(info) if c2 for c in c2)
             pool = [c for c in allowed if c not in taken] or allowed
-            mine = _split(pool, len(loose), loose.index(r))
+            mine = _split(pool, len(loose), loose.index(r), root)
             out.append({"cpus": mine, "numa_node": None if node < 0 else node, "pci": pci,
                         "how": f"no NUMA information for GPU {pci}: share {loose.index(r) + 1} of {len(loose)} of the job's cores"})
     return out

@@ -61,21 +61,44 @@ def _library_cmd(target, extra=()):
     ]
 
 
-def build_library(force=False, verbose=False, diag=True):
-    """The product library and (``diag``) its diagnostic twin, compiled side by side (two hipcc processes)."""
+def build_library(force=False, verbose=False, diag=False):
+    """The product library and (``diag=True``: ``build_all``, tools/variant.sh, the fault-injection test) its diagnostic twin,
+    compiled side by side (two hipcc processes).  The import path (``_native.load_library``) builds the product alone: a cold
+    import must not pay for -- or race other ranks on -- a second 2 MB multi-template build nobody loads.  Each target is
+    linked under a temporary name and moved into place (``os.replace``), so a concurrent importer never maps a half-written
+    file; when one job fails the other is stopped and waited for before the error is raised (no orphaned hipcc)."""
     jobs = []
     for target, extra in ((LIB, ()), (LIB_DIAG, ("-DRT_DIAG",))):
         if target == LIB_DIAG and not diag:
             continue
         if not force and _newer(target, _sources()):
             continue
-        cmd = _library_cmd(target, extra)
+        tmp = f"{target}.tmp{os.getpid()}"
+        cmd = _library_cmd(tmp, extra)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in jobs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        jobs.append((cmd, subprocess.Popen(cmd), tmp, target))
+    failed = None
+    for cmd, pr, tmp, target in jobs:
+        if failed is not None:
+            if pr.poll() is None:
+                pr.terminate()
+            try:
+                pr.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+        elif pr.wait() != 0:
+            failed = (pr.returncode, cmd)
+        else:
+            os.replace(tmp, target)
+            continue
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+    if failed is not None:
+        raise subprocess.CalledProcessError(failed[0], failed[1])
     return LIB
 
 
@@ -91,7 +114,8 @@ def build_hostcheck(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_library(force, verbose), build_hostcheck(force, verbose)
+    """everything: the product, its diagnostic twin and the host check (``__graft_entry__.build``)"""
+    return build_library(force, verbose, diag=True), build_hostcheck(force, verbose)
 
 
 if __name__ == "__main__":

@@ -206,6 +206,27 @@ namespace {
         }                                                                                     \
     } while (0)
 
+#ifdef RT_DIAG
+// The diagnostic library reads a handful of environment switches (rt_diag.h).  A committed script that still sets one that no
+// longer exists would A/B two identical configurations without a word (advisor, round 5): every RT_EXP_* / RT_TEST_* variable
+// this build does not know is named on stderr, once per process.
+extern "C" char **environ;
+void warn_unknown_switches() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    static const char *const known[] = {"RT_EXP_ONE_LEVEL", "RT_EXP_TAIL", "RT_EXP_STREAMS", "RT_EXP_TAIL_PRIO", "RT_TEST_FAIL_LANE", "RT_STAMPS_DUMP"};
+    for (char **e = environ; e && *e; ++e) {
+        if (std::strncmp(*e, "RT_EXP_", 7) != 0 && std::strncmp(*e, "RT_TEST_", 8) != 0) continue;
+        const char *eq = std::strchr(*e, '=');
+        const std::string name(*e, eq ? (size_t)(eq - *e) : std::strlen(*e));
+        bool ok = false;
+        for (const char *k : known) ok = ok || name == k;
+        if (!ok) std::fprintf(stderr, "librt_analyze_diag: environment variable %s is set but this build reads no such switch (known: RT_EXP_ONE_LEVEL, RT_EXP_TAIL, RT_EXP_STREAMS, RT_EXP_TAIL_PRIO, RT_TEST_FAIL_LANE, RT_STAMPS_DUMP)\n", name.c_str());
+    }
+}
+#endif
+
 int fail_create(int code, const std::string &msg) {
     g_create_error = msg;
     return code;
@@ -653,16 +674,24 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         } else {
         // Chunk minima are kept by this level's own scans only (round 5: the sparse scans of an AUTO handle paid for them in every
         // item's epilogue -- config 3 +1.8 % per launch -- for the one call in thousands that climbs here).  None on hand -- the handle's
-        // first call on this level, or the first after calls on other levels: a scan of this buffer provides them (its bits, taken
-        // with the absolute threshold alone, are overwritten by the scan proper below).
+        // first call on this level, or the first after calls on other levels (the minima must be the previous call's): a scan of this
+        // buffer provides them (its bits, taken with the absolute threshold alone, are overwritten by the scan proper below).
+        // "On hand" means: of the buffer immediately before this one (or of this very buffer: a call analysed again on this level).  An
+        // AUTO handle that comes back here after thousands of sparse calls would otherwise build its thresholds from the minima of an
+        // arbitrarily old buffer -- too high (a stale-threshold re-analysis and a host sync) or too low (an unselective filter, which
+        // pushes AUTO on to the dense path for sticky_len calls): advisor, round 5.
         sp.chunk_min = sl.d_chunk_min;
-        if (h->minsum_slot < 0 || h->slot[h->minsum_slot].min_items <= 0) {
+        int src = h->minsum_slot;
+        const bool on_hand = src >= 0 && h->slot[src].min_items > 0 && (h->slot[src].min_seq + 1 == c.seq || h->slot[src].min_seq == c.seq);
+        if (!on_hand) {
             launch_scan<6>(h, sp, blocks, c.u8);
-            h->minsum_slot = slot_index;
             sl.min_items = sp.blocks_per_stream;
             sl.min_seq = sl.call.seq;
+            src = slot_index;
+            // (the LATEST buffer's minima set the next call's thresholds: a call analysed again from rt_fetch keeps that place for a later one)
+            if (h->minsum_slot < 0 || sl.min_seq >= h->slot[h->minsum_slot].min_seq) h->minsum_slot = slot_index;
         }
-        const Slot &ps = h->slot[h->minsum_slot];
+        const Slot &ps = h->slot[src];
         hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, ps.d_chunk_min, ps.min_items, sl.d_thr_bin,
                            sl.d_thr_nat, S, h->R3, h->L * minsum_group(h->L, h->GPW), h->cfg.snr_threshold);
         }
@@ -1070,6 +1099,9 @@ void rt_destroy(rt_handle *h) {
 int rt_create(const rt_config *cfg, rt_handle **out) {
     if (!cfg || !out) return fail_create(RT_E_INVALID, "null argument");
     *out = nullptr;
+#ifdef RT_DIAG
+    warn_unknown_switches();
+#endif
     if (cfg->n_streams < 1 || cfg->max_samples < 0 || !cfg->window || !(cfg->sample_rate > 0))
         return fail_create(RT_E_INVALID, "n_streams, max_samples, window and sample_rate must be set");
     if (!(cfg->max_duration_s >= 0) || !(cfg->min_duration_s >= 0))

@@ -83,6 +83,19 @@ RT_HD int minsum_group(int L, int gpw) {
     return g;
 }
 
+// Sampling of the absolute-threshold bits in the threshold-bit scan's items that need them only for AUTO's count (stft_scan, MODE 6
+// with staged per-bin thresholds: abs_hot).  One step in P = abs_sample_period(L) builds them, P the largest power of two <= min(8, L)
+// -- with chunks of 4 .. 7 segments (small batches) a fixed period of eight never sampled anything -- and a sampled cell counts P
+// times.  Steps run i = 1 .. L in every chunk, so the phase must come from outside the chunk: `phase` = the item's number within
+// its stream + the wave's number (uniform per wave), which turns from item to item whatever L is -- a pulse train whose period is
+// a multiple of eight hops can neither hide from the count nor fill it.
+RT_HD int abs_sample_period(int L) {
+    int p = 1;
+    while (p * 2 <= L && p < 8) p *= 2;
+    return p;
+}
+RT_HD bool abs_sampled(int i, int phase, int period) { return ((i + phase) & (period - 1)) == 0; }
+
 // Factor on the quiet-level estimate when its samples are longer than 32 segments (chunks of 37 .. 71 segments at nperseg >= 1024).
 // The minimum over n samples of the mean of m exponentially distributed powers lies about 2 / sqrt(m) under the mean; the
 // thresholds must stay under snr x the NEXT buffer's row mean, and with long samples (few of them, each close to the mean) that

@@ -93,6 +93,22 @@ int hc_probe_ruled_out(int target, int level, int valid, unsigned long long abs_
     return probe_ruled_out(target, level, valid != 0, abs_hot, list_cells, cells_per_stream) ? 1 : 0;
 }
 
+// how often a cell of a chunk of L segments is counted by the sampled absolute-threshold bits (rt_core.h: abs_sampled):
+// the sampled steps of i = 1 .. L under `phase`, times the period
+int hc_abs_sample_period(int L) { return abs_sample_period(L); }
+int hc_abs_sampled_weight(int L, int phase) {
+    const int P = abs_sample_period(L);
+    int n = 0;
+    for (int i = 1; i <= L; ++i) n += abs_sampled(i, phase, P) ? P : 0;
+    return n;
+}
+int hc_abs_sampled_segment(int L, int phase, int k) {  // the k-th sampled step (0-based) as a segment offset inside the chunk (seg - c0), or -1
+    const int P = abs_sample_period(L);
+    for (int i = 1; i <= L; ++i)
+        if (abs_sampled(i, phase, P) && k-- == 0) return L - i;
+    return -1;
+}
+
 int hc_minsum_group(int L, int gpw) { return minsum_group(L, gpw); }
 double hc_minsum_margin(int m) { return (double)minsum_margin(m); }
 

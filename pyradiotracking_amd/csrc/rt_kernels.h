@@ -663,6 +663,8 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // AUTO's probes (abs_hot) comes from every eighth segment elsewhere: 48 of ~630 vector instructions of every step at the
     // reference's default geometry, where the noise passes the absolute threshold in nearly every lane.
     bool item_hot = true;  // wave-uniform
+    const int samp_period = abs_sample_period(L);  // (see sampled_abs below)
+    const int samp_phase = __builtin_amdgcn_readfirstlane(cb + (int)(threadIdx.x >> 6));
     if constexpr (THR_LDS) {
         if (p.thr_bin) item_hot = __builtin_amdgcn_ballot_w64(p.full != nullptr || c0 + p.segs_per_chunk > p.n_seg - p.tail_cols) != 0ull;
     }
@@ -1161,10 +1163,10 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             // segment is NaN -- the mean is -- so the max is NaN and `!(m < thr)` holds, as for the
             // reference's `not (P < thr)`.)
             // (MODE 6 with staged thresholds: the bits of the absolute threshold alone are built in the items that need them and in one
-            // step of eight elsewhere -- by step number, the same for the whole workgroup, so that seven steps of eight skip the block,
-            // and with a phase that turns from chunk to chunk: a pulse train whose period is a multiple of eight hops cannot hide from
-            // the count or fill it)
-            const bool sampled_abs = THR_LDS && !item_hot && p.abs_hot && (i & 7) == 0 && !halo;  // (see item_hot)
+            // step of P elsewhere (rt_core.h: abs_sample_period -- eight, fewer where chunks are shorter) -- wave-uniform, so that the
+            // other steps skip the block, with a phase that turns from item to item and wave to wave: a pulse train whose period is a
+            // multiple of eight hops cannot hide from the count or fill it)
+            const bool sampled_abs = THR_LDS && !item_hot && p.abs_hot && abs_sampled(i, samp_phase, samp_period) && !halo;  // (see item_hot)
             const bool want_hot = item_hot || sampled_abs;  // wave-uniform
             float mx = 0.f;
             if (want_hot) {
@@ -1224,7 +1226,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                     }
                 }
                 if (active && !halo) {
-                    if constexpr (MODE == 4 || MODE == 6) n_abs += (uint32_t)__builtin_popcount(hot) << ((THR_LDS && !item_hot) ? 3 : 0);
+                    if constexpr (MODE == 4 || MODE == 6) n_abs += (uint32_t)__builtin_popcount(hot) * ((THR_LDS && !item_hot) ? (uint32_t)samp_period : 1u);
                     allhot &= hot;
                     if (chunk == 0 && p.full) {  // (lane index opaque: the address stays out of the loop's registers)
                         int lt_f = lt;

@@ -81,3 +81,35 @@ def test_pin_rank_sets_the_mask_and_reports_it(tmp_path):
         assert set(me["cpus"]) <= set(allowed) and (len(allowed) < 2 or len(me["cpus"]) < len(allowed))
     finally:
         os.sched_setaffinity(0, allowed)
+
+
+def test_hip_and_cuda_visible_devices_are_aliases_not_composed():
+    """launchers set both to the same permutation: one re-indexing, HIP_VISIBLE_DEVICES first"""
+    assert affinity.visible_ordinals(4, {"HIP_VISIBLE_DEVICES": "1,0", "CUDA_VISIBLE_DEVICES": "1,0"}) == [1, 0]
+    assert affinity.visible_ordinals(4, {"CUDA_VISIBLE_DEVICES": "2,3"}) == [2, 3]
+    assert affinity.visible_ordinals(4, {"HIP_VISIBLE_DEVICES": "3", "CUDA_VISIBLE_DEVICES": "0"}) == [3]
+    # ROCR_VISIBLE_DEVICES re-indexes below HIP: the two do compose
+    assert affinity.visible_ordinals(4, {"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1"}) == [3]
+
+
+def _siblings(root, pairs):
+    for a, b in pairs:
+        for c in (a, b):
+            d = root / f"sys/devices/system/cpu/cpu{c}/topology"
+            d.mkdir(parents=True)
+            (d / "thread_siblings_list").write_text(f"{a},{b}\n")
+
+
+def test_shares_are_dealt_by_physical_core(tmp_path):
+    """a core and its SMT sibling go to the same rank (a contiguous split of "0-47,96-143" gave rank 0
+    the cores 0-23 and rank 2 their siblings 96-119)"""
+    gpus = [(0, 0x05 + 0x10 * i, 0, 0, 0) for i in range(4)]
+    _tree(tmp_path, gpus, {0: "0-47,96-143"})
+    _siblings(tmp_path, [(c, c + 96) for c in range(48)])
+    plan = affinity.plan(list(range(4)), list(range(192)), root=str(tmp_path), env={})
+    seen = set()
+    for r, p in enumerate(plan):
+        cpus = set(p["cpus"])
+        assert len(cpus) == 24 and not (cpus & seen)
+        assert cpus == {c for c in range(12 * r, 12 * r + 12)} | {c + 96 for c in range(12 * r, 12 * r + 12)}
+        seen |= cpus

@@ -174,3 +174,28 @@ def test_quiet_level_margin_normalises_long_samples(hc):
     assert hc.hc_minsum_margin(4) == 1.0 and hc.hc_minsum_margin(32) == 1.0
     for m, want in ((37, 0.963), (71, 0.847), (128, 0.785)):
         assert abs(hc.hc_minsum_margin(m) - want) < 2e-3, (m, hc.hc_minsum_margin(m))
+
+
+def test_sampled_absolute_threshold_count_covers_every_chunk_length():
+    """stft_scan MODE 6 counts the cells over the absolute threshold from one step in P (rt_core.h: abs_sample_period /
+    abs_sampled) where nothing else needs the bits.  ADVICE round 5: a fixed period of eight keyed on the step number
+    never sampled chunks of 4 .. 7 segments and kept one phase for every chunk when L is a multiple of eight."""
+    import ctypes as C
+
+    from pyradiotracking_amd import build
+
+    lib = C.CDLL(build.build_hostcheck())
+    for L, want in ((1, 1), (2, 2), (4, 4), (5, 4), (7, 4), (8, 8), (25, 8), (32, 8), (71, 8)):
+        assert lib.hc_abs_sample_period(L) == want
+    for L in (4, 5, 7, 8, 25, 32):
+        P = lib.hc_abs_sample_period(L)
+        weights = [lib.hc_abs_sampled_weight(L, ph) for ph in range(16)]
+        # every chunk is sampled, and a sampled chunk stands for about its length (exactly, where P divides L)
+        assert all(w >= P for w in weights), (L, weights)
+        assert all(L - P < w < L + P for w in weights), (L, weights)
+        if L % P == 0:
+            assert set(weights) == {L}
+    # the phase turns: the sampled segments of consecutive items / waves differ (L = 4: each of the four segments in turn;
+    # L = 32: the residue mod 8 of the sampled segments walks through all eight values)
+    assert sorted(lib.hc_abs_sampled_segment(4, ph, 0) for ph in range(4)) == [0, 1, 2, 3]
+    assert sorted(lib.hc_abs_sampled_segment(32, ph, 0) % 8 for ph in range(8)) == list(range(8))

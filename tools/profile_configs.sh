@@ -12,12 +12,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/s3 -- python3 bench
 cp $(ls $out/s3/*/*kernel_stats.csv | head -1) $out/config3_one_lane_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s5 -- python3 bench.py --workload config5 --total-streams 1024 $common > $out/config5_one_lane.json 2> $out/config5.err
 cp $(ls $out/s5/*/*kernel_stats.csv | head -1) $out/config5_one_lane_kernel_stats.csv
-# the same with the detection in order on the scan's stream (RT_EXP_ONE_STREAM, read by rt_create): every stft_scan64 row is a launch with nothing beside it
-# (by default the detection of the call before starts on its own stream just ahead of the next scan and holds CUs the scan's workgroups wait for)
-RT_EXP_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s5b -- python3 bench.py --workload config5 --total-streams 1024 $common > $out/config5_one_lane_in_order.json 2> $out/config5b.err
-cp $(ls $out/s5b/*/*kernel_stats.csv | head -1) $out/config5_one_lane_in_order_kernel_stats.csv
-rm -rf $out/s3 $out/s5 $out/s5b
+# (round 6: at nperseg >= 1024 the detection runs in order on the scan's stream in the product -- rt_create: `second = R3 <= 2` -- so every stft_scan64
+# row above IS a launch with nothing beside it; the former second pass under RT_EXP_ONE_STREAM profiled the same configuration twice)
+rm -rf $out/s3 $out/s5
 tools/sq_counters.sh ${tag}_n1024 1024 2400000 128 > /dev/null
 tools/sq_counters.sh ${tag}_n4096 4096 3200000 128 > /dev/null
-grep -h "stft_scan" $out/config3_one_lane_kernel_stats.csv $out/config5_one_lane_kernel_stats.csv $out/config5_one_lane_in_order_kernel_stats.csv | cut -c1-140
+grep -h "stft_scan" $out/config3_one_lane_kernel_stats.csv $out/config5_one_lane_kernel_stats.csv | cut -c1-140
 grep -h "LDS_BANK_CONFLICT\|LDS_IDX_ACTIVE" gpurun_out/sq_${tag}_n1024.txt gpurun_out/sq_${tag}_n4096.txt | grep "0, false"

@@ -1,7 +1,8 @@
 #!/bin/bash
-# nperseg 4096: a stream's earliest chunks half as long (default) against chunks of one length (RT_EXP_ONE_LEVEL=1), same box
+# nperseg 4096: a stream's earliest chunks half as long (default) against chunks of one length (RT_EXP_ONE_LEVEL=1, read by the DIAGNOSTIC library only: both variants run on librt_analyze_diag.so), same box
 tag=$1; out=gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export RT_ANALYZE_LIB=$PWD/pyradiotracking_amd/librt_analyze_diag.so
 line() { python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$1: value', d['value'], 'ms/step', d['ms_per_step'], 'scan_ms', r['kernel_ms'], 'frac', r['frac'], 'records', d['config']['records_per_step'], 'parity', d.get('parity',{}).get('streams_mismatched'))"; }
 for rep in 1 2 3; do for v in two one; do
   unset RT_EXP_ONE_LEVEL; [ "$v" = one ] && export RT_EXP_ONE_LEVEL=1
