@@ -77,9 +77,10 @@ OTHER_CONFIGS = [
                                                 threshold_dbw=-91.0, steps=40, settle=20,
                                                 what="the deployment case: the reference's defaults from the uint8 wire format, the threshold 0.8 dB UNDER the quantisation "
                                                      "noise (-90.2 dBW per bin at 300 kS/s): AUTO reaches the exact run-length pre-filter")),
-    # sizes outside the fused scans' 256 ... 4096 (csrc/rt_general.h; dense path: transform + detect_dense, 16 bytes per sample)
-    ("nperseg128_defaults", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=128, window="hamming", trains=False, lanes=1,
-                                 what="the reference's defaults at fft_nperseg 128: stft_small (registers, one wave-private exchange) on the dense path")),
+    # half the default nperseg -- a plausible station setting: a fused scan since round 6 (lane groups of eight lanes, csrc/rt_kernels.h: stft_scan<.., QS>)
+    ("nperseg128_defaults", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=128, window="hamming", trains=False, lanes=3,
+                                 what="the reference's defaults at fft_nperseg 128: the fused scan with lane groups of eight lanes, sparse path")),
+    # a size outside the fused scans' 32 ... 4096 (csrc/rt_general.h; dense path: transform + detect_dense, 16 bytes per sample)
     ("nperseg8192", dict(streams=512, sample_rate=3200000, samples=3200000, nperseg=8192, window="hamming", trains=False, lanes=1,
                          what="fft_nperseg 8192 at 3.2 MS/s: stft_big (radix-2 in LDS, one segment per workgroup) on the dense path")),
 ]
@@ -177,7 +178,7 @@ def resolve_workload(args, world):
     return w
 
 
-SCAN_KERNEL_SYMBOL = "_ZN2rt9stft_scanILi1ELi0ELb0ELb1EEEvNS_10StftParamsE"  # rt::stft_scan<1, 0, false, true>: the default workload's scan
+SCAN_KERNEL_SYMBOL = "_ZN2rt9stft_scanILi1ELi0ELb0ELb1ELi0EEEvNS_10StftParamsE"  # rt::stft_scan<1, 0, false, true, 0>: the default workload's scan
 
 
 def scan_kernel_sha256(lib_path=None, symbol=SCAN_KERNEL_SYMBOL):
@@ -954,8 +955,7 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
     torch.cuda.empty_cache()
     kernel_ms = ms1 / iso
     two_scans = mode_used in ("prefilter", "runfilter")
-    scan_name = ("stft_scan64" if nperseg == 4096 else "stft_scan" if nperseg in (256, 512, 1024, 2048)
-                 else "stft_small (+ the dense map's round trip: frac is quoted against 8 B per sample like the rest)" if nperseg in (32, 64, 128)
+    scan_name = ("stft_scan64" if nperseg == 4096 else "stft_scan" if nperseg in (32, 64, 128, 256, 512, 1024, 2048)
                  else "stft_big (+ the dense map's round trip: frac is quoted against 8 B per sample like the rest)" if nperseg in (8192, 16384)
                  else "general transform")
     return {

@@ -28,7 +28,7 @@ RT_MODE_AUTO, RT_MODE_DENSE, RT_MODE_SPARSE, RT_MODE_PREFILTER, RT_MODE_RUNFILTE
 RT_FLAG_TIMING = 1
 RT_FLAG_NO_LIN_DETREND = 2  # subtract the segment mean before windowing even for hamming / hann / boxcar windows
 
-SUPPORTED_NPERSEG = tuple(range(8, 8193)) + (16384,)  # 8 .. 8192 and 16384 (256 .. 4096 powers of two: the fused scans; everything else: general transforms, dense path)
+SUPPORTED_NPERSEG = tuple(range(8, 8193)) + (16384,)  # 8 .. 8192 and 16384 (32 .. 4096 powers of two: the fused scans; everything else: general transforms, dense path)
 FUSED_NPERSEG = (256, 512, 1024, 2048, 4096)
 
 

@@ -111,6 +111,7 @@ struct Slot {
 struct rt_handle {
     rt_config cfg{};
     int R3 = 1, N = 256, LG = 16, GPW = 16;
+    int QS = 0;            // nperseg 128 / 64 / 32: lanes of a lane group (8 / 4 / 2; R3 = 1 there), else 0 (rt_kernels.h: stft_scan<.., QS>)
     int K = 1;             // tail columns
     int stride = 1;        // probe stride
     int L = 32;            // segments per chunk
@@ -127,9 +128,6 @@ struct rt_handle {
     bool general = false;      // nperseg is not one the fused scans cover: stft_general / stft_bluestein + detect_dense (rt_general.h), dense path only
     int log2n = 8;             // log2 of the LDS transform's length: nperseg (a power of two), or Bluestein's M
     cf *d_twg = nullptr;       // ... its twiddles W_M^j, j < M / 2
-    int small_q = 0;           // nperseg 32 / 64 / 128: nperseg / 16, served by stft_small (registers + one wave-private exchange)
-    int small_steps = 1;       // ... steps of a wave there (fixed per handle: the order of the row sums' partial sums)
-    cf *d_tws = nullptr;       // ... its pass twiddles W_N^(a k1), [small_q][16]
     bool bluestein = false;    // nperseg is not a power of two: Bluestein's algorithm with transforms of length gen_m >= 2 nperseg - 1
     int gen_m = 0;
     cf *d_cwin = nullptr;      // [nperseg] window * sqrt(scale) * exp(-i pi n^2 / nperseg)
@@ -259,7 +257,10 @@ void launch_stft_lin(rt_handle *h, const StftParams &p, int items, hipStream_t s
     // (A/B on one box, whole path, profiles/r03_h_persistent_ab.txt: config 3 one lane 662 k -> 684 k MS/s, config 5 share +1 %)
     const bool persist = scan_persistent(h->R3, MODE);
     const int blocks = persist ? std::min(items, h->n_cu * per_cu) : items;
-    switch (h->R3) {
+    switch (h->QS ? -h->QS : h->R3) {
+        case -8: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN, 8>), dim3(blocks), dim3(blk), 0, st, p); break;  // nperseg 128
+        case -4: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN, 4>), dim3(blocks), dim3(blk), 0, st, p); break;  // 64
+        case -2: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN, 2>), dim3(blocks), dim3(blk), 0, st, p); break;  // 32
         case 1: hipLaunchKernelGGL((stft_scan<1, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
         case 2: hipLaunchKernelGGL((stft_scan<2, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
         case 4: hipLaunchKernelGGL((stft_scan<4, MODE, U8, LIN>), dim3(blocks), dim3(blk), 0, st, p); break;
@@ -302,10 +303,9 @@ void launch_stft(rt_handle *h, const StftParams &p, int blocks, hipStream_t st) 
     }
 }
 
-// the general transform (rt_general.h): the dense spectrogram of a power-of-two nperseg the fused scans do not cover
-// `psum` (or null): where stft_small leaves the row sums of its workgroups.  Returns the number of partial rows per stream it wrote
-// there; 0: none (the caller runs row_sums_dense over the map).
-int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_seg, float *spec, float *tail, bool u8, float *psum = nullptr) {
+// the general transform (rt_general.h): the dense spectrogram of an nperseg the fused scans do not cover (the caller runs
+// row_sums_dense over the map)
+void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_seg, float *spec, float *tail, bool u8) {
     if (h->bluestein) {
         BluesteinParams b{};
         b.iq = iq;
@@ -338,35 +338,7 @@ int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_se
         else if (h->gen_m >= 2048) RT_BLU(2, 256);  // (1 x 512: 56.7 k at nperseg 1000, this 72 k -- enough workgroups per CU as it is)
         else RT_BLU(1, 256);
 #undef RT_BLU
-        return 0;
-    }
-    // (its stores are 8 / 16 bytes wide: a caller's map that is only float-aligned -- rt_spectrogram allows it -- takes the radix-2 kernel)
-    if (h->small_q && reinterpret_cast<uintptr_t>(spec) % 16u == 0 && reinterpret_cast<uintptr_t>(tail) % 16u == 0) {
-        SmallParams m{};
-        m.iq = iq;
-        m.stream_stride = stream_stride;
-        m.n_streams = h->cfg.n_streams;
-        m.n_seg = n_seg;
-        m.tail_cols = h->K;
-        m.window = h->d_window;
-        m.tws = h->d_tws;
-        m.spec = spec;
-        m.tail = tail;
-        m.psum = psum;
-        m.steps = h->small_steps;
-        const int per_block = 4 * (64 / h->small_q) * h->small_steps;
-        const int rows = (n_seg + per_block - 1) / per_block;
-        const unsigned blocks = (unsigned)(h->cfg.n_streams * rows);
-        if (blocks == 0) return 0;
-        switch (h->small_q * 2 + (u8 ? 1 : 0)) {
-        case 4: hipLaunchKernelGGL((stft_small<2, false>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
-        case 5: hipLaunchKernelGGL((stft_small<2, true>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
-        case 8: hipLaunchKernelGGL((stft_small<4, false>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
-        case 9: hipLaunchKernelGGL((stft_small<4, true>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
-        case 16: hipLaunchKernelGGL((stft_small<8, false>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
-        default: hipLaunchKernelGGL((stft_small<8, true>), dim3(blocks), dim3(256), 0, h->s_scan, m); break;
-        }
-        return psum ? rows : 0;
+        return;
     }
     GeneralParams g{};
     g.iq = iq;
@@ -398,7 +370,6 @@ int launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_se
         if (u8) hipLaunchKernelGGL((stft_general<true>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
         else hipLaunchKernelGGL((stft_general<false>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
     }
-    return 0;
 }
 
 // cells a run must have to pass the duration gate unless it runs through t = 0 (see rt_create)
@@ -411,9 +382,9 @@ long long min_run_cells(const rt_handle *h) { return min_run_cells(h->cfg, h->N)
 
 // segments per chunk for a handle of `n_streams` streams (for a laned handle: of all lanes together -- the lanes take the
 // parent's choice, so that a stream's row sums are added in the same order however the batch is split into lanes)
-int choose_chunk(const rt_config &cfg, int R3, int n_streams, int n_seg) {
+int choose_chunk(const rt_config &cfg, int R3, int QS, int n_streams, int n_seg) {
     if (cfg.segs_per_chunk > 0) return cfg.segs_per_chunk;
-    const int N = 256 * R3, GPW = scan_block(R3) / (16 * R3);
+    const int N = QS ? 16 * QS : 256 * R3, GPW = scan_block(R3) / (QS ? QS : 16 * R3);
     // enough workgroups to fill 256 CUs several times over, halo overhead <= 1/L
     int L = 32;
     // ... but where the run-length pre-filter is possible with chunks of 32 (minimum duration >= 64 hops) the chunks
@@ -623,8 +594,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         if (rc != RT_OK) return rc;
         RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
         if (launched) *launched = true;
-        const int rows = launch_general(h, c.iq, c.stream_stride, c.n_seg, h->d_spec, h->d_tail[c.tail_write], c.u8, sl.d_psum);
-        if (rows == 0) {
+        launch_general(h, c.iq, c.stream_stride, c.n_seg, h->d_spec, h->d_tail[c.tail_write], c.u8);
+        {
             const int64_t cells = (int64_t)h->cfg.n_streams * h->N;
             hipLaunchKernelGGL(row_sums_dense, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, h->d_spec, sl.d_psum, h->cfg.n_streams, c.n_seg, h->N);
         }
@@ -634,8 +605,8 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         a.prev = h->d_tail[c.tail_read];
         a.prev_cols = h->K;
         a.spec = h->d_spec;
-        a.psum = sl.d_psum;  // one partial row per stream (row_sums_dense), or one per workgroup of stft_small
-        a.chunks = rows ? rows : 1;
+        a.psum = sl.d_psum;  // one partial row per stream (row_sums_dense)
+        a.chunks = 1;
         hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
         RT_HIP(h, hipGetLastError());
         RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
@@ -670,7 +641,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         const int64_t cells = (int64_t)S * h->N;
         if (own_means) {
             hipLaunchKernelGGL(make_bin_thresholds_from_means, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, sl.d_psum, sp.blocks_per_stream,
-                               c.n_seg, sl.d_thr_bin, sl.d_thr_nat, S, h->R3, h->cfg.snr_threshold);
+                               c.n_seg, sl.d_thr_bin, sl.d_thr_nat, S, h->R3, h->LG, h->cfg.snr_threshold);
         } else {
         // Chunk minima are kept by this level's own scans only (round 5: the sparse scans of an AUTO handle paid for them in every
         // item's epilogue -- config 3 +1.8 % per launch -- for the one call in thousands that climbs here).  None on hand -- the handle's
@@ -693,7 +664,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         }
         const Slot &ps = h->slot[src];
         hipLaunchKernelGGL(make_bin_thresholds, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->s_scan, ps.d_chunk_min, ps.min_items, sl.d_thr_bin,
-                           sl.d_thr_nat, S, h->R3, h->L * minsum_group(h->L, h->GPW), h->cfg.snr_threshold);
+                           sl.d_thr_nat, S, h->R3, h->LG, h->L * minsum_group(h->L, std::min(h->GPW, 16)), h->cfg.snr_threshold);
         }
     }
     if (mode == RT_MODE_RUNFILTER && !second_pass_only) {
@@ -1041,7 +1012,6 @@ void rt_destroy(rt_handle *h) {
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_work);
     (void)hipFree(h->d_twg);
-    (void)hipFree(h->d_tws);
     (void)hipFree(h->d_cwin);
     (void)hipFree(h->d_bfilt);
     (void)hipFree(h->d_window);
@@ -1106,9 +1076,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         return fail_create(RT_E_INVALID, "n_streams, max_samples, window and sample_rate must be set");
     if (!(cfg->max_duration_s >= 0) || !(cfg->min_duration_s >= 0))
         return fail_create(RT_E_INVALID, "durations must be non-negative");
-    int R3 = 0;
+    int R3 = 0, QS = 0;
     for (int r : {1, 2, 4, 8, 16})
         if (cfg->nperseg == 256 * r) R3 = r;
+    for (int q : {2, 4, 8})
+        if (cfg->nperseg == 16 * q) {  // 32 / 64 / 128: the fused scans with lane groups of q lanes (rt_kernels.h: stft_scan<.., QS>)
+            R3 = 1;
+            QS = q;
+        }
     bool general = false, bluestein = false;
     if (!R3) {
         // every other size the reference may be given (it passes any integer on to SciPy): the other powers of two from 8 to 16 384 by a
@@ -1116,7 +1091,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         const int n = cfg->nperseg;
         const bool pow2 = n > 0 && (n & (n - 1)) == 0;
         if (n < 8 || (pow2 && n > kGeneralMaxN) || (!pow2 && n > kGeneralMaxN / 2))
-            return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(n) + " is not supported: 8 ... 8192, or a power of two up to 16384 (256 ... 4096 powers of "
+            return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(n) + " is not supported: 8 ... 8192, or a power of two up to 16384 (32 ... 4096 powers of "
                                                  "two run the fused scan kernels, every other size a general transform on the dense path)");
         general = true;
         bluestein = !pow2;
@@ -1144,7 +1119,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         for (int k = 0; k < lanes; ++k) {
             rt_config kc = *cfg;
             kc.lanes = 1;
-            kc.segs_per_chunk = choose_chunk(*cfg, R3, cfg->n_streams, (int)(cfg->max_samples / cfg->nperseg));  // the whole batch's choice
+            kc.segs_per_chunk = choose_chunk(*cfg, R3, QS, cfg->n_streams, (int)(cfg->max_samples / cfg->nperseg));  // the whole batch's choice
             kc.n_streams = p->kid_base[(size_t)k + 1] - p->kid_base[(size_t)k];
             rt_handle *kid = nullptr;
             g_creating_lane = true;
@@ -1173,6 +1148,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->R3 = R3;
+    h->QS = QS;
     h->general = general;
     if (general) {
         h->cfg.mode = RT_MODE_DENSE;
@@ -1183,7 +1159,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         while ((1 << h->log2n) < h->gen_m) ++h->log2n;
     }
     h->N = cfg->nperseg;
-    h->LG = 16 * R3;
+    h->LG = QS ? QS : 16 * R3;
     h->GPW = scan_block(R3) / h->LG;
     h->timing = (cfg->flags & RT_FLAG_TIMING) != 0;
     h->rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : 1024;
@@ -1195,18 +1171,9 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         if (h->K < 1) h->K = 1;
     }
     h->max_seg = (int)(cfg->max_samples / h->N);
-    h->L = choose_chunk(*cfg, R3, cfg->n_streams, h->max_seg);  // fixed per handle so the scratch bound holds for every call
+    h->L = choose_chunk(*cfg, R3, QS, cfg->n_streams, h->max_seg);  // fixed per handle so the scratch bound holds for every call
     h->max_chunks = std::max(1, (h->max_seg + h->L - 1) / h->L);
     int max_blocks_per_stream = (h->max_chunks + h->GPW - 1) / h->GPW;
-    if (general && !bluestein && (h->N == 32 || h->N == 64 || h->N == 128)) {
-        // stft_small: a workgroup walks 4 waves x (64 / Q) segments x steps of one stream and leaves one partial row of sums.  Eight
-        // steps where the batch fills the chip several times, fewer for small ones -- by the chunk length, which the lanes of a
-        // handle take from the parent: however a batch is split into lanes, a stream's sums are added in the same order.
-        h->small_q = h->N / 16;
-        h->small_steps = std::max(1, std::min(8, h->L / 4));
-        const int per_block = 4 * (64 / h->small_q) * h->small_steps;
-        max_blocks_per_stream = std::max(max_blocks_per_stream, (h->max_seg + per_block - 1) / per_block);
-    }
     h->max_blocks = max_blocks_per_stream;
     {
         // Run-length pre-filter: a run shorter than r_min cells (and not through t = 0) fails the duration gate whatever
@@ -1230,7 +1197,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         // Exact run-length pre-filter: any chunk length, any plateau length the planner's counters hold (rt_kernels.h: plan_runs).
         // Built where it is asked for, and in AUTO mode.
         h->run_cells = (int)std::max<long long>(1, std::min<long long>(r_min, 1 << 20));
-        const bool fits = !general && std::min<long long>(h->run_cells, (long long)h->max_seg + 1) <= kPlanMaxRun && h->max_seg >= 2;
+        // (lane groups of two lanes -- nperseg 32 -- hold half a planner word per row: no exact pre-filter there)
+        const bool fits = !general && h->LG >= 4 && std::min<long long>(h->run_cells, (long long)h->max_seg + 1) <= kPlanMaxRun && h->max_seg >= 2;
         if (cfg->mode == RT_MODE_RUNFILTER && !fits) {
             delete h;
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length (in STFT hops) is beyond the planner's counters");
@@ -1323,16 +1291,6 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         }
         RT_CREATE_HIP(hipMalloc(&h->d_twg, sizeof(cf) * twg.size()));
         RT_CREATE_HIP(hipMemcpy(h->d_twg, twg.data(), sizeof(cf) * twg.size(), hipMemcpyHostToDevice));
-        if (h->small_q) {
-            std::vector<cf> tws((size_t)N);
-            for (int a = 0; a < h->small_q; ++a)
-                for (int k1 = 0; k1 < 16; ++k1) {
-                    const double ang = -6.283185307179586476925286766559 * (double)((a * k1) % N) / (double)N;
-                    tws[(size_t)a * 16 + k1] = cf{(float)std::cos(ang), (float)std::sin(ang)};
-                }
-            RT_CREATE_HIP(hipMalloc(&h->d_tws, sizeof(cf) * tws.size()));
-            RT_CREATE_HIP(hipMemcpy(h->d_tws, tws.data(), sizeof(cf) * tws.size(), hipMemcpyHostToDevice));
-        }
         {
             const void *big_lds[] = {reinterpret_cast<const void *>(stft_general<false>), reinterpret_cast<const void *>(stft_general<true>),
                                      reinterpret_cast<const void *>(stft_big<false, 16, 512>), reinterpret_cast<const void *>(stft_big<true, 16, 512>),
@@ -1415,7 +1373,9 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     const double two_pi = 6.283185307179586476925286766559;
     for (int a = 0; a < LG; ++a)
         for (int k1 = 0; k1 < 16; ++k1) {
-            const double ang = -two_pi * (double)((a * k1) % N) / (double)N;
+            // (QS: register r = e QS + k1 of lane a holds A[n' = (16 / QS) a + e][k1] and takes W_N^(n' k1))
+            const int e = QS ? (((16 / QS) * a + k1 / QS) * (k1 % QS)) % N : (a * k1) % N;
+            const double ang = -two_pi * (double)e / (double)N;
             tw1[(size_t)a * 16 + k1] = cf{(float)std::cos(ang), (float)std::sin(ang)};
         }
     if (scan_wave64(R3)) {

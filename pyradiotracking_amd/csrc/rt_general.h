@@ -1,9 +1,10 @@
-// rt_general.h -- the spectrogram for every nperseg the fused scans do not cover: 32 / 64 / 128 in registers (stft_small), the other
-// powers of two in LDS (stft_general: 8 and 16; stft_big: 8192 and 16 384) and, by Bluestein's algorithm, everything else (stft_bluestein).
+// rt_general.h -- the spectrogram for every nperseg the fused scans do not cover: the powers of two below 32 and above 4096 in LDS
+// (stft_general: 8 and 16; stft_big: 8192 and 16 384) and, by Bluestein's algorithm, everything else (stft_bluestein).
+// (Round 5's stft_small -- 32 / 64 / 128 in registers, dense path -- is gone: those sizes are fused scans now, rt_kernels.h: stft_scan<.., QS>.)
 //
 // The reference hands `fft_nperseg` straight to scipy.signal.spectrogram (radiotracking/__main__.py:59,
-// analyze.py:234-241): any integer.  The fused scans (rt_kernels.h, rt_scan64.h) exist for 256 .. 4096; every other
-// power of two from 8 to 16 384 (128 and 8 192 are plausible station settings) is served here, on the dense path:
+// analyze.py:234-241): any integer.  The fused scans (rt_kernels.h, rt_scan64.h) exist for 32 .. 4096; every other
+// power of two from 8 to 16 384 (8 192 is a plausible station setting) is served here, on the dense path:
 //   stft_general   x -> constant detrend -> window -> FFT -> |X|^2 * scale   (scipy _spectral_py.py:2185-2202, 2126-2128),
 //                  written as the dense spectrogram [S][T][N] (+ the look-back tail of the last K segments),
 // followed by detect_dense (the extractor on a dense map, any number of bins).  Two passes over 4 bytes per cell like every
@@ -201,8 +202,7 @@ __device__ __forceinline__ void lds_fft_stages_dif(cf *xs, int N, int LOG, const
     }
 }
 
-// nperseg 8 and 16 -- and 32 / 64 / 128 into a map that is only float-aligned (stft_small stores 8 / 16 bytes at a time): up to 64
-// segments per workgroup.  Every other power of two has a kernel of its own below.
+// nperseg 8 and 16: up to 64 segments per workgroup.  8192 / 16 384 have a kernel of their own below.
 template <bool U8>
 __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
@@ -349,159 +349,6 @@ __global__ __launch_bounds__(BLK) void stft_big(const GeneralParams p) {
             dst[tid + BLK * (j0 + j)] = pw;
             if (tdst) tdst[tid + BLK * (j0 + j)] = pw;
         }
-    }
-}
-
-// nperseg 32, 64 and 128 (N = 16 Q, Q = 2, 4, 8): the fused scans' transform shape on the dense path.  Q lanes hold a segment,
-// sixteen points each (x[a + Q m] in lane a): a 16-point transform in registers over m, the twiddle W_N^(a k1), ONE wave-private
-// exchange through LDS (lane j takes k1 = j (16 / Q) .. for every a), 16 / Q transforms of Q points in registers, power.  A wave
-// holds 64 / Q segments per step -- 8 KiB of contiguous samples whatever Q is -- and prefetches the next step's samples into
-// registers; no workgroup barrier anywhere.  The radix-2 kernel above needs log2 N LDS round trips with barriers for the same
-// segment (nperseg 128: 7.0 ms per 1.23 GS against the fused dense scan's 2.9 at nperseg 256).
-// Exchange layout (tools/lds_banks.py rules): element (a, k1) of a segment at complex index k1 * ROW + a, segments SEG apart;
-// (ROW, SEG) = (2, 34), (4, 68), (12, 194) keep the sixteen ds_write_b64 and eight ds_read_b128 of a step at 1.0 / 1.33 / 1.67 x
-// the conflict-free cycle count (plain [16][Q] rows: 8 / 5.3 / 4 x).
-struct SmallParams {
-    const void *iq;
-    int64_t stream_stride;
-    int32_t n_streams, n_seg, tail_cols;
-    int32_t steps;         // steps of a wave: a workgroup covers 4 * (64 / Q) * steps consecutive segments of one stream
-    const float *window;   // [N] window * sqrt(scale)
-    const cf *tws;         // [Q][16] W_N^(a k1), from double precision
-    float *spec, *tail;
-    float *psum;           // [S][workgroups per stream][N] row sums of a workgroup's segments (DetectArgs::psum), or null
-};
-
-template <int Q>
-struct SmallLayout {
-    static constexpr int ROW = (Q == 8) ? 12 : Q;
-    static constexpr int SEG = (Q == 8) ? 194 : (Q == 4) ? 68 : 34;
-};
-
-template <int Q, bool U8>
-__global__ __launch_bounds__(256, 3) void stft_small(const SmallParams p) {
-    using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
-    constexpr int N = 16 * Q, SPW = 64 / Q, PER = 16 / Q;
-    constexpr int ROW = SmallLayout<Q>::ROW, SEG = SmallLayout<Q>::SEG;
-    __shared__ __attribute__((aligned(16))) cf xch[4 * SPW * SEG];
-    const int tid = threadIdx.x, lane = tid & 63, sg = lane / Q, a = lane % Q;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = p.n_seg;
-    const int per_block = 4 * SPW * p.steps;
-    const int blocks_per_stream = (T + per_block - 1) / per_block;
-    const int s = blockIdx.x / blocks_per_stream;
-    if (s >= p.n_streams) return;
-    const int seg_w0 = (blockIdx.x % blocks_per_stream) * per_block + wave * SPW * p.steps;  // the wave's first segment (uniform)
-    const raw_t *stream_iq = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride;
-    cf *const mine = xch + (wave * SPW + sg) * SEG;  // this segment slot's exchange block
-
-    // lane constants: the sixteen window coefficients and pass twiddles of this lane
-    float w[16];
-    cf tw[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        w[m] = p.window[a + Q * m];
-        tw[m] = p.tws[a * 16 + m];
-    }
-    const int voff = (sg * N + a) * (int)sizeof(raw_t);
-    auto request = [&](int seg0, raw_t (&dst)[16]) {
-        // the step's 64 / Q segments are 1 024 consecutive samples; what lies beyond the buffer reads as zero (num_records)
-        const int left = T - seg0;
-        const uint32_t bytes = left <= 0 ? 0u : (uint32_t)((left < SPW ? left : SPW) * N * (int)sizeof(raw_t));
-        const rsrc_t r = make_rsrc(stream_iq + (int64_t)(left <= 0 ? 0 : seg0) * N, bytes);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) dst[m] = buf_load_iq(r, voff, Q * m * (int)sizeof(raw_t), raw_t{});
-    };
-    float acc[16];  // row sums of this lane's bins over the wave's segments (register i Q + q: bin a PER + i + 16 q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    raw_t nxt[16];
-    request(seg_w0, nxt);
-    for (int st = 0; st < p.steps; ++st) {
-        const int seg0 = seg_w0 + st * SPW;  // (uniform)
-        if (seg0 >= T) break;
-        cf v[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = to_cf(nxt[m]);
-        if (st + 1 < p.steps) request(seg0 + SPW, nxt);
-        // detrend='constant' (scipy _signaltools.py:3926): the segment's mean over its Q lanes (the same sum in each of them)
-        float sx = 0.f, sy = 0.f;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            sx += v[m].x;
-            sy += v[m].y;
-        }
-#pragma unroll
-        for (int d = 1; d < Q; d <<= 1) {
-            sx += __shfl_xor(sx, d);
-            sy += __shfl_xor(sy, d);
-        }
-        const float mx = sx * (1.0f / (float)N), my = sy * (1.0f / (float)N);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = cf{(v[m].x - mx) * w[m], (v[m].y - my) * w[m]};
-        dft16(v);  // over m: A[a][k1] in v[k1]
-#pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw[k1]);
-        wave_sync();  // (the previous step's readers are done with the rows)
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) mine[k1 * ROW + a] = v[k1];
-        wave_sync();
-        // lane j = a takes k1 = j PER + i (i < PER) for every a': register i Q + a'
-        cf u[16];
-#pragma unroll
-        for (int r2 = 0; r2 < 8; ++r2) {
-            const int i = (2 * r2) / Q, a2 = (2 * r2) % Q;
-            const float4 t = *reinterpret_cast<const float4 *>(&mine[(a * PER + i) * ROW + a2]);
-            u[2 * r2] = cf{t.x, t.y};
-            u[2 * r2 + 1] = cf{t.z, t.w};
-        }
-        dft_groups<Q>(u);  // over a': X[k1 + 16 q] in u[i Q + q]
-        // |X|^2 (scipy _spectral_py.py:2126-2128): bins j PER + i + 16 q -- PER neighbouring bins per q
-        const int seg = seg0 + sg;
-        if (seg < T) {
-            float *dst = p.spec + ((int64_t)s * T + seg) * N + a * PER;
-            const int col = seg - (T - p.tail_cols);
-            float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N + a * PER : nullptr;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                float pw[PER];
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    const cf x = u[i * Q + q];
-                    pw[i] = __builtin_fmaf(x.x, x.x, x.y * x.y);
-                    acc[i * Q + q] += pw[i];
-                }
-                if constexpr (PER == 2) {
-                    *reinterpret_cast<float2 *>(dst + 16 * q) = make_float2(pw[0], pw[1]);
-                    if (tdst) *reinterpret_cast<float2 *>(tdst + 16 * q) = make_float2(pw[0], pw[1]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < PER; i += 4) {
-                        *reinterpret_cast<float4 *>(dst + 16 * q + i) = make_float4(pw[i], pw[i + 1], pw[i + 2], pw[i + 3]);
-                        if (tdst) *reinterpret_cast<float4 *>(tdst + 16 * q + i) = make_float4(pw[i], pw[i + 1], pw[i + 2], pw[i + 3]);
-                    }
-                }
-            }
-        }
-    }
-    // Row sums of the workgroup's segments, one partial row per workgroup in a fixed order: the 64 / Q segment slots of a wave by
-    // butterflies over the lanes that hold the same bins, then the four waves through LDS.
-    if (p.psum) {
-#pragma unroll
-        for (int d = Q; d < 64; d <<= 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += __shfl_xor(acc[r], d);
-        }
-        __syncthreads();  // (every wave is past its last exchange)
-        float *const rows = reinterpret_cast<float *>(xch);  // [4 waves][N]
-        if (sg == 0) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-#pragma unroll
-                for (int i = 0; i < PER; ++i) rows[wave * N + a * PER + i + 16 * q] = acc[i * Q + q];
-        }
-        __syncthreads();
-        if (tid < N) p.psum[((int64_t)s * blocks_per_stream + blockIdx.x % blocks_per_stream) * N + tid] = ((rows[tid] + rows[N + tid]) + rows[2 * N + tid]) + rows[3 * N + tid];
     }
 }
 

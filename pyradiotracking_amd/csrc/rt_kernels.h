@@ -256,10 +256,11 @@ __device__ __forceinline__ float dpp_add_rows(float v) {
 // ~1 000 at nperseg 4096 (profiles/r03_d_stage_stamps.txt, stage 3).
 template <int LG>
 __device__ __forceinline__ cf wave_sum(cf v) {
+    // (lane groups of 2 / 4 / 8 lanes -- nperseg 32 / 64 / 128 -- stop after the first one / two / three folds)
     v.x = dpp_add<0xB1>(v.x);   v.y = dpp_add<0xB1>(v.y);    // quad_perm [1,0,3,2]
-    v.x = dpp_add<0x4E>(v.x);   v.y = dpp_add<0x4E>(v.y);    // quad_perm [2,3,0,1]
-    v.x = dpp_add<0x141>(v.x);  v.y = dpp_add<0x141>(v.y);   // row_half_mirror
-    v.x = dpp_add<0x140>(v.x);  v.y = dpp_add<0x140>(v.y);   // row_mirror
+    if constexpr (LG >= 4) { v.x = dpp_add<0x4E>(v.x);   v.y = dpp_add<0x4E>(v.y); }    // quad_perm [2,3,0,1]
+    if constexpr (LG >= 8) { v.x = dpp_add<0x141>(v.x);  v.y = dpp_add<0x141>(v.y); }   // row_half_mirror
+    if constexpr (LG >= 16) { v.x = dpp_add<0x140>(v.x);  v.y = dpp_add<0x140>(v.y); }  // row_mirror
     if constexpr (LG >= 32) {
         v.x = dpp_add_rows<0x142, 0xA>(v.x);  v.y = dpp_add_rows<0x142, 0xA>(v.y);  // rows 1, 3 += rows 0, 2
         if constexpr (LG >= 64) {
@@ -320,10 +321,11 @@ __device__ __forceinline__ int x2_rotation(int k1) {
 }
 
 // bin index of result register r in lane `lt` of a group after the last pass
-template <int R3>
+// (LGv: lanes of a group -- 16 R3, or 8 / 4 / 2 at nperseg 128 / 64 / 32, where R3 = 1 and the last pass is over the group's lanes alike)
+template <int R3, int LGv = 16 * R3>
 __device__ __forceinline__ int bin_of(int lt, int r) {
     if constexpr (R3 == 1) {
-        return lt + 16 * r;  // k1 = lt, q1 = r
+        return lt + LGv * r;  // k1 = lt, q1 = r
     } else {
         constexpr int G = 16 / R3;
         const int k1 = lt / R3, qg = lt % R3;
@@ -336,9 +338,9 @@ __device__ __forceinline__ int bin_of(int lt, int r) {
 struct BinSlot {
     int lane, reg;
 };
-template <int R3>
+template <int R3, int LGv = 16 * R3>
 constexpr BinSlot slot_of_bin(int bin) {
-    if (R3 == 1) return BinSlot{bin % 16, bin / 16};
+    if (R3 == 1) return BinSlot{bin % LGv, bin / LGv};
     constexpr int G = 16 / R3;
     const int k1 = bin % 16, q1 = (bin / 16) % 16, q2 = bin / 256;
     const int qg = q1 / G, u = q1 % G;
@@ -435,6 +437,40 @@ __device__ __forceinline__ cf to_cf(iq_u8 x) {
     return cf{__builtin_fmaf((float)(x.iq & 0xFFu), c, -1.0f), __builtin_fmaf((float)(x.iq >> 8), c, -1.0f)};
 }
 
+// stft_scan<.., QS>: the PER = 16 / QS consecutive samples a lane holds of one sixteenth of its segment, as 16-byte loads (complex64:
+// two samples each; uint8 I/Q: 4 / 8 / 16 bytes in one load) into the registers e QS + m, e < PER.  The stream bases the host passes
+// are aligned to these loads (rt_analyze.hip: process_impl); segments are 16 QS samples long, so every run is.
+template <int PER, int QS>
+__device__ __forceinline__ void load_iq_run(const cf *p, cf (&dst)[16], int m) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int h = 0; h < PER / 2; ++h) {
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p + 2 * h));
+        dst[(2 * h) * QS + m] = cf{v.x, v.y};
+        dst[(2 * h + 1) * QS + m] = cf{v.z, v.w};
+    }
+}
+template <int PER, int QS>
+__device__ __forceinline__ void load_iq_run(const iq_u8 *p, iq_u8 (&dst)[16], int m) {
+    uint32_t w[PER / 2];
+    if constexpr (PER == 2) {
+        w[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
+    } else if constexpr (PER == 4) {
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(p));
+        w[0] = v.x;  w[1] = v.y;
+    } else {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(p));
+        w[0] = v.x;  w[1] = v.y;  w[2] = v.z;  w[3] = v.w;
+    }
+#pragma unroll
+    for (int h = 0; h < PER / 2; ++h) {
+        dst[(2 * h) * QS + m] = iq_u8{(uint16_t)(w[h] & 0xFFFFu)};
+        dst[(2 * h + 1) * QS + m] = iq_u8{(uint16_t)(w[h] >> 16)};
+    }
+}
+
 // Threads per workgroup of the scan: 256.  One wave per workgroup at nperseg 256 (its lane groups never meet a workgroup
 // barrier inside the step loop, and with four waves to a workgroup every wave waits at the end of an item for the slowest
 // of the four: 12.7 us of a 109-us item, profiles/r03_g_wave_skew.txt) was built and measured: the scan launch 4 - 8 %
@@ -458,7 +494,17 @@ __host__ __device__ constexpr int scan_block(int R3) { return R3 <= RT_ONE_WAVE_
 // so "subtract the mean from every sample" (32 subtractions per lane and step, and the transform waiting for the
 // group-wide sum) becomes "subtract sum * W[k]/N from three output bins" (six fused multiply-adds, after pass 3).
 // The host picks LIN when the window qualifies (rt_create); other windows keep the subtract-first form.
-template <int R3, int MODE, bool U8 = false, bool LIN = false>
+// QS (round 6): nperseg 128 / 64 / 32 = 16 QS, lane groups of QS = 8 / 4 / 2 lanes (R3 = 1 in every other respect: one wave-private
+// exchange, no barrier in the step loop, bin = lane + LG * register).  The transform is the 16 x QS form with the SMALL pass first:
+// lane a of a group holds the 16 / QS consecutive samples n' = (16 / QS) a + e of every sixteenth of the segment, x[n' + 16 m'] --
+// whole 128-byte lines per lane group and load instruction, eight 16-byte loads per lane and segment --
+//   pass 1 (in-lane over m', 16 / QS transforms of QS points)   A[n'][k1] = sum_m' x[n' + 16 m'] W_QS^(m' k1),  times W_N^(n' k1)
+//   exchange (LDS: row k1 of the group, column e QS + a)          lane k1 takes the sixteen n'
+//   pass 2 (in-lane over n', one 16-point transform)            X[k1 + QS k2] = sum_n' A[n'][k1] W16^(n' k2)
+// so everything behind the transform -- power, row sums, look-back tail, threshold bits, candidate emission, every MODE -- is the
+// nperseg-256 code with LG = QS.  (Round 5 served these sizes by a kernel of its own on the dense path, stft_small: 282 k MS/s at
+// nperseg 128 against the 650 k+ of the sparse path at 256.)
+template <int R3, int MODE, bool U8 = false, bool LIN = false, int QS = 0>
 // Experiment switch (default off): -DRT_WG4_MAX_R3=1 runs nperseg 256 at four workgroups per CU (its kernels need
 // <= 124 VGPRs and, with 32 staged cells per wave, exactly 40 960 B of LDS).  Measured in round 2: one lane 0.792 ->
 // 0.826 ms, two lanes 0.766 -> 0.788 ms per step (uint8 input +3 %): more waves do not help the complex64 scan.
@@ -480,11 +526,18 @@ template <int R3, int MODE, bool U8 = false, bool LIN = false>
 __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
-    constexpr int N = 256 * R3;
-    constexpr int LG = 16 * R3;
+    static_assert(QS == 0 || (R3 == 1 && (QS == 2 || QS == 4 || QS == 8)), "QS: lane groups of 2 / 4 / 8 lanes, R3 = 1");
+    constexpr int N = QS ? 16 * QS : 256 * R3;
+    constexpr int LG = QS ? QS : 16 * R3;
+    constexpr int PER = QS ? 16 / QS : 1;  // QS: consecutive samples a lane holds of every sixteenth of the segment
     constexpr int BLK = scan_block(R3);  // threads per workgroup
     constexpr int GPW = BLK / LG;  // lane groups per workgroup
     constexpr int G = 16 / R3;
+    // Exchange rows: ROW complex values per lane, GPAD more per lane group.  QS (tools/lds_banks.py rules, `small` section): the
+    // writes of a step go to column e QS + a of row k1 -- the lanes of a group side by side, the groups of a 16-lane write group in
+    // different bank quarters by the pad -- and stay conflict-free; the ds_read_b128 of a lane's row are conflict-free at QS = 2, 2-way at 4 / 8.
+    constexpr int ROW = (QS == 2) ? 16 : kRowF2;
+    constexpr int GPAD = (U8 && QS == 8) ? 0 : QS;  // (uint8 at nperseg 128: with the pad the block is 512 B over a quarter of a CU's LDS, the four-workgroup form's limit; without it the writes are 2-way)
 
     // One LDS block carved by hand: at nperseg 256 the pieces add up to exactly 40 960 B, a quarter of a CU's LDS
     // (separate __shared__ arrays cannot have size zero, and their placeholders cost the fourth workgroup).
@@ -495,7 +548,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // (nperseg 2048: 96 -- with 128 the block is 54 576 B, and LDS is handed out in 512-byte pieces: three workgroups
     // would need 164 352 of the CU's 163 840 B, so the kernel ran at two; profiles/r03_d_stage_stamps.txt)
     constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 32 : (R3 == 8) ? 96 : kStageCap;  // candidate cells staged per wave before a flush
-    constexpr size_t kXchB = sizeof(cf) * BLK * kRowF2;
+    constexpr size_t kXchB = sizeof(cf) * (BLK * ROW + GPW * GPAD);
     constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (BLK / 64) + 16 : 0;  // + the three tail_any words
     constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
     constexpr size_t kT1fB = T1_FACTORED ? sizeof(float4) * 2 * LG : 0;
@@ -512,7 +565,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // 128-byte lines) instead of a 2-byte store per lane and step: the short stores cost the scan 10 % -- a vector-memory instruction
     // per step in a kernel whose waves queue for the address path (profiles/r05_c_mode6_ablations.txt: 1 760 -> 1 587 us without
     // them).  Where a group lives inside one wave and the block still fits three times into a CU's LDS: nperseg <= 512.
-    constexpr bool BITS_LDS = (MODE == 6) && R3 <= 2;
+    constexpr bool BITS_LDS = (MODE == 6) && R3 <= 2 && (QS == 0 || QS >= 4);  // (a lane stores the words of four lanes: groups of two keep the short stores)
     constexpr size_t kBitsB = BITS_LDS ? sizeof(uint16_t) * 4 * BLK : 0;
     __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB + kBitsB];
     uint16_t *const bits_lds = reinterpret_cast<uint16_t *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB) + (BITS_LDS ? g_of(threadIdx.x, LG) * 4 * LG : 0);  // this group's [4 steps][LG]
@@ -530,7 +583,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // the transform's arithmetic form: packed pairs where the registers are free (rt_fft.h), else scalar -- same results
     constexpr bool PK = ((RT_PK_R3_MASK & R3) != 0) && (!U8 || (RT_EXP_U8_PK && R3 == 1));
     using C = typename std::conditional<PK, cfv, cf>::type;
-    C *gx = reinterpret_cast<C *>(xch + g * LG * kRowF2);  // this group's exchange rows
+    C *gx = reinterpret_cast<C *>(xch + g * (LG * ROW + GPAD));  // this group's exchange rows
 
     // window and pass twiddles staged in LDS, laid out in the order the lanes
     // read them (16-byte pieces, consecutive lanes -> consecutive pieces), and
@@ -547,8 +600,14 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     if constexpr (W_IN_LDS) {
         for (int idx = tid; idx < 4 * LG; idx += BLK) {
             const int mm = idx / LG, l = idx % LG;
-            w_lds[idx] = make_float4(p.window[l + LG * (4 * mm)], p.window[l + LG * (4 * mm + 1)],
-                                     p.window[l + LG * (4 * mm + 2)], p.window[l + LG * (4 * mm + 3)]);
+            if constexpr (QS) {
+                // register r = e QS + m' holds sample PER l + e + 16 m'
+                auto smp = [&](int r) { return p.window[PER * l + r / QS + 16 * (r % QS)]; };
+                w_lds[idx] = make_float4(smp(4 * mm), smp(4 * mm + 1), smp(4 * mm + 2), smp(4 * mm + 3));
+            } else {
+                w_lds[idx] = make_float4(p.window[l + LG * (4 * mm)], p.window[l + LG * (4 * mm + 1)],
+                                         p.window[l + LG * (4 * mm + 2)], p.window[l + LG * (4 * mm + 3)]);
+            }
         }
     }
     if constexpr (T1_IN_LDS) {
@@ -679,7 +738,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     const float thr = p.thr_s ? p.thr_s[s] : p.thr;  // wave-uniform
     // LIN: the (lane, register) slots of bins 0, 1 and N-1, slots in one register merged: lin_k[j] is this lane's
     // coefficient for register kLinReg[j] (zero in all but three lanes of a group)
-    constexpr BinSlot kS0 = slot_of_bin<R3>(0), kS1 = slot_of_bin<R3>(1), kS2 = slot_of_bin<R3>(N - 1);
+    constexpr BinSlot kS0 = slot_of_bin<R3, LG>(0), kS1 = slot_of_bin<R3, LG>(1), kS2 = slot_of_bin<R3, LG>(N - 1);
     constexpr int kLinIdx1 = (kS1.reg == kS0.reg) ? 0 : 1;
     constexpr int kLinIdx2 = (kS2.reg == kS0.reg) ? 0 : (kS2.reg == kS1.reg) ? kLinIdx1 : kLinIdx1 + 1;
     constexpr int kLinRegs = kLinIdx2 > kLinIdx1 ? kLinIdx2 + 1 : kLinIdx1 + 1;
@@ -799,12 +858,18 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #ifdef RT_EXP_ALIAS  // diagnostic build (tools/variant.sh alias -DRT_EXP_ALIAS=63): every load hits the same 64 segments of
                      // stream 0 (L2-resident) -- the scan kernel without HBM, i.e. its arithmetic + LDS floor; a mask of
                      // 8191 keeps a whole stream (16 MB at nperseg 256: misses L2, stays in the Infinity Cache)
-            const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(sc & RT_EXP_ALIAS) * N + lt;
+            const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(sc & RT_EXP_ALIAS) * N + PER * lt;
 #else
-            const raw_t *src = stream_iq + (int64_t)sc * N + lt;
+            const raw_t *src = stream_iq + (int64_t)sc * N + PER * lt;
 #endif
+            if constexpr (QS) {
+                // PER consecutive samples of every sixteenth of the segment: register e QS + m' <- sample PER lt + e + 16 m'
 #pragma unroll
-            for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
+                for (int m = 0; m < QS; ++m) load_iq_run<PER, QS>(src + 16 * m, nxt, m);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) nxt[m] = load_iq(src + LG * m);
+            }
         }
     };
     request_segment(LISTED ? seg7_cur : c0 + L - i_first);
@@ -950,7 +1015,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         RT_STAMP(4);  // window multiply (nperseg 4096: waits for the window loads)
         RT_ABLATE_STOP(1)  // loads + detrend + window
         // pass 1
-        dft16(v);
+        if constexpr (QS) dft_groups<QS>(v); else dft16(v);  // (QS: v[e QS + k1] = A[PER lt + e][k1])
         if constexpr (T1_FACTORED) {
             const float4 ta = t1f_lds[lt], tb = t1f_lds[LG + lt];
             const C w1 = make_c<C>(ta.x, ta.y), w2 = make_c<C>(ta.z, ta.w), w4 = make_c<C>(tb.x, tb.y), w8 = make_c<C>(tb.z, tb.w);
@@ -974,15 +1039,19 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const float4 t = t1_lds[kk * LG + lt];
-                if (kk) v[2 * kk] = cmul(v[2 * kk], make_c<C>(t.x, t.y));
-                v[2 * kk + 1] = cmul(v[2 * kk + 1], make_c<C>(t.z, t.w));
+                // (QS: register e QS + k1 takes W_N^((PER lt + e) k1) -- one for k1 = 0)
+                if (kk && (!QS || (2 * kk) % (QS ? QS : 1) != 0)) v[2 * kk] = cmul(v[2 * kk], make_c<C>(t.x, t.y));
+                if (!QS || (2 * kk + 1) % (QS ? QS : 1) != 0) v[2 * kk + 1] = cmul(v[2 * kk + 1], make_c<C>(t.z, t.w));
             }
         }
 
         RT_STAMP(5);  // pass 1 and its twiddles
         RT_ABLATE_STOP(2)  // + pass 1 and twiddles
         // exchange 1: element (a = lt, k1) -> row k1*R3 + b, column c
-        {
+        if constexpr (QS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gx[(r % QS) * ROW + (r / QS) * QS + lt] = v[r];  // row k1, column e QS + lt
+        } else {
             const int b = lt % R3, c = (lt / R3 + x1_rotation<R3>(lt % R3)) & 15;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) gx[(k1 * R3 + b) * kRowF2 + c] = v[k1];
@@ -998,7 +1067,19 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             for (int w = 0; w < WPG; ++w) t = cadd(t, red[w0 + w]);
             sum = t;  // (used after pass 3)
         }
-        {
+        if constexpr (QS) {
+            // column c = e QS + a of the lane's row holds n' = PER a + e: back to the order of n' (a renaming of registers)
+            const float4 *row = reinterpret_cast<const float4 *>(gx + lt * ROW);
+            C col[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float4 q = row[j];
+                col[2 * j] = make_c<C>(q.x, q.y);
+                col[2 * j + 1] = make_c<C>(q.z, q.w);
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = col[(n1 % PER) * QS + n1 / PER];
+        } else {
             const float4 *row = reinterpret_cast<const float4 *>(gx + lt * kRowF2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1092,18 +1173,18 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 // bin = lane + 16 r: every store instruction already writes 64-byte runs
                 if (to_spec) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) spec_dst[bin_of<R3>(lt, r)] = P[r];
+                    for (int r = 0; r < 16; ++r) spec_dst[bin_of<R3, LG>(lt, r)] = P[r];
                 }
                 if (to_tail) {
                     if (!FLAGS || __builtin_amdgcn_ballot_w64(tail_mask != 0xFFFFu) == 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) tail_dst[bin_of<R3>(lt, r)] = P[r];
+                        for (int r = 0; r < 16; ++r) tail_dst[bin_of<R3, LG>(lt, r)] = P[r];
                     } else if (__builtin_amdgcn_ballot_w64(tail_mask != 0u) != 0) {
                         int lt_t = lt;  // (opaque: the sixteen addresses are rebuilt here, not kept across the loop)
                         asm volatile("" : "+v"(lt_t));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            if ((tail_mask >> r) & 1u) tail_dst[bin_of<R3>(lt_t, r)] = P[r];
+                            if ((tail_mask >> r) & 1u) tail_dst[bin_of<R3, LG>(lt_t, r)] = P[r];
                         }
                     }
                 }
@@ -1140,7 +1221,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                     asm volatile("" : "+v"(lt_w));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int bin = bin_of<R3>(lt_w, r);
+                        const int bin = bin_of<R3, LG>(lt_w, r);
                         row[bin + kSkew * (bin >> 5)] = P[r];
                     }
                     group_sync<LG>();
@@ -1273,7 +1354,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                         if (e) {
                             const int r = __builtin_ctz(e);
                             e &= e - 1u;
-                            const uint32_t key = ((uint32_t)bin_of<R3>(lt_e, r) << p.tbits) | (uint32_t)seg;
+                            const uint32_t key = ((uint32_t)bin_of<R3, LG>(lt_e, r) << p.tbits) | (uint32_t)seg;
                             stg[o++] = make_uint2(key, __float_as_uint(pick_range<0, 16>(P, r)));
                         }
                     }
@@ -1289,7 +1370,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
 #pragma unroll
                     for (int r = 0; r < 16 && !gave_up; ++r) {
                         if (emit & (1u << r)) {
-                            const int bin = bin_of<R3>(lt_e, r);
+                            const int bin = bin_of<R3, LG>(lt_e, r);
                             const int bkt = bin & (kBuckets - 1);
                             const uint32_t slot = atomicAdd(&p.hot_count[s * kBuckets + bkt], 1u);
                             if (slot < (uint32_t)p.hot_cap) {
@@ -1378,9 +1459,51 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         __syncthreads();
         float *part = reinterpret_cast<float *>(xch);  // [GPW][N] floats = 16 KiB
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[g * N + bin_of<R3>(lt, r)] = chunk_ok ? acc[r] : 0.f;
+        for (int r = 0; r < 16; ++r) part[g * N + bin_of<R3, LG>(lt, r)] = chunk_ok ? acc[r] : 0.f;
         __syncthreads();
         float *dst = p.psum + ((int64_t)s * p.blocks_per_stream + cb) * N;
+        if constexpr (N < BLK) {
+            // nperseg < 256 (QS): BLK / N threads per bin, each over its sixteen lane groups in order; their sums (and minima) through
+            // LDS behind the rows just read, added in order by the first of them -- a fixed order again
+            constexpr int PARTS = BLK / N, PERP = GPW / PARTS;
+            static_assert(PERP == 16, "sixteen lane groups per part at every QS");
+            float *const part2 = part + GPW * N;  // [PARTS][N] sums, then [PARTS][N] minima (the exchange block holds >= 2 GPW N floats)
+            const int bin = tid % N, hpart = tid / N;
+            float sum = 0.f;
+#pragma unroll
+            for (int gg = 0; gg < PERP; ++gg) sum += part[(hpart * PERP + gg) * N + bin];
+            part2[hpart * N + bin] = sum;
+            if (p.chunk_min && !(RT_EXP6 & 2)) {
+                const int grp = minsum_group(L, PERP);  // (a power of two <= 16: the parts hold whole groups)
+                float mn = 3.0e38f, run = 0.f;
+                bool whole = true;
+#pragma unroll
+                for (int gg = 0; gg < PERP; ++gg) {
+                    const int ch = cb * GPW + hpart * PERP + gg;
+                    whole = whole && (ch < p.chunks && (ch + 1) * L <= T);
+                    run += part[(hpart * PERP + gg) * N + bin];
+                    if (((gg + 1) & (grp - 1)) == 0) {
+                        if (whole) mn = fminf(mn, run);
+                        run = 0.f;
+                        whole = true;
+                    }
+                }
+                part2[(PARTS + hpart) * N + bin] = mn;
+            }
+            __syncthreads();
+            if (tid < N) {
+                float tot = part2[tid];
+#pragma unroll
+                for (int h2 = 1; h2 < PARTS; ++h2) tot += part2[h2 * N + tid];
+                dst[tid] = tot;
+                if (p.chunk_min && !(RT_EXP6 & 2)) {
+                    float mn = part2[PARTS * N + tid];
+#pragma unroll
+                    for (int h2 = 1; h2 < PARTS; ++h2) mn = fminf(mn, part2[(PARTS + h2) * N + tid]);
+                    p.chunk_min[((int64_t)s * p.blocks_per_stream + cb) * N + tid] = (mn < 3.0e38f) ? __float_as_uint(mn) : 0x7f7f7f7fu;
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < N / BLK; ++j) {
             const int bin = tid + BLK * j;
@@ -1407,6 +1530,7 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
                 }
                 p.chunk_min[((int64_t)s * p.blocks_per_stream + cb) * N + bin] = (mn < 3.0e38f) ? __float_as_uint(mn) : 0x7f7f7f7fu;
             }
+        }
         }
     }
     if constexpr (!PERSIST) break;
@@ -1639,8 +1763,8 @@ __host__ __device__ inline void chunk_geometry(int n_seg, int L, bool two_level,
 __host__ __device__ constexpr bool scan_wave64(int R3) { return RT_WAVE64_4096 && R3 == 16; }
 
 // bin of result register r in lane lt of a group, R3 at run time (bin_of<R3>)
-__device__ __forceinline__ int bin_of_rt(int R3, int lt, int r) {
-    if (R3 == 1) return lt + 16 * r;
+__device__ __forceinline__ int bin_of_rt(int R3, int lg, int lt, int r) {
+    if (R3 == 1) return lt + lg * r;
     const int G = 16 / R3;
     const int k1 = lt / R3, qg = lt % R3;
     const int u = (r / R3 - ((k1 * R3 / 8) & (G - 1))) & (G - 1), q2 = r % R3;
@@ -1649,9 +1773,9 @@ __device__ __forceinline__ int bin_of_rt(int R3, int lt, int r) {
 
 // the bin whose threshold sits at position j of a stream's table in lane order (StftParams::thr_bin): [lane][16 registers] of the
 // 16-points-per-lane scans, [lane][64 registers] of stft_scan64 (bin = lane + 64 register)
-__device__ __forceinline__ int lane_order_bin(int R3, int j) {
+__device__ __forceinline__ int lane_order_bin(int R3, int lg, int j) {
     if (scan_wave64(R3)) return j / 64 + 64 * (j % 64);
-    return bin_of_rt(R3, j / 16, j % 16);
+    return bin_of_rt(R3, lg, j / 16, j % 16);
 }
 
 // Per-bin thresholds for the exact pre-filter's bits (MODE 6), from the PREVIOUS call's chunk minima.  The reference's
@@ -1665,12 +1789,12 @@ __device__ __forceinline__ int lane_order_bin(int R3, int j) {
 // more than ~2.5 dB from one buffer to the next) is analysed again (rt_fetch: a few streams dense, else the call on its own
 // row means).  No estimate (first call, buffers shorter than a chunk): theta = 0, the bits are the absolute threshold's alone.
 __global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk_min_prev /* [S][prev_items][N] */, int prev_items, float *thr_bin /* lane order */,
-                                                          float *thr_nat /* [S][N] */, int n_streams, int R3, int L, float snr) {
-    const int N = 256 * R3;
+                                                          float *thr_nat /* [S][N] */, int n_streams, int R3, int lg, int L, float snr) {
+    const int N = 16 * lg;  // (every scan holds sixteen bins per lane -- stft_scan64: 64 per lane, lg = 256 there as well)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [S][LG][16]
     if (i >= (int64_t)n_streams * N) return;
     const int s = (int)(i / N);
-    const int bin = lane_order_bin(R3, (int)(i % N));
+    const int bin = lane_order_bin(R3, lg, (int)(i % N));
     float th = 0.f;
     if (chunk_min_prev) {
         uint32_t m = 0x7f7f7f7fu;  // (positive floats order like their bits)
@@ -1685,12 +1809,12 @@ __global__ __launch_bounds__(256) void make_bin_thresholds(const uint32_t *chunk
 // The same table from THIS buffer's row means (a call analysed again after its thresholds failed the check below: the
 // failed scan left the partial row sums): theta = snr * row_mean * (1 - 1e-6), the bound itself -- the check cannot fail.
 __global__ __launch_bounds__(256) void make_bin_thresholds_from_means(const float *psum, int items_per_stream, int n_seg, float *thr_bin, float *thr_nat,
-                                                                     int n_streams, int R3, float snr) {
-    const int N = 256 * R3;
+                                                                     int n_streams, int R3, int lg, float snr) {
+    const int N = 16 * lg;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [S][LG][16]
     if (i >= (int64_t)n_streams * N) return;
     const int s = (int)(i / N);
-    const int bin = lane_order_bin(R3, (int)(i % N));
+    const int bin = lane_order_bin(R3, lg, (int)(i % N));
     double sum = 0.0;
     for (int c = 0; c < items_per_stream; ++c) sum += (double)psum[((int64_t)s * items_per_stream + c) * N + bin];
     const float avg = (float)sum / (float)n_seg;

@@ -131,9 +131,9 @@ def test_spectrogram_matches_oracle(nperseg, window):
 
 
 def test_spectrogram_into_a_map_that_is_only_float_aligned():
-    """rt_spectrogram asks for a 4-byte aligned map.  nperseg 32 / 64 / 128 normally run stft_small, whose stores are 8 / 16 bytes
-    wide: a map at an odd float offset takes the radix-2 kernel instead -- the same spectrogram within the float32 round-off of two
-    different transforms."""
+    """rt_spectrogram asks for a 4-byte aligned map, at every size (nperseg 128: round 5's kernel stored 8 / 16 bytes at a time and
+    sent such a map to another kernel; the fused scan that serves the size now stores single floats): the same spectrogram at an odd
+    float offset."""
     _need_gpu()
     fs, nperseg, n_seg = 300000, 128, 53
     n = n_seg * nperseg + 5
@@ -161,9 +161,11 @@ def test_spectrogram_into_a_map_that_is_only_float_aligned():
 # ---------------------------------------------------------------------------
 # (the cases with the noise floor at / over the threshold overflow the plain sparse path by design: AUTO and the exact
 # pre-filter take its place there -- the reference's own output is the yardstick on every level)
-# (nperseg 128 / 8192 -- n128_short, n8192_short -- run the general transform, which lives on the dense path: AUTO goes there by itself)
+# (nperseg 8192 and 300 -- n8192_short, n300_short -- run the general transforms, which live on the dense path: AUTO goes there by itself;
+# nperseg 128 -- n128_short -- is a fused scan since round 6: sparse, AUTO (which stays sparse on this clean input) and dense)
 _IQ_CASE_MODES = [(n, m) for n in gu.iq_case_names()
-                  for m in (("auto", "runfilter", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith(("n128", "n8192", "n300")) else ("sparse", "dense"))]
+                  for m in (("auto", "runfilter", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith(("n8192", "n300"))
+                            else ("sparse", "auto", "dense") if n.startswith("n128") else ("sparse", "dense"))]
 
 
 @pytest.mark.parametrize("name,mode", _IQ_CASE_MODES)
@@ -178,6 +180,8 @@ def test_golden_iq_case(name, mode):
         info = an._batch.native.call_info()
         if mode != "auto":
             assert info.mode_used == {"dense": _native.RT_MODE_DENSE, "sparse": _native.RT_MODE_SPARSE, "runfilter": _native.RT_MODE_RUNFILTER}[mode]
+        elif name.startswith("n128"):
+            assert info.mode_used == _native.RT_MODE_SPARSE and info.fell_back == 0  # (clean input: AUTO stays on the sparse level)
         else:
             assert info.mode_used != _native.RT_MODE_SPARSE  # (it overflowed: some level above finished the call)
         sigs = an._decoder.signals(rec, ["0"], [ts])
@@ -347,11 +351,12 @@ def _extract_analyzer(kwargs):
 # batching: stream i in a batch == stream i alone == oracle
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["sparse", "dense"])
-@pytest.mark.parametrize("nperseg,window,fs", [(256, "hamming", 2048000), (1024, "hann", 2400000), (4096, "hamming", 3200000)])
+@pytest.mark.parametrize("nperseg,window,fs", [(256, "hamming", 2048000), (1024, "hann", 2400000), (4096, "hamming", 3200000),
+                                               (128, "hamming", 300000), (64, "hann", 300000), (32, "hamming", 300000), (128, "blackmanharris", 2048000)])
 def test_batch_of_streams_matches_oracle(nperseg, window, fs, mode):
     _need_gpu()
     n_streams, n_buf = 7, 3
-    blen = 150 * nperseg + 77
+    blen = (150 if nperseg >= 256 else 40000 // nperseg) * nperseg + 77  # (the small sizes: 133 ms at 300 kS/s)
     w = oracle.window_coefficients(window, nperseg)
     rng = np.random.default_rng(nperseg + len(mode))
     iq = []
@@ -384,7 +389,8 @@ def test_batch_of_streams_matches_oracle(nperseg, window, fs, mode):
 
 
 @pytest.mark.parametrize("nperseg,fs,mode", [(256, 2048000, "sparse"), (256, 2048000, "prefilter"), (512, 2048000, "sparse"), (1024, 2400000, "sparse"),
-                                             (2048, 2048000, "sparse"), (4096, 3200000, "sparse"), (1024, 2400000, "dense")])
+                                             (2048, 2048000, "sparse"), (4096, 3200000, "sparse"), (1024, 2400000, "dense"),
+                                             (128, 300000, "sparse"), (128, 1024000, "prefilter"), (64, 300000, "sparse"), (32, 300000, "sparse"), (128, 300000, "dense")])
 def test_look_back_over_several_chunks(nperseg, fs, mode):
     """The sparse scans write only those look-back tail cells a walk from the next buffer can reach (per chunk of 32
     segments: the last column, and a cell whose later cells of the chunk all pass the threshold).  Runs that reach
@@ -517,7 +523,7 @@ def test_varying_buffer_lengths_and_short_buffers(mode):
     assert seen > 10
 
 
-@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann")])
+@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann"), (128, "hamming"), (64, "hann"), (32, "hamming")])
 def test_uint8_wire_format_ingestion(nperseg, window):
     """interleaved uint8 I/Q converted inside the scan kernel's load.
     (1) identical to the complex64 path fed with the same conversion; (2) against the oracle on
@@ -603,7 +609,7 @@ def test_pipelined_calls_match_serial():
         piped.fetch_records()
 
 
-@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann"), (2048, "boxcar"), (4096, "hamming")])
+@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann"), (2048, "boxcar"), (4096, "hamming"), (128, "hamming"), (64, "boxcar"), (32, "hann")])
 def test_detrend_by_linearity_equals_subtract_first(nperseg, window):
     """Hamming / hann / boxcar windows: the constant detrend is applied to the transform (mean * FFT(window) off bins
     0 and +-1) instead of to the samples.  Against the subtract-first kernels (RT_FLAG_NO_LIN_DETREND) on input with a
@@ -654,7 +660,7 @@ def test_detrend_by_linearity_equals_subtract_first(nperseg, window):
     assert len(recs[0]) > 0
 
 
-@pytest.mark.parametrize("nperseg", [256, 1024, 4096])
+@pytest.mark.parametrize("nperseg", [256, 1024, 4096, 128])
 @pytest.mark.parametrize("noise_sigma", [1e-4, 1e-5])
 def test_detrend_by_linearity_under_a_large_dc_offset(nperseg, noise_sigma):
     """An RTL-SDR's DC spike is 0.05 .. 0.1 of full scale.  The linearity form carries the whole offset through the
@@ -1424,6 +1430,8 @@ def test_auto_climbs_from_the_chunk_bit_prefilter_to_the_exact_one_under_a_high_
     (2048000, 256, 1500, 0.0),    # config-2 geometry: plateaus need 63 cells
     (2400000, 1024, 600, 0.0),    # a lane group = one wave
     (3200000, 4096, 200, 0.0),    # a lane group = four waves
+    (300000, 128, 2343, 0.0), (300000, 128, 2343, 2.0),  # lane groups of eight lanes (round 6): two planner words per row
+    (300000, 64, 3000, 0.0),      # ... of four: one word per row
 ])
 def test_exact_run_length_prefilter_equals_dense(fs, nperseg, n_seg, floor_db):
     """RT_MODE_RUNFILTER: threshold bits of every cell, cells of threshold runs of at least the minimum plateau length (or
@@ -1938,6 +1946,50 @@ def test_misaligned_device_pointers_are_refused():
     b.fetch_records()
 
 
+@pytest.mark.parametrize("nperseg", [128, 64, 32])
+def test_small_sizes_take_any_whole_sample_alignment(nperseg):
+    """nperseg 32 / 64 / 128 read 16 / 32 / 64 bytes of consecutive samples per lane (16-byte loads; uint8: 4 / 8 / 16 bytes): a
+    batch whose streams start on any whole sample -- an odd sample offset, an odd stream stride -- gives the records of the
+    same samples at an aligned place, from complex64 and from the uint8 wire format."""
+    _need_gpu()
+    fs, n_streams = 300000, 3
+    blen = 700 * nperseg + 5
+    stride = blen + 3  # odd: the second stream starts 8 bytes off a 16-byte boundary
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(nperseg)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg)
+    iq = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 6, dur_ms=(9, 30))), 70 + s) for s in range(n_streams)])
+    ref = _batch_for(kw, n_streams, blen, "sparse")
+    ref.enqueue(iq)
+    want = ref.fetch_records()
+    assert len(want) > n_streams
+    padded = np.zeros((n_streams, stride), np.complex64)
+    padded[:, :blen] = iq
+    dev = _native.DeviceBuffer(0, padded.nbytes + 64)
+    for off in (0, 8, 24):
+        dev.upload(np.concatenate([np.zeros(off // 8, np.complex64), padded.reshape(-1)]))
+        b = _batch_for(kw, n_streams, blen, "sparse")
+        b.enqueue(dev.ptr + off, n_samples=blen, stream_stride=stride)
+        assert b.fetch_records().tobytes() == want.tobytes(), off
+    # uint8: 2-byte alignment of the pairs is all that is asked
+    kw8 = dict(kw, signal_threshold_dbw=-75.0)
+    x8 = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 6, dur_ms=(9, 30), peak_dbw=(-60.0, -45.0)), noise_sigma=0.012), 80 + s)
+                   for s in range(n_streams)])
+    raw = synth.quantize_u8(x8)  # [S, 2 blen] bytes
+    ref8 = _batch_for(kw8, n_streams, blen, "sparse")
+    ref8.enqueue_bytes(raw)
+    want8 = ref8.fetch_records()
+    assert len(want8) > n_streams
+    padded8 = np.zeros((n_streams, 2 * stride), np.uint8)
+    padded8[:, :2 * blen] = raw
+    dev8 = _native.DeviceBuffer(0, padded8.nbytes + 64)
+    for off in (0, 2, 6, 10):
+        dev8.upload(np.concatenate([np.zeros(off, np.uint8), padded8.reshape(-1)]))
+        b = _batch_for(kw8, n_streams, blen, "sparse")
+        b.enqueue_bytes(dev8.ptr + off, n_samples=blen, stream_stride=stride)
+        assert b.fetch_records().tobytes() == want8.tobytes(), off
+
+
 def test_unsupported_nperseg_is_refused():
     """The reference takes any integer (radiotracking/__main__.py:59 -> scipy, analyze.py:238); here every size from 8 to 8 192 and
     the powers of two up to 16 384 run, anything else is refused with a message that says so -- and the fused-scan-only modes are
@@ -1949,8 +2001,12 @@ def test_unsupported_nperseg_is_refused():
         assert ei.value.code == _native.RT_E_UNSUPPORTED and "8 ... 8192, or a power of two up to 16384" in str(ei.value)
     for mode in ("sparse", "runfilter", "prefilter"):
         with pytest.raises(_native.NativeError) as ei:
-            _batch_for(dict(sample_rate=300000, fft_nperseg=128), 2, 128 * 100, mode)
+            _batch_for(dict(sample_rate=3200000, fft_nperseg=8192), 2, 8192 * 100, mode)
         assert ei.value.code == _native.RT_E_UNSUPPORTED and "dense path only" in str(ei.value)
+    # lane groups of two lanes (nperseg 32) hold half a planner word per row: no exact pre-filter there, AUTO does without it
+    with pytest.raises(_native.NativeError) as ei:
+        _batch_for(dict(sample_rate=300000, fft_nperseg=32), 2, 32 * 400, "runfilter")
+    assert ei.value.code == _native.RT_E_UNSUPPORTED
 
 
 @pytest.mark.parametrize("lanes,wire", [(1, "complex64"), (2, "complex64"), (1, "uint8")])
@@ -1986,7 +2042,8 @@ def test_other_powers_of_two_match_oracle(nperseg, window, fs, lanes, wire):
         else:
             b.enqueue(chunk)
         rec = b.fetch_records()
-        assert b.native.call_info().mode_used == _native.RT_MODE_DENSE
+        # (32 / 64 / 128 are fused scans since round 6: AUTO stays on the sparse level on this clean input)
+        assert b.native.call_info().mode_used == (_native.RT_MODE_SPARSE if nperseg in (32, 64, 128) else _native.RT_MODE_DENSE)
         for s in range(n_streams):
             want_all, want_kept = oas[s].process(chunk[s], gu.TS0)
             mine = rec[rec["stream"] == s]
