@@ -80,10 +80,23 @@ OTHER_CONFIGS = [
     # half the default nperseg -- a plausible station setting: a fused scan since round 6 (lane groups of eight lanes, csrc/rt_kernels.h: stft_scan<.., QS>)
     ("nperseg128_defaults", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=128, window="hamming", trains=False, lanes=3,
                                  what="the reference's defaults at fft_nperseg 128: the fused scan with lane groups of eight lanes, sparse path")),
-    # a size outside the fused scans' 32 ... 4096 (csrc/rt_general.h; dense path: transform + detect_dense, 16 bytes per sample)
+    # twice the largest size of the rounds before: a fused scan since round 6 as well (csrc/rt_scan_wg.h)
     ("nperseg8192", dict(streams=512, sample_rate=3200000, samples=3200000, nperseg=8192, window="hamming", trains=False, lanes=1,
-                         what="fft_nperseg 8192 at 3.2 MS/s: stft_big (radix-2 in LDS, one segment per workgroup) on the dense path")),
+                         what="fft_nperseg 8192 at 3.2 MS/s: stft_wg (one workgroup per segment, radix 32 x 16 x 16 in registers, two LDS exchanges), sparse path")),
 ]
+
+
+# What `sharded_configs` times after the weak-scaled headline when the bare command runs on N > 1 GPUs: north_star's own curve --
+# ONE population sharded one-subset-per-GPU (shard.stream_range), no collective on the data path (the reference: one analyzer
+# process per SDR, radiotracking/__main__.py:118-140).  Same generator and seed as `--workload config4|5`: a stream's samples
+# depend on (seed, global stream number) only, so the population is the same at every N.
+SHARDED_CONFIGS = [
+    ("config4", dict(total=32768, sample_rate=2048000, samples=524288, nperseg=256, window="hamming", trains=False,
+                     what="BASELINE config 4: 32 768 streams x 524 288 samples (137 GB) sharded over the GPUs -- north_star's 1/2/4/8 curve")),
+    ("config5", dict(total=8192, sample_rate=3200000, samples=3200000, nperseg=4096, window="hamming", trains=True,
+                     what="BASELINE config 5: 8 192 streams x 3.2 MS (210 GB) of dense tag trains sharded over the GPUs")),
+]
+N1_REFERENCE_FILE = os.path.join(REPO, "profiles", "n1_reference.json")  # the N = 1 points of those curves, measured by this script on one GPU
 
 
 def parse():
@@ -135,6 +148,10 @@ def parse():
                     help="after the headline, time the other BASELINE configurations (3, 4, the config-5 share) and the reference's default "
                          "geometry with a noise floor over its threshold in the same run -> `other_configs` in the JSON line.  auto: on for the bare "
                          "default command at N = 1")
+    ap.add_argument("--sharded-configs", default="auto", choices=["auto", "on", "off"],
+                    help="after the headline, time BASELINE configs 4 and 5 as ONE population each sharded over the ranks (strong scaling, "
+                         "north_star's curve) -> `sharded_configs` in the JSON line.  auto: on for the bare default command at N > 1")
+    ap.add_argument("--sharded-budget-s", type=float, default=300.0, help="wall-clock budget of the whole --sharded-configs block")
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps per configuration of --other-configs")
     ap.add_argument("--other-budget-s", type=float, default=240.0,
                     help="wall-clock budget of the whole --other-configs block: a configuration is only started while it is not spent")
@@ -591,6 +608,20 @@ def main():
         torch.cuda.empty_cache()
         others = other_configs(torch, args, local_rank)
 
+    # north_star's curve in the driver's own multi-GPU run: configs 4 and 5 as one population each, sharded over these same ranks
+    sharded = None
+    if args.sharded_configs == "on" or (args.sharded_configs == "auto" and world > 1 and default_workload):
+        if others is None:
+            if args.isolated_steps <= 0:
+                an.close()
+                del an
+            del iq, rec
+            torch.cuda.empty_cache()
+        try:
+            sharded = sharded_configs(torch, dist if world > 1 else None, args, rank, world, local_rank)
+        except Exception as e:  # the headline above has been measured: it is printed whatever happens to this block
+            sharded = [{"name": "sharded_configs", "failed": f"{type(e).__name__}: {e}"[:500]}]
+
     conc_frac = achieved / HBM_PEAK_GBS
     if iso_ms:
         kernel_ms, kernel_frac = iso_ms, samples_per_step_rank * bytes_per_sample / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -668,16 +699,22 @@ def main():
         out.update(latency)
     if others is not None:
         out["other_configs"] = others
+    if sharded is not None:
+        out["sharded_configs"] = sharded
     if base is not None:
         out["cpu_baseline"] = base
     if parity is not None:
         out["parity"] = parity
 
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if world > 1:
+        try:
+            if not (sharded and any("failed" in c for c in sharded)):
+                dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # (a rank that failed inside the sharded block has left the others in a collective: the line is out already)
+            pass
 
 
 def host_sinks(decoder, rec, device_names, records_per_s_produced):
@@ -956,7 +993,7 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
     kernel_ms = ms1 / iso
     two_scans = mode_used in ("prefilter", "runfilter")
     scan_name = ("stft_scan64" if nperseg == 4096 else "stft_scan" if nperseg in (32, 64, 128, 256, 512, 1024, 2048)
-                 else "stft_big (+ the dense map's round trip: frac is quoted against 8 B per sample like the rest)" if nperseg in (8192, 16384)
+                 else "stft_wg" if nperseg in (8192, 16384)
                  else "general transform")
     return {
         "name": name,
@@ -987,6 +1024,149 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
         "generate_s": round(t_gen, 1),
         "wall_s": round(time.perf_counter() - t_begin, 1),
     }
+
+
+def measure_sharded(torch, dist, name, spec, rank, world, local_rank, steps, seed=1000):
+    """One population of SHARDED_CONFIGS over the `world` ranks of this run: rank r generates and analyses the streams
+    shard.stream_range(r, world, total) in its own HBM; a barrier and a device synchronisation either side of the timed steps,
+    the MAX over ranks of the elapsed time, value = all ranks' samples / that.  Every rank checks the first and the last stream
+    of its shard against the oracle.  Collective calls (gloo, control plane only) are made by every rank in the same order."""
+    import numpy as np
+
+    from pyradiotracking_amd import shard, synth
+    from pyradiotracking_amd.analyze import BatchSignalAnalyzer, default_lanes, window_coefficients
+
+    t_begin = time.perf_counter()
+    total, fs, blen, nperseg = spec["total"], spec["sample_rate"], spec["samples"], spec["nperseg"]
+    n_seg = blen // nperseg
+    lo, hi = shard.stream_range(rank, world, total)
+    S = hi - lo
+    dev = f"cuda:{local_rank}"
+    win = window_coefficients(spec["window"], nperseg)
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=spec["window"])
+    lanes = int(spec.get("lanes") or default_lanes(nperseg, S))
+    iq = synth.make_batch_device(S, blen, fs, win, seed=seed, device=dev, trains=spec["trains"], first_stream=lo)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    an = BatchSignalAnalyzer([str(i) for i in range(lo, hi)], sdr_callback_length=blen, gpu=local_rank, mode="auto", timing=True,
+                             hip_stream=stream.cuda_stream if lanes <= 1 else None, lanes=lanes, **kw)
+
+    def run(n_steps):
+        rec = info = None
+        fell = 0
+        if n_steps:
+            an.enqueue(iq)
+        for i in range(n_steps):
+            if i + 1 < n_steps:
+                an.enqueue(iq)
+            rec = an.fetch_records()
+            info = an.call_info()
+            fell += info.fell_back
+        return rec, info, fell
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    run(int(spec.get("settle", 4)))
+    run(2)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec, info, fell_back = run(steps)
+    torch.cuda.synchronize()
+    mine_s = time.perf_counter() - t0  # this rank's own steps
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _, parity = cpu_baseline(None, an, iq, rec, kw, blen, n_seg, nperseg, timed=False)  # first and last stream of the shard
+    counts = [int(len(rec)), int(info.n_hot), int(fell_back), parity["streams_checked"], parity["streams_mismatched"], parity["records_checked"], S]
+    per_rank_ms = [mine_s / steps * 1e3]
+    worst_db = parity["worst_db_difference"]
+    if dist is not None:
+        t = torch.tensor([elapsed, worst_db], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, worst_db = float(t[0]), float(t[1])
+        c = torch.tensor(counts[:6], dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        counts[:6] = [int(v) for v in c]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (per_rank_ms[0], S))
+        per_rank_ms = [round(g[0], 4) for g in gathered]
+        streams_per_rank = [g[1] for g in gathered]
+    else:
+        per_rank_ms = [round(per_rank_ms[0], 4)]
+        streams_per_rank = [S]
+    mode_used = {1: "dense", 2: "sparse", 3: "prefilter", 4: "runfilter"}.get(info.mode_used, "?")
+    an.close()
+    del an, iq, rec
+    torch.cuda.empty_cache()
+    value = total * n_seg * nperseg * steps / elapsed / 1e6
+    ref = None
+    try:
+        with open(N1_REFERENCE_FILE) as f:
+            ref = json.load(f).get(name)
+    except (OSError, ValueError):
+        pass
+    same_population = ref is not None and (spec["total"], fs, blen, nperseg) == (ref.get("total"), ref.get("sample_rate"), ref.get("samples"), ref.get("nperseg"))
+    return {
+        "name": name,
+        "workload": f"{total} streams x {fs} SPS x {blen} samples complex64, nperseg {nperseg} {spec['window']}, "
+                    + ("tag trains, 8-16 tags/stream" if spec["trains"] else "4-8 sparse 15 ms pulses/stream") + f" -- {spec['what']}",
+        "scaling": "strong",
+        "n_gpus": world,
+        "value": round(value, 1),
+        "unit": "MSamples/s",
+        "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "per_rank_ms": per_rank_ms,
+        "streams_per_rank": streams_per_rank,
+        "lanes_per_gpu": lanes,
+        "mode": mode_used,
+        "fallbacks": counts[2],
+        "records_per_step": counts[0],
+        "candidate_cells_per_step": counts[1],
+        "whole_path_frac_per_gpu": round(value * 1e6 / world * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
+        "parity_streams_checked": counts[3],
+        "parity_streams_mismatched": counts[4],
+        "parity_records_checked": counts[5],
+        "parity_worst_db_difference": round(worst_db, 6),
+        "parity_note": "first and last stream of every rank's shard against the oracle on the same bits",
+        "speedup_vs_n1_reference": round(value / ref["value"], 3) if same_population and ref.get("value") else None,
+        "n1_reference": ({"value": ref.get("value"), "source": ref.get("source")} if same_population else None),
+        "wall_s": round(time.perf_counter() - t_begin, 1),
+    }
+
+
+def sharded_configs(torch, dist, args, rank, world, local_rank):
+    """The `sharded_configs` block: every population of SHARDED_CONFIGS in order while the block's budget lasts.  Whether a
+    configuration runs is decided on rank 0 and told to the others (every rank must make the same collective calls)."""
+    out = []
+    t0 = time.perf_counter()
+    configs = SHARDED_CONFIGS
+    if os.environ.get("RT_BENCH_SHARDED_CONFIGS_JSON"):  # (tests: a scaled-down table, same code path)
+        configs = [(n, dict(sp)) for n, sp in json.loads(os.environ["RT_BENCH_SHARDED_CONFIGS_JSON"])]
+    for name, spec in configs:
+        go = [time.perf_counter() - t0 <= args.sharded_budget_s]
+        if dist is not None:
+            dist.broadcast_object_list(go, src=0)
+        if not go[0]:
+            out.append({"name": name, "skipped": f"the block's budget of {args.sharded_budget_s:.0f} s was spent before this configuration"})
+            continue
+        try:
+            res = measure_sharded(torch, dist, name, spec, rank, world, local_rank, max(args.other_steps, int(spec.get("steps", 0))))
+            err = None
+        except Exception as e:  # (a rank that fails leaves the others in a collective: the rendezvous time-out ends the run, named below)
+            res, err = None, f"{type(e).__name__}: {e}"[:500]
+        if err is not None:
+            # (the other ranks are inside this configuration's collectives: they leave them by the rendezvous time-out and land here too;
+            # nothing further is attempted)
+            out.append({"name": name, "failed": f"rank {rank}: {err}"})
+            torch.cuda.empty_cache()
+            break
+        out.append(res)
+    return out
 
 
 def other_configs(torch, args, local_rank):

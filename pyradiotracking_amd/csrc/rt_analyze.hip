@@ -111,6 +111,8 @@ struct Slot {
 struct rt_handle {
     rt_config cfg{};
     int R3 = 1, N = 256, LG = 16, GPW = 16;
+    bool wcos = false;     // ... its window is a cosine sum of order <= 1: computed in the kernel from lin_c[0] + lin_c[1] cos(2 pi n / N) (stft_wg: WCOS)
+    int big = 0;           // nperseg 8192 / 16 384: threads of the one-workgroup-per-segment scan (256 / 512; rt_scan_wg.h: stft_wg), else 0
     int QS = 0;            // nperseg 128 / 64 / 32: lanes of a lane group (8 / 4 / 2; R3 = 1 there), else 0 (rt_kernels.h: stft_scan<.., QS>)
     int K = 1;             // tail columns
     int stride = 1;        // probe stride
@@ -244,6 +246,19 @@ int next_pow2(int v) {
 // queue in the dispatcher and find the counter exhausted.
 template <int MODE, bool U8, bool LIN>
 void launch_stft_lin(rt_handle *h, const StftParams &p, int items, hipStream_t st) {
+    if (h->big) {
+        // nperseg 8192 / 16 384: one workgroup per item (a chunk of one stream), a segment per step (rt_scan_wg.h)
+        if constexpr (MODE <= 2) {
+            if (h->big == 256) {
+                if (h->wcos) hipLaunchKernelGGL((stft_wg<256, MODE, U8, true>), dim3(items), dim3(256), wg_lds_bytes(256), st, p);
+                else hipLaunchKernelGGL((stft_wg<256, MODE, U8, false>), dim3(items), dim3(256), wg_lds_bytes(256), st, p);
+            } else {
+                if (h->wcos) hipLaunchKernelGGL((stft_wg<512, MODE, U8, true>), dim3(items), dim3(512), wg_lds_bytes(512), st, p);
+                else hipLaunchKernelGGL((stft_wg<512, MODE, U8, false>), dim3(items), dim3(512), wg_lds_bytes(512), st, p);
+            }
+        }
+        return;  // (the other modes do not exist at these sizes: rt_create refuses them)
+    }
     if (scan_wave64(h->R3)) {
         // nperseg 4096: one wave per segment, items drawn per wave; one 8-wave workgroup (all of a CU's LDS) per CU
         const int wgs = std::min((items + kW64Waves - 1) / kW64Waves, h->n_cu);
@@ -355,21 +370,8 @@ void launch_general(rt_handle *h, const void *iq, int64_t stream_stride, int n_s
     g.tail = tail;
     const int blocks = h->cfg.n_streams * ((n_seg + g.segs_per_block - 1) / g.segs_per_block);
     const size_t lds = (size_t)g.segs_per_block * h->N * sizeof(cf);
-    if (h->N >= 8192) {  // (stft_big: a segment per workgroup, samples in registers until the mean is known, padded LDS)
-        const unsigned nb = (unsigned)(h->cfg.n_streams * n_seg);
-        const size_t big_lds = (size_t)padded_len(h->N, h->log2n) * sizeof(cf);
-        if (h->N == 8192) {
-            if (u8) hipLaunchKernelGGL((stft_big<true, 16, 512>), dim3(nb), dim3(512), big_lds, h->s_scan, g);
-            else hipLaunchKernelGGL((stft_big<false, 16, 512>), dim3(nb), dim3(512), big_lds, h->s_scan, g);
-        } else {
-            // (one workgroup per CU at 128 KiB of LDS: eight waves rather than four to cover the LDS latency of the double stages)
-            if (u8) hipLaunchKernelGGL((stft_big<true, 16, 1024>), dim3(nb), dim3(1024), big_lds, h->s_scan, g);
-            else hipLaunchKernelGGL((stft_big<false, 16, 1024>), dim3(nb), dim3(1024), big_lds, h->s_scan, g);
-        }
-    } else {
-        if (u8) hipLaunchKernelGGL((stft_general<true>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
-        else hipLaunchKernelGGL((stft_general<false>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
-    }
+    if (u8) hipLaunchKernelGGL((stft_general<true>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
+    else hipLaunchKernelGGL((stft_general<false>), dim3(blocks), dim3(kGeneralBlock), lds, h->s_scan, g);
 }
 
 // cells a run must have to pass the duration gate unless it runs through t = 0 (see rt_create)
@@ -384,6 +386,16 @@ long long min_run_cells(const rt_handle *h) { return min_run_cells(h->cfg, h->N)
 // parent's choice, so that a stream's row sums are added in the same order however the batch is split into lanes)
 int choose_chunk(const rt_config &cfg, int R3, int QS, int n_streams, int n_seg) {
     if (cfg.segs_per_chunk > 0) return cfg.segs_per_chunk;
+    if (cfg.nperseg >= 8192) {
+        // stft_wg: one chunk per workgroup, 512 workgroup slots on the chip (two per CU at 8192; 256 at 16 384).  A workgroup pays
+        // ~2 steps on top of its L (tables, the first segment's round trip with nothing to overlap it, the row sums' stores): chunks of
+        // about 40 segments where the batch fills the chip eight times over, shorter ones -- down to 8 -- for small batches; then the
+        // length that leaves no short last chunk.
+        int L = 40;
+        while (L > 8 && (int64_t)n_streams * ((n_seg + L - 1) / L) < 8 * 512) L -= 8;
+        const int chunks = std::max(1, (n_seg + L - 1) / L);
+        return std::max(1, (n_seg + chunks - 1) / chunks);
+    }
     const int N = QS ? 16 * QS : 256 * R3, GPW = scan_block(R3) / (QS ? QS : 16 * R3);
     // enough workgroups to fill 256 CUs several times over, halo overhead <= 1/L
     int L = 32;
@@ -1084,6 +1096,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             R3 = 1;
             QS = q;
         }
+    int big = 0;
+    if (cfg->nperseg == 8192 || cfg->nperseg == 16384) {  // one workgroup per segment (rt_scan_wg.h: stft_wg), sparse and dense path
+        R3 = 1;  // (sizes scratch nobody uses at these sizes)
+        big = wg_block(cfg->nperseg);
+    }
     bool general = false, bluestein = false;
     if (!R3) {
         // every other size the reference may be given (it passes any integer on to SciPy): the other powers of two from 8 to 16 384 by a
@@ -1091,8 +1108,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         const int n = cfg->nperseg;
         const bool pow2 = n > 0 && (n & (n - 1)) == 0;
         if (n < 8 || (pow2 && n > kGeneralMaxN) || (!pow2 && n > kGeneralMaxN / 2))
-            return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(n) + " is not supported: 8 ... 8192, or a power of two up to 16384 (32 ... 4096 powers of "
-                                                 "two run the fused scan kernels, every other size a general transform on the dense path)");
+            return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(n) + " is not supported: 8 ... 8192, or a power of two up to 16384 (the powers of two from 32 "
+                                                 "on run the fused scan kernels, every other size a general transform on the dense path)");
         general = true;
         bluestein = !pow2;
         R3 = 1;  // (sizes the scratch the general path does not use)
@@ -1100,6 +1117,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     if (cfg->mode < RT_MODE_AUTO || cfg->mode > RT_MODE_RUNFILTER) return fail_create(RT_E_INVALID, "bad mode");
     if (general && cfg->mode != RT_MODE_AUTO && cfg->mode != RT_MODE_DENSE)
         return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(cfg->nperseg) + " runs on the dense path only: mode must be RT_MODE_AUTO or RT_MODE_DENSE");
+    if (big && (cfg->mode == RT_MODE_PREFILTER || cfg->mode == RT_MODE_RUNFILTER))
+        return fail_create(RT_E_UNSUPPORTED, "fft_nperseg " + std::to_string(cfg->nperseg) + " has the sparse and the dense path only: mode must be RT_MODE_AUTO, RT_MODE_SPARSE or RT_MODE_DENSE");
     if (cfg->lanes > 1 && cfg->n_streams > 1) {
         // stream groups on their own handles and HIP streams: the detection kernels, launch gaps and last
         // workgroup round of one group overlap the scan of another
@@ -1148,6 +1167,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->R3 = R3;
+    h->big = big;
     h->QS = QS;
     h->general = general;
     if (general) {
@@ -1160,7 +1180,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     }
     h->N = cfg->nperseg;
     h->LG = QS ? QS : 16 * R3;
-    h->GPW = scan_block(R3) / h->LG;
+    h->GPW = big ? 1 : scan_block(R3) / h->LG;  // (stft_wg: a chunk per workgroup)
     h->timing = (cfg->flags & RT_FLAG_TIMING) != 0;
     h->rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : 1024;
     h->stride = probe_stride(h->N, cfg->sample_rate, cfg->min_duration_s);
@@ -1180,7 +1200,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         // else holds -- (len + 1) * hop < signal_min_duration (analyze.py:427-430; rt_core.h: gate_run), with a margin of
         // 1e-9 for the rounding of the float64 expressions.  A run of >= 2 L - 1 cells covers an aligned chunk of L.
         const long long r_min = min_run_cells(h);
-        h->prefilter_ok = !general && h->L >= 4 && 2ll * h->L - 1 <= r_min && h->max_seg >= 2 * h->L &&
+        h->prefilter_ok = !general && !big && h->L >= 4 && 2ll * h->L - 1 <= r_min && h->max_seg >= 2 * h->L &&
                           h->max_chunks <= (1 << 18);  // (plan_pass_b keeps a bit per chunk in LDS)
         if (cfg->mode == RT_MODE_PREFILTER && !h->prefilter_ok) {
             delete h;
@@ -1198,7 +1218,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         // Built where it is asked for, and in AUTO mode.
         h->run_cells = (int)std::max<long long>(1, std::min<long long>(r_min, 1 << 20));
         // (lane groups of two lanes -- nperseg 32 -- hold half a planner word per row: no exact pre-filter there)
-        const bool fits = !general && h->LG >= 4 && std::min<long long>(h->run_cells, (long long)h->max_seg + 1) <= kPlanMaxRun && h->max_seg >= 2;
+        const bool fits = !general && !big && h->LG >= 4 && std::min<long long>(h->run_cells, (long long)h->max_seg + 1) <= kPlanMaxRun && h->max_seg >= 2;
         if (cfg->mode == RT_MODE_RUNFILTER && !fits) {
             delete h;
             return fail_create(RT_E_UNSUPPORTED, "RT_MODE_RUNFILTER: the minimum plateau length (in STFT hops) is beyond the planner's counters");
@@ -1266,7 +1286,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         // step; nperseg 4096: 5.09 ms per launch in order against 5.34 with the detection's stream beside it, round 4's csv).
         // The lanes of a laned handle overlap one another's tails already (config 2 two lanes 0.688 -> 0.735 with a second stream
         // per lane).  Stream priorities changed none of this.
-        bool second = R3 <= 2 && !g_creating_lane;
+        bool second = R3 <= 2 && !big && !g_creating_lane;  // (stft_wg's launches fill the chip many times over: in order, like nperseg >= 1024)
         if (const char *v = RT_DIAG_ENV("RT_EXP_TAIL")) h->tail_mode = (v[0] == 'C') ? 1 : 0;
         if (const char *v = RT_DIAG_ENV("RT_EXP_STREAMS")) second = (v[0] == '2');  // (diagnostic builds: "1" / "2" force the choice, lanes included)
         if (!second) {
@@ -1293,8 +1313,6 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipMemcpy(h->d_twg, twg.data(), sizeof(cf) * twg.size(), hipMemcpyHostToDevice));
         {
             const void *big_lds[] = {reinterpret_cast<const void *>(stft_general<false>), reinterpret_cast<const void *>(stft_general<true>),
-                                     reinterpret_cast<const void *>(stft_big<false, 16, 512>), reinterpret_cast<const void *>(stft_big<true, 16, 512>),
-                                     reinterpret_cast<const void *>(stft_big<false, 16, 1024>), reinterpret_cast<const void *>(stft_big<true, 16, 1024>),
                                      reinterpret_cast<const void *>(stft_bluestein<false, 1, 256>), reinterpret_cast<const void *>(stft_bluestein<true, 1, 256>),
                                      reinterpret_cast<const void *>(stft_bluestein<false, 2, 256>), reinterpret_cast<const void *>(stft_bluestein<true, 2, 256>),
                                      reinterpret_cast<const void *>(stft_bluestein<false, 2, 512>), reinterpret_cast<const void *>(stft_bluestein<true, 2, 512>),
@@ -1378,6 +1396,22 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             const double ang = -two_pi * (double)e / (double)N;
             tw1[(size_t)a * 16 + k1] = cf{(float)std::cos(ang), (float)std::sin(ang)};
         }
+    if (big) {
+        // stft_wg: W_N^(t 2^i), i < 5, as [i][t]; W_BLK^(d p) as [d][p] (rt_scan_wg.h)
+        const int R = big / 16;
+        tw1.assign((size_t)5 * big, cf{1.f, 0.f});
+        for (int i = 0; i < 5; ++i)
+            for (int t = 0; t < big; ++t) {
+                const double ang = -two_pi * (double)(((long long)t << i) % N) / (double)N;
+                tw1[(size_t)i * big + t] = cf{(float)std::cos(ang), (float)std::sin(ang)};
+            }
+        tw2.assign((size_t)R * 16, cf{1.f, 0.f});
+        for (int d = 0; d < R; ++d)
+            for (int pp = 0; pp < 16; ++pp) {
+                const double ang = -two_pi * (double)((d * pp) % big) / (double)big;
+                tw2[(size_t)d * 16 + pp] = cf{(float)std::cos(ang), (float)std::sin(ang)};
+            }
+    }
     if (scan_wave64(R3)) {
         // stft_scan64: W_N^(ka n1) with n1 = c + 8 d as W^(8 ka d) (rows 0..6, d = 1..7) times W^(ka c) (rows 7..13, c = 1..7), lane ka
         tw1.assign((size_t)kW64TwRows * 64, cf{1.f, 0.f});
@@ -1388,7 +1422,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                 tw1[(size_t)row * 64 + ka] = cf{(float)std::cos(ang), (float)std::sin(ang)};
             }
     }
-    for (int b = 0; b < R3; ++b)
+    for (int b = 0; b < R3 && !big; ++b)
         for (int q1 = 0; q1 < 16; ++q1) {
             // W_LG^(b q1), times the phase W16^(-s q1) that undoes the column rotation s = x1_rotation(b) of exchange 1
             // (rt_kernels.h): together W_LG^((b - s R3) q1), the exponent reduced in integers
@@ -1418,6 +1452,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         const double root = std::sqrt((double)cfg->scale);
         for (int i = 0; i < N; ++i) ws[(size_t)i] = (float)((double)cfg->window[i] * root);
         RT_CREATE_HIP(hipMemcpy(h->d_window, ws.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        if (big) {
+            // stft_wg reads the window in thread order: [t][32] = window[t + BLK j]
+            std::vector<float> wt((size_t)N);
+            for (int t = 0; t < big; ++t)
+                for (int j = 0; j < 32; ++j) wt[(size_t)t * 32 + j] = ws[(size_t)t + (size_t)big * j];
+            RT_CREATE_HIP(hipMalloc(&h->d_window_t, sizeof(float) * N));
+            RT_CREATE_HIP(hipMemcpy(h->d_window_t, wt.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        }
         if (R3 == 16) {
             std::vector<float> wt((size_t)N);
             for (int l = 0; l < LG; ++l)
@@ -1453,12 +1495,21 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             dev = std::max(dev, std::fabs((double)ws[(size_t)n] - fit));
         }
         const double w0 = std::fabs(wr[0]);
-        bool ok = w0 > 0.0 && !(cfg->flags & RT_FLAG_NO_LIN_DETREND) && dev <= 1e-6 * wmax;
+        bool cosine_sum = w0 > 0.0 && dev <= 1e-6 * wmax;
         for (int j = 0; j < 3; ++j)
-            if (std::fabs(wi[j]) > 1e-6 * w0) ok = false;  // real transform (w[n] = w[N-n])
+            if (std::fabs(wi[j]) > 1e-6 * w0) cosine_sum = false;  // real transform (w[n] = w[N-n])
+        const bool ok = cosine_sum && !(cfg->flags & RT_FLAG_NO_LIN_DETREND) && !big;
         h->lin = ok;
         if (ok) {
             for (int j = 0; j < 3; ++j) h->lin_c[j] = (float)(wr[j] / N);
+        }
+        if (big) {
+            // stft_wg subtracts the mean first, in SciPy's order (no linearity form, no guard); what it takes from the fit is the WINDOW:
+            // w[n] = c0 + c1 cos(2 pi n / N), c0 = W[0] / N, c1 = (W[1] + W[N-1]) / N (rt_scan_wg.h: WCOS)
+            h->wcos = cosine_sum;
+            h->lin_c[0] = (float)(wr[0] / N);
+            h->lin_c[1] = (float)((wr[1] + wr[2]) / N);
+            h->lin_c[2] = 0.f;
         }
     }
     RT_CREATE_HIP(hipMemcpy(h->d_tw1, tw1.data(), sizeof(cf) * tw1.size(), hipMemcpyHostToDevice));
@@ -1525,6 +1576,14 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         RT_CREATE_HIP(hipEventCreate(&sl.ev_done));
     }
 
+    if (big) {
+#define RT_WG_SET(B_, M_, U_, W_) RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_wg<B_, M_, U_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_lds_bytes(B_)))
+#define RT_WG_SET4(B_, M_) RT_WG_SET(B_, M_, false, false); RT_WG_SET(B_, M_, false, true); RT_WG_SET(B_, M_, true, false); RT_WG_SET(B_, M_, true, true)
+        RT_WG_SET4(256, 0); RT_WG_SET4(256, 1); RT_WG_SET4(256, 2);
+        RT_WG_SET4(512, 0); RT_WG_SET4(512, 1); RT_WG_SET4(512, 2);
+#undef RT_WG_SET4
+#undef RT_WG_SET
+    }
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
@@ -2216,8 +2275,8 @@ int rt_calibrate_read(rt_handle *h, const void *iq_dev, int64_t n_samples, int64
     }
     RT_HIP(h, hipSetDevice(h->cfg.device));
     const int T = (int)(n_samples / h->N);
-    if (h->general) {
-        h->err = "rt_calibrate_read: the load stream of the fused scans only (nperseg 256 ... 4096)";
+    if (h->general || h->big) {
+        h->err = "rt_calibrate_read: the load stream of the fused scans of nperseg 32 ... 4096 only";
         return RT_E_UNSUPPORTED;
     }
     if (T < 2) return RT_OK;

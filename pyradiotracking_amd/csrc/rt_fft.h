@@ -243,5 +243,29 @@ __device__ __forceinline__ void dft64(C (&v)[64]) {
     dft64_finish(v);
 }
 
+// 32-point DFT in place, natural order in and out:  n = n0 + 2 n1, k = ka + 16 kb.
+// Two 16-point transforms (even / odd inputs), W32^ka = W64^(2 ka) on the odd one's outputs, sixteen 2-point transforms.
+template <class C>
+__device__ __forceinline__ void dft32(C (&v)[32]) {
+    C a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        a[i] = v[2 * i];
+        b[i] = v[2 * i + 1];
+    }
+    dft16(a);
+    dft16(b);
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+        C t = b[ka];
+        if (ka == 4) t = mul_w8_1(t);
+        else if (ka == 8) t = mul_mi(t);
+        else if (ka == 12) t = mul_w8_3(t);
+        else if (ka) t = cmul_const(t, kW64Re[2 * ka], kW64Im[2 * ka]);
+        v[ka] = cadd(a[ka], t);
+        v[ka + 16] = csub(a[ka], t);
+    }
+}
+
 }  // namespace rt
 #endif

@@ -1,10 +1,11 @@
-// rt_general.h -- the spectrogram for every nperseg the fused scans do not cover: the powers of two below 32 and above 4096 in LDS
-// (stft_general: 8 and 16; stft_big: 8192 and 16 384) and, by Bluestein's algorithm, everything else (stft_bluestein).
-// (Round 5's stft_small -- 32 / 64 / 128 in registers, dense path -- is gone: those sizes are fused scans now, rt_kernels.h: stft_scan<.., QS>.)
+// rt_general.h -- the spectrogram for every nperseg the fused scans do not cover: 8 and 16 in LDS (stft_general) and, by Bluestein's
+// algorithm on LDS transforms of up to 16 384 points, every size that is not a power of two (stft_bluestein).
+// (Round 5's stft_small -- 32 / 64 / 128 in registers -- and stft_big -- 8192 / 16 384, radix-2 in LDS -- are gone: those sizes are fused
+// scans since round 6: rt_kernels.h: stft_scan<.., QS>, rt_scan_wg.h: stft_wg.)
 //
 // The reference hands `fft_nperseg` straight to scipy.signal.spectrogram (radiotracking/__main__.py:59,
-// analyze.py:234-241): any integer.  The fused scans (rt_kernels.h, rt_scan64.h) exist for 32 .. 4096; every other
-// power of two from 8 to 16 384 (8 192 is a plausible station setting) is served here, on the dense path:
+// analyze.py:234-241): any integer.  The fused scans (rt_kernels.h, rt_scan64.h, rt_scan_wg.h) exist for the powers of two from 32 to
+// 16 384; 8, 16 and every other size up to 8 192 are served here, on the dense path:
 //   stft_general   x -> constant detrend -> window -> FFT -> |X|^2 * scale   (scipy _spectral_py.py:2185-2202, 2126-2128),
 //                  written as the dense spectrogram [S][T][N] (+ the look-back tail of the last K segments),
 // followed by detect_dense (the extractor on a dense map, any number of bins).  Two passes over 4 bytes per cell like every
@@ -202,7 +203,7 @@ __device__ __forceinline__ void lds_fft_stages_dif(cf *xs, int N, int LOG, const
     }
 }
 
-// nperseg 8 and 16: up to 64 segments per workgroup.  8192 / 16 384 have a kernel of their own below.
+// nperseg 8 and 16: up to 64 segments per workgroup.
 template <bool U8>
 __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
@@ -267,87 +268,6 @@ __global__ __launch_bounds__(kGeneralBlock) void stft_general(const GeneralParam
             const float pw = __builtin_fmaf(v.x, v.x, v.y * v.y);
             dst[k] = pw;
             if (tdst) tdst[k] = pw;
-        }
-    }
-}
-
-// nperseg 8192 / 16 384 (N = 256 PT, PT = 32 / 64): one segment per workgroup, like stft_general at these sizes, without its three
-// passes over bit-reversed places.  There a thread's samples went to LDS raw, came back for detrend and window and went out again --
-// and at bit-reversed places the 64 lanes of a wave, neighbours in the segment, lie N / 64 elements apart: every one of those
-// ds_write / ds_read instructions met in ONE bank pair, 64 cycles each, more than half of the kernel's LDS time (the butterflies'
-// seven double stages are the rest).  Here the samples stay in registers (PT per thread) until the mean is known, detrend and window
-// happen there, and the single scatter goes to padded places (pad_at).
-template <bool U8, int PT, int BLK = kGeneralBlock>
-__global__ __launch_bounds__(BLK) void stft_big(const GeneralParams p) {
-    using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
-    constexpr int N = BLK * PT, LOG = (N == 8192) ? 13 : 14, U = (N / 4 / BLK < 8) ? N / 4 / BLK : 8, NW = BLK / 64;
-    static_assert(N == 8192 || N == 16384, "stft_big: nperseg 8192 or 16384");
-    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
-    cf *const xs = reinterpret_cast<cf *>(big_smem);  // [padded_len(N, LOG)]
-    constexpr int PS = pad_shift(LOG);
-    __shared__ double red[2 * NW];
-    __shared__ cf tw_hi[N / 2 / kTwSplit], tw_lo[kTwSplit];
-    const int T = p.n_seg, tid = threadIdx.x;
-    fft_stage_tables(tw_hi, tw_lo, p.tw, N, tid, BLK);
-    const int s = blockIdx.x / T, seg = blockIdx.x % T;
-    if (s >= p.n_streams) return;
-    const raw_t *src = reinterpret_cast<const raw_t *>(p.iq) + (int64_t)s * p.stream_stride + (int64_t)seg * N;
-    raw_t raw[PT];
-#pragma unroll
-    for (int j = 0; j < PT; ++j) raw[j] = load_iq(src + tid + BLK * j);
-    // the segment's mean from a float64 sum (stft_general: why), in a fixed order: a thread's samples, the wave's lanes by
-    // butterflies, the four waves
-    double sx = 0.0, sy = 0.0;
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const cf v = to_cf(raw[j]);
-        sx += (double)v.x;
-        sy += (double)v.y;
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        sx += __shfl_xor(sx, d);
-        sy += __shfl_xor(sy, d);
-    }
-    if ((tid & 63) == 0) {
-        red[2 * (tid >> 6)] = sx;
-        red[2 * (tid >> 6) + 1] = sy;
-    }
-    __syncthreads();
-    double tx = 0.0, ty = 0.0;
-#pragma unroll
-    for (int wv = 0; wv < NW; ++wv) {
-        tx += red[2 * wv];
-        ty += red[2 * wv + 1];
-    }
-    const float mx = (float)(tx / (double)N), my = (float)(ty / (double)N);
-    // detrend='constant' (scipy _signaltools.py:3926), window (times sqrt(scale)), to the bit-reversed place
-#pragma unroll
-    for (int j0 = 0; j0 < PT; j0 += 16) {
-        float w[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = p.window[tid + BLK * (j0 + j)];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const cf v = to_cf(raw[j0 + j]);
-            xs[pad_at((int)(__brev((unsigned)(tid + BLK * (j0 + j))) >> (32 - LOG)), PS)] = cf{(v.x - mx) * w[j], (v.y - my) * w[j]};
-        }
-    }
-    __syncthreads();
-    lds_fft_stages<U>(xs, N, LOG, p.tw, tid, BLK, true, tw_hi, tw_lo, PS);
-    float *dst = p.spec + ((int64_t)s * T + seg) * N;
-    const int col = seg - (T - p.tail_cols);
-    float *tdst = (p.tail && col >= 0) ? p.tail + ((int64_t)s * p.tail_cols + col) * N : nullptr;
-#pragma unroll
-    for (int j0 = 0; j0 < PT; j0 += 16) {
-        cf v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = xs[pad_at(tid + BLK * (j0 + j), PS)];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float pw = __builtin_fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
-            dst[tid + BLK * (j0 + j)] = pw;
-            if (tdst) tdst[tid + BLK * (j0 + j)] = pw;
         }
     }
 }

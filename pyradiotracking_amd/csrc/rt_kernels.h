@@ -2926,4 +2926,5 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
 }  // namespace rt
 
 #include "rt_scan64.h"  // the nperseg-4096 scan (one wave per segment)
+#include "rt_scan_wg.h"  // the nperseg-8192 / 16 384 scan (one workgroup per segment)
 #endif

@@ -161,11 +161,11 @@ def test_spectrogram_into_a_map_that_is_only_float_aligned():
 # ---------------------------------------------------------------------------
 # (the cases with the noise floor at / over the threshold overflow the plain sparse path by design: AUTO and the exact
 # pre-filter take its place there -- the reference's own output is the yardstick on every level)
-# (nperseg 8192 and 300 -- n8192_short, n300_short -- run the general transforms, which live on the dense path: AUTO goes there by itself;
-# nperseg 128 -- n128_short -- is a fused scan since round 6: sparse, AUTO (which stays sparse on this clean input) and dense)
+# (nperseg 300 -- n300_short -- runs Bluestein's transform, which lives on the dense path: AUTO goes there by itself; nperseg 128 and
+# 8192 -- n128_short, n8192_short -- are fused scans since round 6: sparse, AUTO (which stays sparse on this clean input) and dense)
 _IQ_CASE_MODES = [(n, m) for n in gu.iq_case_names()
-                  for m in (("auto", "runfilter", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith(("n8192", "n300"))
-                            else ("sparse", "auto", "dense") if n.startswith("n128") else ("sparse", "dense"))]
+                  for m in (("auto", "runfilter", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith("n300")
+                            else ("sparse", "auto", "dense") if n.startswith(("n128", "n8192")) else ("sparse", "dense"))]
 
 
 @pytest.mark.parametrize("name,mode", _IQ_CASE_MODES)
@@ -180,7 +180,7 @@ def test_golden_iq_case(name, mode):
         info = an._batch.native.call_info()
         if mode != "auto":
             assert info.mode_used == {"dense": _native.RT_MODE_DENSE, "sparse": _native.RT_MODE_SPARSE, "runfilter": _native.RT_MODE_RUNFILTER}[mode]
-        elif name.startswith("n128"):
+        elif name.startswith(("n128", "n8192")):
             assert info.mode_used == _native.RT_MODE_SPARSE and info.fell_back == 0  # (clean input: AUTO stays on the sparse level)
         else:
             assert info.mode_used != _native.RT_MODE_SPARSE  # (it overflowed: some level above finished the call)
@@ -352,11 +352,12 @@ def _extract_analyzer(kwargs):
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["sparse", "dense"])
 @pytest.mark.parametrize("nperseg,window,fs", [(256, "hamming", 2048000), (1024, "hann", 2400000), (4096, "hamming", 3200000),
-                                               (128, "hamming", 300000), (64, "hann", 300000), (32, "hamming", 300000), (128, "blackmanharris", 2048000)])
+                                               (128, "hamming", 300000), (64, "hann", 300000), (32, "hamming", 300000), (128, "blackmanharris", 2048000),
+                                               (8192, "hamming", 3200000), (16384, "hann", 3200000), (8192, "blackmanharris", 3200000)])
 def test_batch_of_streams_matches_oracle(nperseg, window, fs, mode):
     _need_gpu()
     n_streams, n_buf = 7, 3
-    blen = (150 if nperseg >= 256 else 40000 // nperseg) * nperseg + 77  # (the small sizes: 133 ms at 300 kS/s)
+    blen = (150 if 256 <= nperseg <= 4096 else 100 if nperseg > 4096 else 40000 // nperseg) * nperseg + 77  # (the small sizes: 133 ms at 300 kS/s)
     w = oracle.window_coefficients(window, nperseg)
     rng = np.random.default_rng(nperseg + len(mode))
     iq = []
@@ -390,7 +391,8 @@ def test_batch_of_streams_matches_oracle(nperseg, window, fs, mode):
 
 @pytest.mark.parametrize("nperseg,fs,mode", [(256, 2048000, "sparse"), (256, 2048000, "prefilter"), (512, 2048000, "sparse"), (1024, 2400000, "sparse"),
                                              (2048, 2048000, "sparse"), (4096, 3200000, "sparse"), (1024, 2400000, "dense"),
-                                             (128, 300000, "sparse"), (128, 1024000, "prefilter"), (64, 300000, "sparse"), (32, 300000, "sparse"), (128, 300000, "dense")])
+                                             (128, 300000, "sparse"), (128, 1024000, "prefilter"), (64, 300000, "sparse"), (32, 300000, "sparse"), (128, 300000, "dense"),
+                                             (8192, 3200000, "sparse"), (8192, 3200000, "dense")])
 def test_look_back_over_several_chunks(nperseg, fs, mode):
     """The sparse scans write only those look-back tail cells a walk from the next buffer can reach (per chunk of 32
     segments: the last column, and a cell whose later cells of the chunk all pass the threshold).  Runs that reach
@@ -523,7 +525,7 @@ def test_varying_buffer_lengths_and_short_buffers(mode):
     assert seen > 10
 
 
-@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann"), (128, "hamming"), (64, "hann"), (32, "hamming")])
+@pytest.mark.parametrize("nperseg,window", [(256, "hamming"), (1024, "hann"), (128, "hamming"), (64, "hann"), (32, "hamming"), (8192, "hamming")])
 def test_uint8_wire_format_ingestion(nperseg, window):
     """interleaved uint8 I/Q converted inside the scan kernel's load.
     (1) identical to the complex64 path fed with the same conversion; (2) against the oracle on
@@ -2001,8 +2003,13 @@ def test_unsupported_nperseg_is_refused():
         assert ei.value.code == _native.RT_E_UNSUPPORTED and "8 ... 8192, or a power of two up to 16384" in str(ei.value)
     for mode in ("sparse", "runfilter", "prefilter"):
         with pytest.raises(_native.NativeError) as ei:
-            _batch_for(dict(sample_rate=3200000, fft_nperseg=8192), 2, 8192 * 100, mode)
+            _batch_for(dict(sample_rate=300000, fft_nperseg=300), 2, 300 * 100, mode)
         assert ei.value.code == _native.RT_E_UNSUPPORTED and "dense path only" in str(ei.value)
+    # nperseg 8192 / 16 384 (one workgroup per segment): the sparse and the dense path, no pre-filter levels
+    for mode in ("runfilter", "prefilter"):
+        with pytest.raises(_native.NativeError) as ei:
+            _batch_for(dict(sample_rate=3200000, fft_nperseg=8192), 2, 8192 * 100, mode)
+        assert ei.value.code == _native.RT_E_UNSUPPORTED and "sparse and the dense path only" in str(ei.value)
     # lane groups of two lanes (nperseg 32) hold half a planner word per row: no exact pre-filter there, AUTO does without it
     with pytest.raises(_native.NativeError) as ei:
         _batch_for(dict(sample_rate=300000, fft_nperseg=32), 2, 32 * 400, "runfilter")
@@ -2042,8 +2049,8 @@ def test_other_powers_of_two_match_oracle(nperseg, window, fs, lanes, wire):
         else:
             b.enqueue(chunk)
         rec = b.fetch_records()
-        # (32 / 64 / 128 are fused scans since round 6: AUTO stays on the sparse level on this clean input)
-        assert b.native.call_info().mode_used == (_native.RT_MODE_SPARSE if nperseg in (32, 64, 128) else _native.RT_MODE_DENSE)
+        # (32 / 64 / 128 / 8192 are fused scans since round 6: AUTO stays on the sparse level on this clean input)
+        assert b.native.call_info().mode_used == (_native.RT_MODE_SPARSE if nperseg in (32, 64, 128, 8192) else _native.RT_MODE_DENSE)
         for s in range(n_streams):
             want_all, want_kept = oas[s].process(chunk[s], gu.TS0)
             mine = rec[rec["stream"] == s]

@@ -249,3 +249,37 @@ def test_bench_other_configs_block_is_timed_in_the_same_run(monkeypatch):
         assert o["steps"] == 3
     assert oc[1]["mode"] in ("runfilter", "dense") and oc[0]["mode"] == "sparse", oc
     assert bench.OTHER_CONFIGS[1][1]["streams"] == 32768  # the real block: all of config 4 on one GPU
+
+
+def test_bench_sharded_configs_block_carries_north_stars_curve():
+    """At N > 1 the bare `bench.py --gpus N` times, after the weak-scaled headline, BASELINE configs 4 and 5 as ONE population
+    each sharded over the same ranks (`sharded_configs`; populations scaled down here, two ranks sharing the test box's GPU):
+    every rank's boundary streams match the oracle, the shards add up to the population, and the block at world 1 reports the
+    same records -- a population is the same however it is sharded (the reference: one analyzer process per SDR,
+    radiotracking/__main__.py:118-140)."""
+    small = [
+        ("config4", dict(total=48, sample_rate=2048000, samples=524288, nperseg=256, window="hamming", trains=False, what="scaled down")),
+        ("config5", dict(total=10, sample_rate=3200000, samples=3200000, nperseg=4096, window="hamming", trains=True, what="scaled down")),
+    ]
+    os.environ["RT_BENCH_SHARDED_CONFIGS_JSON"] = json.dumps(small)
+    try:
+        runs = {n: _run_bench(n, ["--streams", "32", "--sharded-configs", "on", "--other-configs", "off", "--other-steps", "3"]) for n in (2, 1)}
+    finally:
+        del os.environ["RT_BENCH_SHARDED_CONFIGS_JSON"]
+    for n, d in runs.items():
+        assert d["n_gpus"] == n and d["scaling"] == "weak" and d["config"]["workload"].startswith("config2") and d["value"] > 0  # headline keys untouched
+        sc = d["sharded_configs"]
+        assert [c["name"] for c in sc] == ["config4", "config5"], sc
+        for c, (_, spec) in zip(sc, small):
+            assert "failed" not in c and "skipped" not in c, c
+            assert c["scaling"] == "strong" and c["n_gpus"] == n and c["value"] > 0 and c["steps"] == 3
+            assert len(c["per_rank_ms"]) == n and all(ms > 0 for ms in c["per_rank_ms"])
+            assert sum(c["streams_per_rank"]) == spec["total"] and len(c["streams_per_rank"]) == n
+            assert c["parity_streams_checked"] == 2 * n and c["parity_streams_mismatched"] == 0, c
+            assert c["fallbacks"] == 0 and c["records_per_step"] > 0
+            assert c["speedup_vs_n1_reference"] is None  # (the reference on file is of the full population)
+    for a, b in zip(runs[1]["sharded_configs"], runs[2]["sharded_configs"]):
+        assert a["records_per_step"] == b["records_per_step"] and a["candidate_cells_per_step"] == b["candidate_cells_per_step"]
+    import bench
+
+    assert [(n, sp["total"]) for n, sp in bench.SHARDED_CONFIGS] == [("config4", 32768), ("config5", 8192)]  # the real block: north_star's populations

@@ -11,3 +11,7 @@ for ln in open(sys.argv[1]):
           "frac_concurrent", r.get("frac_concurrent"), "kernel_ms_concurrent", r.get("kernel_ms_concurrent"), "whole", r["whole_path_frac"],
           "fallbacks", d["config"]["fallbacks"], "records", d["config"]["records_per_step"],
           "parity_bad", d.get("parity", {}).get("streams_mismatched"), "cpu", d.get("cpu_baseline", {}).get("value"))
+    for blk in ("other_configs", "sharded_configs"):
+        for o in d.get(blk) or []:
+            print("   ", blk, o.get("name"), {k: o.get(k) for k in ("value", "ms_per_step", "mode", "kernel", "kernel_ms", "frac", "whole_path_frac", "parity_streams_mismatched",
+                                                                     "per_rank_ms", "speedup_vs_n1_reference", "skipped", "failed") if o.get(k) is not None})
