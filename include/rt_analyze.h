@@ -103,7 +103,9 @@ typedef struct rt_config {
     double max_duration_s;      /* signal_max_duration (analyze.py:114)                  */
     int32_t hot_capacity;       /* sparse path: candidate cells kept per (stream, bin mod 16 bucket) and call
                                    (0 = default: one full bin row times max(1, nperseg / 1024), 1024..8192)      */
-    int32_t record_capacity;    /* records kept per stream and call (0 = default 1024)   */
+    int32_t record_capacity;    /* records per stream and call the handle has room for AT FIRST (0 = default 1024): a stream
+                                   that finds more grows the capacity -- the call is analysed again inside rt_fetch --, as
+                                   the reference appends without limit (analyze.py:449-450).  Only rt_extract truncates. */
     int32_t segs_per_chunk;     /* segments per lane-group chunk (0 = default)           */
     int32_t flags;              /* RT_FLAG_*                                             */
     void *hip_stream;           /* hipStream_t to launch on, or NULL for an own stream   */
@@ -218,13 +220,13 @@ int rt_process_u8_host(rt_handle *h, const void *iq_u8_host, int64_t n_samples, 
  * query: the result stays pending until it is fetched with a buffer.  A fetch
  * with a buffer consumes the call whatever `cap` is (records beyond `cap` are
  * lost; with cfg.lanes > 1 in every lane alike).
- * RT_E_CAPACITY: a stream had more than record_capacity records, the result is
- * truncated (and still delivered).  The record pool of a call is no limit (ABI v5):
- * a call that finds more records than the pool holds grows the pool and is analysed
- * again inside this function -- only rt_extract (whose spectrogram the library does
- * not keep) or a host without memory for the larger pool end in RT_E_CAPACITY for
- * that reason, and then every stream still delivers the first records, in (bin, start)
- * order -- the reference's append order -- that fit (never an empty list).  RT_E_HOT_OVERFLOW (RT_MODE_SPARSE): no
+ * RT_E_CAPACITY: the result is truncated (and still delivered).  Neither the record
+ * pool of a call (ABI v5) nor the per-stream record capacity (round 6) is a limit for
+ * rt_process*: a call that finds more records than either holds grows it and is
+ * analysed again inside this function -- only rt_extract (whose spectrogram the
+ * library does not keep) or a device / host without memory for the larger areas end
+ * in RT_E_CAPACITY, and then every stream still delivers the first records, in (bin,
+ * start) order -- the reference's append order -- that fit (never an empty list).  RT_E_HOT_OVERFLOW (RT_MODE_SPARSE): no
  * result, the call is consumed.
  * If an rt_process fails, nothing stays enqueued for it (with lanes: in no lane),
  * and the look-back state is the one before the call.

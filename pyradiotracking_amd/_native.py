@@ -358,8 +358,8 @@ class NativeAnalyzer:
         self._check(self._lib.rt_process_u8_host(self._handle, a.ctypes.data, a.shape[1] // 2, a.shape[1] // 2))
 
     def fetch(self, allow_truncated: bool = False) -> np.ndarray:
-        """Records of the oldest enqueued call.  A call whose records were truncated (``RT_E_CAPACITY``: a stream
-        had more than ``record_capacity`` records) raises unless ``allow_truncated`` -- then the truncated list is
+        """Records of the oldest enqueued call.  A call whose records were truncated (``RT_E_CAPACITY``: an ``rt_extract``
+        call with more records in a stream than ``record_capacity``, or no memory to grow) raises unless ``allow_truncated`` -- then the truncated list is
         returned and ``last_truncated`` is set; either way it is consumed, so the next fetch belongs to the next
         call.  A call without any result (``RT_E_HOT_OVERFLOW``: sparse mode, candidate lists overflowed) always
         raises: an empty array would read as "no signals"."""

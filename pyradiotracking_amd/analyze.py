@@ -239,8 +239,8 @@ class BatchSignalAnalyzer:
         ``"dense"`` pin one level (the first three refuse an input they cannot hold with ``RT_E_HOT_OVERFLOW``).
 
         ``record_pool`` (``rt_config.record_pool``): records the pinned result pool holds at first (0: up to 4 Mi); a
-        buffer with more signals grows it -- the reference appends without limit (``analyze.py:449-450``), here only
-        ``record_capacity`` per stream bounds a call.
+        buffer with more signals grows it -- the reference appends without limit (``analyze.py:449-450``); so does the
+        per-stream ``record_capacity`` (where a stream's room STARTS, default 1024): nothing bounds a call but memory.
 
         ``subtract_first``: apply SciPy's ``detrend='constant'`` in SciPy's order (segment mean subtracted before
         the window) even for hamming / hann / boxcar windows, where the kernels by default subtract ``mean * FFT(window)``
@@ -431,8 +431,9 @@ class BatchSignalAnalyzer:
 
     def fetch_records(self, allow_truncated: bool = False) -> np.ndarray:
         """Wait for the oldest enqueued call; structured array of ``rt_record`` ordered by stream.  The reference
-        has no limit on signals per buffer; here a stream is cut off at ``record_capacity`` (default 1024) records:
-        that raises unless ``allow_truncated`` (then ``native.last_truncated`` tells)."""
+        has no limit on signals per buffer, and neither has an analysed buffer here (a stream that outgrows
+        ``record_capacity`` grows it; the call is analysed again inside the fetch).  Only ``extract_signals`` on a caller's
+        spectrogram can be cut off: that raises unless ``allow_truncated`` (then ``native.last_truncated`` tells)."""
         return self._native.fetch(allow_truncated)
 
     def process_batch(self, iq, ts_starts: Union[datetime.datetime, Sequence[datetime.datetime]], filtered: bool = True):

@@ -60,6 +60,7 @@ struct CallCtx {
     bool no_last = false;   // the slot's h_no_last flags apply (some stream was reset, rt_reset_stream)
     int n_dense_streams = 0;  // streams of this call that were re-run dense on their own (AUTO, partial fall-back)
     bool pool_grown = false;  // the record pool was enlarged for this call and the call analysed again (fetch_one)
+    int cap_grown = 0;        // times the handle's per-stream record capacity was enlarged for this call (fetch_one: grow_record_capacity)
     bool thr_rerun = false;   // analysed again on RT_MODE_RUNFILTER with thresholds from its own row means (once per call)
     bool abs_counted = false; // a MODE 4 / 6 scan of this call left the slot's h_abs_hot
     bool level_settled = false;  // AUTO's level bookkeeping for this call is done (fetch_one passes over a call twice: size query / peek, then delivery)
@@ -232,7 +233,13 @@ int fail_create(int code, const std::string &msg) {
     return code;
 }
 
-size_t rec_lds_bytes(int rec_cap) { return (size_t)rec_cap * (8 + 8 + sizeof(rt_record)) + 16; }
+size_t rec_lds_bytes(int rec_cap) { return (size_t)std::min(rec_cap, kDenseLdsRecords) * (8 + 8 + sizeof(rt_record)) + 16; }
+
+// The dense extractor over `grid` streams (all of them, or the list in a.stream_list).  While the handle's record capacity fits
+// the kernel's LDS staging it orders, filters and publishes its records itself; beyond that (a capacity that has grown: the
+// reference appends without limit, analyze.py:449-450) the list is staged in the streams' raw-record areas and finalize_records,
+// the sparse path's last kernel, finishes the call.
+void launch_detect_dense(rt_handle *h, int grid, hipStream_t st, const DetectArgs &a);
 
 int next_pow2(int v) {
     int p = 1;
@@ -561,6 +568,15 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     return a;
 }
 
+void launch_detect_dense(rt_handle *h, int grid, hipStream_t st, const DetectArgs &a) {
+    if (h->rec_cap <= kDenseLdsRecords) {
+        hipLaunchKernelGGL(detect_dense<false>, dim3(grid), dim3(kDetBlock), h->lds_dense, st, a);
+    } else {
+        hipLaunchKernelGGL(detect_dense<true>, dim3(grid), dim3(kDetBlock), 0, st, a);
+        hipLaunchKernelGGL(finalize_records, dim3(grid), dim3(256), 0, st, a);
+    }
+}
+
 int ensure_dense_spec(rt_handle *h) {
     if (h->d_spec) return RT_OK;
     const size_t bytes = (size_t)h->cfg.n_streams * (size_t)h->max_seg * (size_t)h->N * sizeof(float);
@@ -575,7 +591,7 @@ int ensure_dense_spec(rt_handle *h) {
 
 // calls without a detect kernel (empty spectrogram): counter words -> pinned host memory by a copy
 int enqueue_readback(rt_handle *h, Slot &sl, hipStream_t st) {
-    RT_HIP(h, hipMemcpyAsync(sl.h_counters, sl.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RT_HIP(h, hipMemcpyAsync(sl.h_counters, sl.d_counters, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     return RT_OK;
 }
 
@@ -619,7 +635,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         a.spec = h->d_spec;
         a.psum = sl.d_psum;  // one partial row per stream (row_sums_dense)
         a.chunks = 1;
-        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
+        launch_detect_dense(h, h->cfg.n_streams, h->s_scan, a);
         RT_HIP(h, hipGetLastError());
         RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
         return RT_OK;
@@ -822,7 +838,7 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
         a.host_seg_total = sl.h_seg_total;
     }
     if (dense) {
-        hipLaunchKernelGGL(detect_dense, dim3(S), dim3(kDetBlock), h->lds_dense, sd, a);
+        launch_detect_dense(h, S, sd, a);
     } else {
         const int waves = S * kBuckets;
         hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
@@ -867,7 +883,7 @@ int enqueue_partial_dense(rt_handle *h, Slot &sl, int n_list, unsigned long long
     a.chunks = sp.blocks_per_stream;
     a.spec = h->d_spec_part;
     a.stream_list = sl.h_list;
-    hipLaunchKernelGGL(detect_dense, dim3(n_list), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
+    launch_detect_dense(h, n_list, h->s_scan, a);
     RT_HIP(h, hipGetLastError());
     RT_HIP(h, hipEventRecord(sl.ev_done, h->s_scan));
     return RT_OK;
@@ -895,6 +911,37 @@ int grow_pool(rt_handle *h, Slot &sl, int64_t want) {
     sl.h_records = p;
     sl.pool_cap = cap;
     h->pool_want = std::max(h->pool_want, cap);
+    return RT_OK;
+}
+
+// A stream of the call wanted more records than the handle's per-stream capacity (word 4 of the counters): the capacity --
+// rt_config.record_capacity is where it STARTS -- grows to hold them, for this call and every later one.  The reference appends
+// signals without limit (analyze.py:449-450); here the limit is the memory: per stream and slot 40 bytes a record of raw-record
+// area, and what the pinned pool may then be asked to hold.  Everything in flight is waited for first (the other slot's kernels
+// write their own raw-record area, which is replaced as well).  Failure leaves the old capacity in place.
+int grow_record_capacity(rt_handle *h, unsigned long long wanted) {
+    if (wanted <= (unsigned long long)h->rec_cap) return RT_OK;
+    if (wanted > (1ull << 24)) wanted = 1ull << 24;  // (a buffer of 2^24 records per stream is beyond any key space the scans have)
+    const int cap = next_pow2((int)wanted);
+    RT_HIP(h, hipStreamSynchronize(h->s_scan));
+    RT_HIP(h, hipStreamSynchronize(h->s_detect));
+    const size_t bytes = (size_t)h->cfg.n_streams * (size_t)cap * sizeof(rt_record);
+    rt_record *fresh[kSlots] = {nullptr, nullptr};
+    for (int i = 0; i < kSlots; ++i) {
+        if (hipMalloc(&fresh[i], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < i; ++j) (void)hipFree(fresh[j]);
+            h->err = "raw-record area for " + std::to_string(cap) + " records per stream (" + std::to_string(bytes) + " bytes per slot) does not fit the device";
+            return RT_E_NOMEM;
+        }
+    }
+    for (int i = 0; i < kSlots; ++i) {
+        (void)hipFree(h->slot[i].d_raw);
+        h->slot[i].d_raw = fresh[i];
+    }
+    h->rec_cap = cap;
+    h->lds_dense = rec_lds_bytes(cap);
+    h->pool_max = ((int64_t)h->cfg.n_streams + std::min(h->cfg.n_streams, kMaxPartial)) * cap;
     return RT_OK;
 }
 
@@ -1255,9 +1302,9 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         h->lds_large = (size_t)next_pow2(std::max(h->hot_cap, 64)) * 8 + tail;
         h->lds_small = 4 * ((size_t)kSmallBucket * 8 + tail);
     }
-    if (h->lds_large + 8 * 1024 > 160 * 1024 || h->lds_dense > 160 * 1024) {
+    if (h->lds_large + 8 * 1024 > 160 * 1024) {
         delete h;
-        return fail_create(RT_E_INVALID, "hot_capacity/record_capacity do not fit the 160 KiB LDS of a CU");
+        return fail_create(RT_E_INVALID, "hot_capacity does not fit the 160 KiB LDS of a CU");
     }
 
     auto fail = [&](int code, const std::string &msg) {
@@ -1552,11 +1599,11 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
         std::memset(sl.h_hot_total, 0, (size_t)S * sizeof(int32_t));
         RT_CREATE_HIP(hipMalloc(&sl.d_raw, (size_t)S * h->rec_cap * sizeof(rt_record)));
         RT_CREATE_HIP(hipMalloc(&sl.d_raw_count, (size_t)S * sizeof(int32_t)));
-        RT_CREATE_HIP(hipMalloc(&sl.d_counters, 4 * sizeof(unsigned long long)));
+        RT_CREATE_HIP(hipMalloc(&sl.d_counters, kCounterWords * sizeof(unsigned long long)));
         RT_CREATE_HIP(hipMemset(sl.d_hot_count, 0, (size_t)S * kBuckets * sizeof(uint32_t)));
         RT_CREATE_HIP(hipMemset(sl.d_raw_count, 0, (size_t)S * sizeof(int32_t)));
-        RT_CREATE_HIP(hipMemset(sl.d_counters, 0, 4 * sizeof(unsigned long long)));
-        RT_CREATE_HIP(hipHostMalloc(&sl.h_counters, 4 * sizeof(unsigned long long)));
+        RT_CREATE_HIP(hipMemset(sl.d_counters, 0, kCounterWords * sizeof(unsigned long long)));
+        RT_CREATE_HIP(hipHostMalloc(&sl.h_counters, kCounterWords * sizeof(unsigned long long)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_offset, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_rec_count, (size_t)S * sizeof(int32_t)));
         RT_CREATE_HIP(hipHostMalloc(&sl.h_records, (size_t)sl.pool_cap * sizeof(rt_record)));
@@ -1588,8 +1635,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
-    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dense));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)rec_lds_bytes(kDenseLdsRecords)));
 #undef RT_CREATE_HIP
     *out = h;
     return RT_OK;
@@ -1756,7 +1803,7 @@ static int process_impl(rt_handle *h, const void *iq_dev, int64_t n_samples, int
             // empty spectrogram: no signals; `_spectrogram_last` becomes an empty map
             const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
             launched = true;  // (the slot's result arrays are rewritten from here on)
-            RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
+            RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, kCounterWords * sizeof(unsigned long long), h->s_scan));
             RT_HIP(h, hipMemsetAsync(sl.h_rec_count, 0, sb, h->s_scan));
             RT_HIP(h, hipMemsetAsync(sl.h_rec_offset, 0, sb, h->s_scan));
             RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
@@ -1873,7 +1920,7 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
     c.is_extract = true;
     c.mode_used = RT_MODE_DENSE;
     const size_t sb = (size_t)h->cfg.n_streams * sizeof(int32_t);
-    RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, 4 * sizeof(unsigned long long), h->s_scan));
+    RT_HIP(h, hipMemsetAsync(sl.d_counters, 0, kCounterWords * sizeof(unsigned long long), h->s_scan));
     RT_HIP(h, hipEventRecord(sl.ev_begin, h->s_scan));
     RT_HIP(h, hipEventRecord(sl.ev_scan, h->s_scan));
     if (n_seg == 0) {
@@ -1886,7 +1933,7 @@ int rt_extract(rt_handle *h, const float *spec_dev, int32_t n_seg, int32_t n_bin
         a.prev_cols = last_dev ? n_seg_last : 0;
         a.spec = spec_dev;
         a.psum = nullptr;  // caller-supplied map: the kernel sums the rows itself
-        hipLaunchKernelGGL(detect_dense, dim3(h->cfg.n_streams), dim3(kDetBlock), h->lds_dense, h->s_scan, a);
+        launch_detect_dense(h, h->cfg.n_streams, h->s_scan, a);
         RT_HIP(h, hipGetLastError());
     }
     if (n_seg == 0) {
@@ -2072,6 +2119,22 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     // look-back state, like a fall-back re-run -- so the caller loses nothing; later calls find the larger pool.  Not
     // possible for rt_extract (the caller's spectrogram is not kept) or when the host has no memory left: then the
     // truncated lists are delivered with RT_E_CAPACITY.
+    // A stream wanted more records than the handle's per-stream capacity holds (word 4): the capacity grows and the call is
+    // analysed again, like a call that outgrew the pool -- the reference has no limit (analyze.py:449-450).  Up to three times per
+    // call (a re-run on a higher level may find more).  rt_extract cannot (the caller's spectrogram is not kept).
+    if ((flags & kFlagRecOverflow) && !c.is_extract && c.n_seg > 0 && sl.h_counters[4] > (unsigned long long)h->rec_cap && c.cap_grown < 3) {
+        if (grow_record_capacity(h, sl.h_counters[4]) == RT_OK) {
+            ++c.cap_grown;
+            for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
+            c.n_dense_streams = 0;
+            int rc = before_rerun(h, sl);
+            if (rc == RT_OK) rc = enqueue_analysis(h, sl, c.mode_used);
+            if (rc != RT_OK) return rc;
+            RT_HIP(h, hipEventSynchronize(sl.ev_done));
+            flags = sl.h_counters[2];
+            continue;
+        }
+    }
     if ((flags & kFlagRecOverflow) && !c.is_extract && c.n_seg > 0 && sl.h_counters[0] > (unsigned long long)sl.pool_cap &&
         sl.pool_cap < h->pool_max && !c.pool_grown) {
         if (grow_pool(h, sl, (int64_t)std::min<unsigned long long>(sl.h_counters[0], (unsigned long long)h->pool_max)) == RT_OK) {

@@ -1912,8 +1912,8 @@ struct DetectArgs {
     int32_t rec_cap;           // per stream
     int32_t *rec_offset;       // [S]
     int32_t *rec_count;        // [S]
-    unsigned long long *counters;  // [0] records allocated, [1] hot total, [2] flags, [3] workgroups done (close_call)
-    unsigned long long *host_counters;  // pinned host copy of the four words, written by the call's last workgroup
+    unsigned long long *counters;  // [0] records allocated, [1] hot total, [2] flags, [3] workgroups done (close_call), [4] the most records any stream wanted
+    unsigned long long *host_counters;  // pinned host copy of the kCounterWords words, written by the call's last workgroup
     // per-stream overrides (null = dp's value for every stream)
     const float *thr_s;        // [S] signal_threshold of the stream's SDR (analyze.py:115)
     const float *cal_s;        // [S] its calibration_db (orders maxima in the shadow filter)
@@ -1939,6 +1939,11 @@ __device__ __forceinline__ DetectParams stream_params(const DetectArgs &a, int s
     return dp;
 }
 
+constexpr int kCounterWords = 5;
+// Records a stream may have on the dense path while its unordered list is staged in LDS (detect_dense<false>: 56 bytes each);
+// a handle whose record capacity has grown beyond it -- the reference appends without limit, analyze.py:449-450 -- stages in
+// global memory instead and leaves ranking and shadow verdicts to finalize_records (detect_dense<true>).
+constexpr int kDenseLdsRecords = 2048;
 constexpr unsigned long long kFlagHotOverflow = 1ull;
 constexpr unsigned long long kFlagRecOverflow = 2ull;
 constexpr unsigned long long kFlagInconsistent = 4ull;
@@ -2005,8 +2010,10 @@ __device__ __forceinline__ void push_candidate(const DetectArgs &a, RecLds &l, i
         r.shadowed = 0;
         r.reserved = cell_off;
         l.rec[idx] = r;
-        l.ts_us[idx] = timedelta_us(start_time(a.dp, start));
-        l.dur_us[idx] = timedelta_us(run_duration(a.dp, start, end));
+        if (l.ts_us) {  // (staged in LDS: publish_records ranks from these; in global memory finalize_records derives them itself)
+            l.ts_us[idx] = timedelta_us(start_time(a.dp, start));
+            l.dur_us[idx] = timedelta_us(run_duration(a.dp, start, end));
+        }
     }
 }
 
@@ -2122,7 +2129,8 @@ __device__ __forceinline__ void close_call(const DetectArgs &a) {
     const unsigned long long ticket = atomicAdd(&a.counters[3], 1ull);
     if (ticket + 1 == (unsigned long long)gridDim.x) {
         __threadfence();
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < kCounterWords; ++i) {
+            if (i == 3) continue;
             a.host_counters[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -2177,7 +2185,10 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
     __syncthreads();
     int n = *l.count;
     if (n > a.rec_cap) {
-        if (threadIdx.x == 0) atomicOr(&a.counters[2], kFlagRecOverflow);
+        if (threadIdx.x == 0) {
+            atomicOr(&a.counters[2], kFlagRecOverflow);
+            atomicMax(&a.counters[4], (unsigned long long)n);  // (the capacity this stream wants: rt_fetch grows the handle's and analyses the call again)
+        }
         n = a.rec_cap;
     }
     return n;
@@ -2688,23 +2699,31 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     __shared__ long long t_ts[kFinalTile], t_dur[kFinalTile];
     __shared__ long long sh_base;
     __shared__ int sh_fit;
-    const int s = blockIdx.x;
+    const int s = a.stream_list ? a.stream_list[blockIdx.x] : (int)blockIdx.x;  // (a list: the dense re-run of a few streams, detect_dense<true>)
     const int tid = threadIdx.x;
     int n = a.raw_count[s];
+    const int wanted = n;
     if (n > a.rec_cap) n = a.rec_cap;  // overflow already flagged by the producer
     if (n < 0) n = 0;
     __syncthreads();
     if (tid == 0) {
-        if (n) a.raw_count[s] = 0;  // ready for the slot's next call
-        // last reader of the stream's candidate counters: their sum for the statistics, then zero for the slot's next call
-        uint32_t tot = 0;
-        for (int b = 0; b < kBuckets; ++b) {
-            const uint32_t c = a.hot_count[s * kBuckets + b];
-            tot += c;
-            if (c) a.hot_count_rw[s * kBuckets + b] = 0u;
+        if (wanted) a.raw_count[s] = 0;  // ready for the slot's next call
+        if (wanted > a.rec_cap) {
+            // the stream found more records than the handle's capacity holds: rt_fetch grows it and analyses the call again
+            atomicOr(&a.counters[2], kFlagRecOverflow);
+            atomicMax(&a.counters[4], (unsigned long long)wanted);
         }
-        a.hot_total[s] = (int32_t)tot;
-        a.large_any[s] = 0u;
+        if (!a.stream_list) {
+            // last reader of the stream's candidate counters: their sum for the statistics, then zero for the slot's next call
+            uint32_t tot = 0;
+            for (int b = 0; b < kBuckets; ++b) {
+                const uint32_t c = a.hot_count[s * kBuckets + b];
+                tot += c;
+                if (c) a.hot_count_rw[s * kBuckets + b] = 0u;
+            }
+            a.hot_total[s] = (int32_t)tot;
+            a.large_any[s] = 0u;
+        }
         const unsigned long long v = atomicAdd(&a.counters[0], (unsigned long long)n | (1ull << kTicketShift));
         const unsigned long long mask = (1ull << kTicketShift) - 1ull;
         const long long base = (long long)(v & mask);
@@ -2725,8 +2744,9 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
             a.host_counters[1] = __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.host_counters[2] = flags;
             a.host_counters[3] = (unsigned long long)gridDim.x;
+            a.host_counters[4] = __hip_atomic_load(&a.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.seg_total) *a.host_seg_total = __hip_atomic_load(a.seg_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int i = 0; i < 4; ++i) __hip_atomic_store(&a.counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < kCounterWords; ++i) __hip_atomic_store(&a.counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -2864,6 +2884,10 @@ __device__ __forceinline__ bool scan_dense_row_blocked(const DetectParams &p, co
 // One workgroup per stream.  Phase 1: one thread per bin (strided) scans its
 // row sequentially in time -- the reference's row scan (analyze.py:357-450) in
 // run-based form.  Phase 2/3 as in detect_sparse.
+// GLOBAL (a handle whose record capacity has grown beyond kDenseLdsRecords): the unordered list lives in the stream's raw-record
+// area in global memory, like the sparse path's, and finalize_records -- launched behind this kernel -- orders it, applies the
+// shadow verdicts and closes the call.
+template <bool GLOBAL>
 __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s_pos = blockIdx.x;
@@ -2872,8 +2896,16 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
     const int F = a.n_bins;
     const int T = a.dp.n_seg;
     unsigned char *ptr = smem;
-    RecLds l = carve_rec_lds(ptr, a.rec_cap);
-    if (tid == 0) *l.count = 0;
+    RecLds l;
+    if constexpr (GLOBAL) {
+        l.rec = a.raw + (int64_t)s * a.rec_cap;
+        l.ts_us = nullptr;
+        l.dur_us = nullptr;
+        l.count = a.raw_count + s;  // (zero between calls: finalize_records leaves it so)
+    } else {
+        l = carve_rec_lds(ptr, a.rec_cap);
+        if (tid == 0) *l.count = 0;
+    }
     __syncthreads();
 
     const DetectParams dp = stream_params(a, s);
@@ -2900,7 +2932,15 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
         };
         scan_dense_row_blocked(dp, row, F, row_sum, t_begin, t_end, &av, on_run);
     }
-    const int nrec = settled_count(a, l);
+    int nrec;
+    if constexpr (GLOBAL) {
+        __threadfence();
+        __syncthreads();
+        nrec = __hip_atomic_load(l.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (finalize_records clamps, flags and reports what was wanted)
+        if (nrec > a.rec_cap) nrec = a.rec_cap;
+    } else {
+        nrec = settled_count(a, l);
+    }
 
     for (int c = tid >> 6; c < nrec; c += kDetBlock / 64) {
         rt_record &r = l.rec[c];
@@ -2918,9 +2958,11 @@ __global__ __launch_bounds__(kDetBlock) void detect_dense(const DetectArgs a) {
             r.std_db = st.std_db;
         }
     }
-    __syncthreads();
-    publish_records(a, l, s, nrec);
-    if (tid == 0) close_call(a);
+    if constexpr (!GLOBAL) {
+        __syncthreads();
+        publish_records(a, l, s, nrec);
+        if (tid == 0) close_call(a);
+    }
 }
 
 }  // namespace rt

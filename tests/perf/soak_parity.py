@@ -56,7 +56,9 @@ while time.time() < t_end:
             hop = nperseg / fs
             min_ms = float(rng_g.choice([0.0, 2 * hop * 1e3, 8.0, 5.0]))
             max_ms = float(max(min_ms + 3 * hop * 1e3, rng_g.choice([10.0, 40.0, 80.0])))
-            mode = "auto" if mode != "dense" else "dense"
+            # (round 6: 32 / 64 / 128 / 8192 / 16384 are fused scans -- every mode they have; the other sizes live on the dense path)
+            if nperseg not in (32, 64, 128, 8192, 16384):
+                mode = "auto" if mode != "dense" else "dense"
             if nperseg >= 4099:
                 n_streams = min(n_streams, 6)
                 if isinstance(cal, list):
@@ -121,11 +123,20 @@ while time.time() < t_end:
                          else [np.nan, np.inf, complex(0, -np.inf), 1e30, complex(np.nan, 1.0), 3e38], dtype=np.complex64))
     kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window=window, signal_min_duration_ms=min_ms, signal_max_duration_ms=max_ms,
               signal_threshold_dbw=thr, snr_threshold_db=snr)
-    try:
-        b = BatchSignalAnalyzer([str(i) for i in range(n_streams)], sdr_callback_length=blen, mode=mode, lanes=lanes, calibration_db=cal,
-                                record_capacity=2048, segs_per_chunk=chunking, subtract_first=subtract_first, **kw)
-    except Exception as e:  # configuration refused: report, go on
-        print(f"case {case}: create failed: {e}")
+    # (round 6: the per-stream record capacity STARTS small -- a stream that needs more grows it inside rt_fetch, so no buffer is
+    # skipped for its record count any more; a mode the geometry does not have -- the chunk-bit pre-filter with a short minimum
+    # duration, the exact one beyond its planner's counters or at nperseg 32 / 8192 / 16384 -- falls back to AUTO instead of
+    # wasting the case)
+    b = None
+    for m_try in (mode, "auto"):
+        try:
+            b = BatchSignalAnalyzer([str(i) for i in range(n_streams)], sdr_callback_length=blen, mode=m_try, lanes=lanes, calibration_db=cal,
+                                    record_capacity=64, segs_per_chunk=chunking, subtract_first=subtract_first, **kw)
+            mode = m_try
+            break
+        except Exception as e:
+            print(f"case {case}: create failed in mode {m_try}: {e}")
+    if b is None:
         continue
     cals = cal if isinstance(cal, list) else [cal] * n_streams
     oas = [oracle.OracleAnalyzer(device=str(s), calibration_db=cals[s], **kw) for s in range(n_streams)]
@@ -187,7 +198,7 @@ while time.time() < t_end:
             continue
         k += 1
         chunk = res[2]
-        if res[0] == "skipped":  # e.g. more records than record_capacity: not a parity question
+        if res[0] == "skipped":  # (a sparse-mode handle whose candidate lists overflowed: no result by contract)
             print(f"case {case}: buffer {k} skipped: {res[1]}")
             try:
                 for s in range(n_streams):

@@ -1098,11 +1098,12 @@ def test_pinned_deviation_std_nan_over_a_cell_that_is_zero_in_exact_arithmetic()
 # ---------------------------------------------------------------------------
 # capacity handling and degenerate inputs
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["sparse", "dense"])
-def test_a_truncated_call_is_consumed(mode):
-    """More records in a stream than record_capacity: the fetch raises RT_E_CAPACITY (or hands out the truncated
-    list on request) and the call is gone -- the next fetch belongs to the next enqueue (found by the randomised
-    soak: the Python layer left the truncated call pending, every later fetch was one call behind)."""
+@pytest.mark.parametrize("mode,lanes", [("sparse", 1), ("dense", 1), ("sparse", 2), ("auto", 1)])
+def test_record_capacity_grows_with_the_stream_that_needs_it(mode, lanes):
+    """The reference appends signals without limit (analyze.py:449-450).  `record_capacity` is where a handle's per-stream
+    capacity STARTS: a stream that finds more records grows it (the call is analysed again inside rt_fetch) and nothing is
+    truncated -- byte-identical to a handle that was large from the start, the calls before and after untouched, with lanes,
+    on every path (round 5 returned a truncated list with RT_E_CAPACITY)."""
     _need_gpu()
     fs, nperseg, blen = 2048000, 256, 900 * 256
     w = oracle.window_coefficients("hamming", nperseg)
@@ -1111,22 +1112,95 @@ def test_a_truncated_call_is_consumed(mode):
     many = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 12, dur_ms=(9, 12), keep_clear_tail=1024)), 60 + s) for s in range(3)])
     few = np.stack([synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 1, dur_ms=(9, 12), keep_clear_tail=1024)), 70 + s) for s in range(3)])
     ref = _batch_for(kw, 3, blen, mode)
-    ref.enqueue(many); n_many = len(ref.fetch_records())
-    ref.enqueue(few); want_few = ref.fetch_records()
+    want = []
+    for x in (few, many, few, many):
+        ref.enqueue(x)
+        want.append(ref.fetch_records())
     cap = 8
-    assert n_many > 3 * cap and 0 < len(want_few) and max(np.bincount(want_few["stream"], minlength=3)) <= cap
-    b = _batch_for(kw, 3, blen, mode, record_capacity=cap)
+    assert len(want[1]) > 3 * cap and 0 < len(want[0]) and max(np.bincount(want[0]["stream"], minlength=3)) <= cap
+    b = _batch_for(kw, 3, blen, mode, record_capacity=cap, lanes=lanes)
+    b.enqueue(few)
+    assert b.fetch_records().tobytes() == want[0].tobytes()
+    b.enqueue(many)   # outgrows the capacity: grown inside the fetch
+    b.enqueue(few)    # ... with the next call already in flight
+    assert b.fetch_records().tobytes() == want[1].tobytes()
+    assert b.fetch_records().tobytes() == want[2].tobytes()
     b.enqueue(many)
+    assert b.fetch_records().tobytes() == want[3].tobytes()
+    assert not b.native.last_truncated
+
+
+def test_thousands_of_plateaus_in_one_stream_equal_the_oracle():
+    """More than 5 000 plateaus in ONE stream-buffer (nine tags keyed on and off every twelve hops for a second, a quiet SDR
+    beside it): the handle's capacity of 1 024 records per stream grows to hold them, finalize_records ranks and shadows them
+    in tiles, and every record equals the oracle's -- indices, verdicts, dB figures."""
+    _need_gpu()
+    fs, nperseg, n_seg = 2048000, 256, 8000
+    blen = n_seg * nperseg
+    w = oracle.window_coefficients("boxcar", nperseg)
+    pulses = []
+    for j in range(9):
+        amp = synth.amp_for_peak_dbw(-60.0 - 2.0 * j, w, fs)
+        f = (17 + 17 * j) * fs / nperseg  # bin-centred under a boxcar window, keyed on segment boundaries: no leakage into other bins
+        # (bins 17, 34 .. 153: one per candidate bucket -- bin mod 16 --, 5 300 cells each: inside the sparse lists' 8 192)
+        pulses += [synth.Pulse(t0 * nperseg, 7 * nperseg, f, amp) for t0 in range(3, n_seg - 12, 12)]
+    heavy = synth.make_stream(synth.StreamSpec(blen, fs, pulses), seed=5)
+    rng = np.random.default_rng(2)
+    light = synth.make_stream(synth.StreamSpec(blen, fs, synth.random_pulses(rng, blen, fs, w, 3, dur_ms=(2, 5))), seed=6)
+    iq = np.stack([heavy, light])
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, fft_window="boxcar", signal_min_duration_ms=0.5, snr_threshold_db=-20.0)
+    oas = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(2)]
+    want = [oas[s].process(iq[s], gu.TS0) for s in range(2)]
+    assert len(want[0][0]) > 5000 and 0 < len(want[1][0]) < 50
+    for mode in ("sparse", "dense"):
+        b = _batch_for(kw, 2, blen, mode)
+        b.enqueue(iq)
+        rec = b.fetch_records()
+        assert not b.native.last_truncated
+        for s in range(2):
+            want_all, want_kept = want[s]
+            mine = rec[rec["stream"] == s]
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(x.fi, x.start, x.end) for x in want_all], (mode, s, len(mine), len(want_all))
+            kept_ids = {id(x) for x in want_kept}
+            assert [bool(r["shadowed"]) for r in mine] == [id(x) not in kept_ids for x in want_all]
+            _, _, _, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = b._decoder.decode(mine)
+            for name, got in (("max", max_dbw), ("avg", avg_dbw), ("std", std_db), ("noise", noise_dbw), ("snr", snr_db)):
+                ref = np.array([getattr(x, name) for x in want_all])
+                assert np.all(np.abs(got - ref) < POWER_TOL_DB), (mode, s, name, float(np.abs(got - ref).max()))
+        # the next, ordinary call on the grown handle
+        b.enqueue(np.stack([light, light]))
+        rec2 = b.fetch_records()
+        assert len(rec2) == 2 * len(rec2[rec2["stream"] == 0]) > 0
+
+
+def test_a_truncated_extract_call_is_consumed():
+    """rt_extract analyses a caller-owned spectrogram the library does not keep: it cannot analyse the call again with a larger
+    capacity, so a stream with more records than record_capacity gets RT_E_CAPACITY (or the truncated list on request) and the
+    call is gone -- the next fetch belongs to the next call (found by the randomised soak: the Python layer once left the
+    truncated call pending, every later fetch was one call behind)."""
+    _need_gpu()
+    import torch
+
+    fs, nperseg, F, T = 2048000, 256, 256, 400
+    small = SignalAnalyzer("0", sample_rate=fs, fft_nperseg=nperseg, sdr_callback_length=4096, signal_min_duration_ms=1.0, record_capacity=8)
+    rng = np.random.default_rng(3)
+    cur = (rng.exponential(1.0, (F, T)) * 1e-12).astype(np.float32)
+    for j in range(40):
+        cur[5 * j + 3, 20 + 7 * j: 20 + 7 * j + 12] = 1e-7 * (1 + j)
+    quiet = (rng.exponential(1.0, (F, T)) * 1e-12).astype(np.float32)
+    quiet[17, 30:45] = 1e-7
+    freqs = np.fft.fftfreq(F, 1 / fs)
+    times = (nperseg / 2 + np.arange(T) * nperseg) / float(fs)
     with pytest.raises(_native.NativeError) as e:
-        b.fetch_records()
+        small.extract_signals(freqs, times, cur, gu.TS0)
     assert e.value.code == _native.RT_E_CAPACITY
-    b.enqueue(few)
-    assert b.fetch_records().tobytes() == want_few.tobytes()
-    b.enqueue(many)
-    part = b.native.fetch(allow_truncated=True)
-    assert 0 < len(part) <= 3 * cap
-    b.enqueue(few)
-    assert b.fetch_records().tobytes() == want_few.tobytes()
+    assert len(small.extract_signals(freqs, times, quiet, gu.TS0)) == 1  # the truncated call is gone
+    nat = small._batch.native
+    d = torch.from_numpy(np.ascontiguousarray(cur.T)).cuda()
+    nat.extract_device(d.data_ptr(), T, F, None, 0)
+    part = nat.fetch(allow_truncated=True)
+    assert nat.last_truncated and 0 < len(part) <= 8
+    assert len(small.extract_signals(freqs, times, quiet, gu.TS0)) == 1
 
 
 @pytest.mark.parametrize("mode,lanes", [("sparse", 1), ("dense", 1), ("sparse", 2)])
