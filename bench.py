@@ -198,6 +198,40 @@ def resolve_workload(args, world):
 SCAN_KERNEL_SYMBOL = "_ZN2rt9stft_scanILi1ELi0ELb0ELb1ELi0EEEvNS_10StftParamsE"  # rt::stft_scan<1, 0, false, true, 0>: the default workload's scan
 
 
+SCAN_KERNEL_SYMBOL_U8 = "_ZN2rt9stft_scanILi1ELi0ELb1ELb0ELi0EEEvNS_10StftParamsE"  # rt::stft_scan<1, 0, true, false, 0>: the sparse scan of uint8 input at nperseg 256
+PMC_VALU_FILE = os.path.join(REPO, "profiles", "pmc_valu_u8.json")  # written by tools/r6/u8_valu.sh
+# The roofline of the uint8 path: vector-instruction issue.  A wave64 v_fma_f32 takes a SIMD 2 cycles (MI355X_MICROARCH.md, "Per-instruction
+# cycle constants"); 256 CUs x 4 SIMDs at the 2.4 GHz engine clock issue at most 1 024 x 2.4e9 / 2 wave-level vector instructions a second.
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0  # 1 228.8 G wave-instructions/s
+
+
+def valu_roofline(block, kernel_ms):
+    """`roofline`-style object for a uint8 line: the scan kernels' wave-level vector instructions per step (SQ_INSTS_VALU of the
+    committed PMC pass over the same geometry, tools/r6/u8_valu.sh) / the step's scan time, against the chip's issue peak --
+    quoted only while the uint8 scan kernel's machine code is the one that was counted."""
+    try:
+        with open(PMC_VALU_FILE) as f:
+            doc = json.load(f).get(block)
+    except (OSError, ValueError):
+        doc = None
+    if not doc or not doc.get("insts_valu_per_step"):
+        return {"bound": "valu", "frac": None, "note": "profiles/pmc_valu_u8.json has no entry for this block (run tools/r6/u8_valu.sh)"}
+    if doc.get("scan_kernel_sha256") != scan_kernel_sha256(symbol=SCAN_KERNEL_SYMBOL_U8):
+        return {"bound": "valu", "frac": None, "note": "the uint8 scan kernel's machine code differs from the one profiles/pmc_valu_u8.json was counted on (run tools/r6/u8_valu.sh)"}
+    insts = float(doc["insts_valu_per_step"])
+    achieved = insts / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else 0.0
+    c = doc.get("counters_per_step", {})
+    out = {"bound": "valu", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": round(achieved / VALU_PEAK_GINST, 4),
+           "insts_valu_per_step": int(insts), "insts_valu_per_sample": round(insts * 64 / doc["workload"]["samples_per_step"], 2),
+           "peak_note": "1 024 SIMDs x 2.4 GHz / 2 cycles per wave64 vector instruction (MI355X_MICROARCH.md)",
+           "source": "SQ_INSTS_VALU per step, " + doc.get("source", "profiles/pmc_valu_u8.json")}
+    if c.get("SQ_WAVE_CYCLES"):
+        # where a wave's time goes in the counted pass (quad-cycles over all waves): issuing, waiting on s_waitcnt / barriers, stalled at issue
+        out["wave_time_shares"] = {k: round(c[n] / c["SQ_WAVE_CYCLES"], 3) for k, n in (("active_inst_any", "SQ_ACTIVE_INST_ANY"), ("active_inst_valu", "SQ_ACTIVE_INST_VALU"),
+                                                                                         ("wait_any", "SQ_WAIT_ANY"), ("wait_inst_any", "SQ_WAIT_INST_ANY")) if c.get(n) is not None}
+    return out
+
+
 def scan_kernel_sha256(lib_path=None, symbol=SCAN_KERNEL_SYMBOL):
     """sha256 of the MACHINE CODE of the default workload's scan kernel inside the built library (the gfx950 code object of
     the offload bundle, the symbol's bytes in .text).  It ties profiles/pmc_traffic.json to the kernel that was measured:
@@ -652,6 +686,9 @@ def main():
         "whole_path_frac": round(value * 1e6 / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
     }
 
+    if u8:
+        # (2 bytes per sample: HBM does not bound this step -- the fraction of the roofline that does, where it has been counted)
+        roofline["valu_roofline"] = valu_roofline("config2_uint8" if (wl["name"], S) == ("config2", 256) else "", kernel_ms)
     part = (f"{total_streams} streams sharded over {world} GPU(s) ({S} on rank 0)" if wl["scaling"] == "strong"
             else f"{S} streams/GPU")
     out = {
@@ -753,10 +790,66 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
 
     out["signal_objects_per_s"] = rate(lambda: decoder.signals(kept, device_names, ts0), len(kept))
     out["signal_batch_records_per_s"] = rate(lambda: decoder.signal_batch(kept, device_names, ts0), len(kept))
-    out["csv_rows_per_s"] = rate(lambda: consume.format_signals("csv", consume.rows_from_analysis(rec, decoder, ts0_us), device_names), len(kept))
+    # The native sinks work on arrays and, since round 6, on several cores (rt_host_set_threads; byte-identical output for any number).
+    # A step's records are few thousand: the sample is repeated to a batch a station fleet would hand over (>= 262 144 records).
+    # (the rank is pinned to its NUMA share: the sinks get the cores the job had, like the CPU baseline's workers)
+    pinned_to = None
+    try:
+        if _ORIG_AFFINITY:
+            pinned_to = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, _ORIG_AFFINITY)
+    except (AttributeError, OSError):
+        pinned_to = None
+    try:
+        reps = max(1, -(-262144 // max(1, n)))
+        big = np.concatenate([rec] * reps) if reps > 1 else rec
+        n_big = int((big["shadowed"] == 0).sum())
+        out["sink_batch_records"] = n_big
+        consume.set_host_threads(1)
+        out["csv_rows_per_s_one_thread"] = rate(lambda: consume.format_signals("csv", consume.rows_from_analysis(big, decoder, ts0_us), device_names), n_big)
+        out["threads"] = consume.set_host_threads(0)
+        out["csv_rows_per_s"] = rate(lambda: consume.format_signals("csv", consume.rows_from_analysis(big, decoder, ts0_us), device_names), n_big)
+        out["json_documents_per_s"] = rate(lambda: consume.format_signals("json", consume.rows_from_analysis(big, decoder, ts0_us), device_names), n_big)
+        # the matcher: stations of four consecutive streams (the reference: four antennas per station, one SignalMatcher per station
+        # process, match.py:21-50), every station's signals in time order, all stations in one native call
+        from pyradiotracking_amd import match as rtm
+
+        nd = 4
+        n_st = -(-len(device_names) // nd)
+        rows = consume.rows_from_analysis(big, decoder, ts0_us)
+        st = rows["device"] // nd
+        order = np.lexsort((rows["ts_us"], st))
+        msig = np.zeros(len(order), dtype=rtm.SIGNAL_DTYPE)
+        msig["device"], msig["ts_us"], msig["duration_us"] = rows["device"][order] % nd, rows["ts_us"][order], rows["duration_us"][order]
+        msig["frequency"], msig["avg"] = rows["frequency"][order], rows["avg_dbw"][order]
+        offs = np.searchsorted(st[order], np.arange(n_st + 1))
+
+        def fleet_rate(threads):
+            consume.set_host_threads(threads)
+            best = 0.0
+            for _ in range(3):
+                fl = rtm.MatcherFleet(n_st, nd, timeout_s=2.0, time_diff_s=0.0, bandwidth_hz=4000.0)
+                t0 = time.perf_counter()
+                fl.add(msig, offs)
+                best = max(best, len(msig) / (time.perf_counter() - t0))
+                fl.close()
+            return round(best, 1)
+
+        out["matched_signals_per_s_one_thread"] = fleet_rate(1)
+        out["matched_signals_per_s"] = fleet_rate(0)
+        out["matcher_stations"] = n_st
+    finally:
+        consume.set_host_threads(0)
+        if pinned_to:
+            try:
+                os.sched_setaffinity(0, pinned_to)
+            except OSError:
+                pass
     out["note"] = ("signal_objects_per_s: Signal objects built from the records that pass the shadow filter (the reference's signal_queue.put payload); "
-                   "signal_batch_records_per_s: the same nine fields per record as a lazy sequence (SignalBatch: columns at once, a Signal object when an element is asked for); "
-                   "csv_rows_per_s: the same records to `;`-separated CSV rows through rows_from_analysis + rt_format_signals")
+                   "signal_batch_records_per_s: the same nine fields per record as a lazy sequence (SignalBatch: columns at once, a Signal object when an element is "
+                   "asked for -- what BatchSignalAnalyzer.process_batch returns by default); csv_rows_per_s / json_documents_per_s: records to `;`-separated CSV rows / "
+                   "JSON documents through rows_from_analysis (rt_signal_rows_from_records) + rt_format_signals on `threads` host threads; matched_signals_per_s: "
+                   "the same signals through one SignalMatcher per station of four streams, all stations in one rt_match_add_many call")
     return out
 
 
@@ -1023,6 +1116,8 @@ def measure_other(torch, name, spec, local_rank, steps, seed=1000, parity_stream
         "parity_worst_db_difference": parity["worst_db_difference"],
         "generate_s": round(t_gen, 1),
         "wall_s": round(time.perf_counter() - t_begin, 1),
+        # uint8 input: HBM (2 B per sample) does not bound the step, vector-instruction issue does -- the fraction of THAT roofline
+        **({"valu_roofline": valu_roofline(name, kernel_ms)} if u8 else {}),
     }
 
 

@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5
+/* 6 (round 6): fft_nperseg 32 / 64 / 128 / 8192 / 16384 run fused scans (every mode they have); record_capacity is where a stream's
+ * room starts, not a limit (rt_fetch); rt_format.h: rt_signal_rows_from_records, rt_host_set_threads; rt_match.h:
+ * rt_match_add_many, rt_match_pending_count_many.  Nothing of version 5 was removed or changed in layout. */
+#define RT_ABI_VERSION 6
 
 typedef enum rt_status {
     RT_OK = 0,

@@ -36,6 +36,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "rt_analyze.h" /* rt_record */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -76,6 +78,25 @@ int rt_format_matched(int32_t kind, const rt_matched_row *rows, const double *av
 
 /* repr(float) of one value into buf (>= 32 bytes); returns the length.  Exposed for tests. */
 int rt_format_float_repr(double x, char *buf);
+
+/*
+ * Signal rows of the records of one analysis call, for whole arrays (the conversion the reference does per signal at
+ * analyze.py:420-449, __init__.py:110-170): start time and duration from the cell coordinates through the reference's float64
+ * expressions and datetime.timedelta's rounding, on `rt_host_set_threads` threads.  `rec`: n records (the caller drops shadowed
+ * ones first: the reference never hands them to a consumer, analyze.py:248-251); `ts_start_us[stream]`: the buffer's start
+ * (microseconds since the epoch, UTC); `frequency` and the five float32 dB columns: per record, evaluated by the caller with the
+ * reference's own NumPy expressions (their last digit is printed by the CSV / JSON consumers).
+ */
+int rt_signal_rows_from_records(const rt_record *rec, size_t n, int32_t nperseg, double sample_rate, const int64_t *ts_start_us,
+                                int32_t n_streams, const double *frequency, const float *max_dbw, const float *avg_dbw, const float *std_db,
+                                const float *noise_dbw, const float *snr_db, rt_signal_row *out);
+
+/*
+ * Threads the host-side sinks (rt_format_*, rt_signal_rows_from_records, rt_match_add_many) use per call: n > 0 exactly n, 0 =
+ * automatic (the machine's hardware threads, at most 32).  Process-wide; returns the number in force.  The output of every sink is
+ * byte for byte the same for any number of threads (blocks of rows / whole matchers per thread, assembled in order).
+ */
+int rt_host_set_threads(int32_t n);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,23 @@ int rt_match_pending_count(rt_matcher *m, size_t *n_out);
 int rt_match_add(rt_matcher *m, const rt_match_signal *sigs, size_t n, rt_matched *out, double *out_avgs,
                  uint8_t *out_present, size_t cap, size_t *n_out);
 
+/*
+ * rt_match_add for MANY matchers in one call -- one matcher per station (the reference runs one SignalMatcher per station
+ * process, match.py:21-50; its rule is sequential inside a station and independent between stations) --, the matchers dealt to
+ * `rt_host_set_threads` threads (include/rt_format.h).  Matcher k takes the signals sigs[sig_offsets[k] .. sig_offsets[k + 1]) in
+ * order and writes its timed-out groups from out[out_offsets[k]] on (out_avgs / out_present: rows of ITS n_devices columns from
+ * element out_offsets[k] * n_devices_max on, n_devices_max = the largest n_devices of the set); out_offsets[k + 1] - out_offsets[k]
+ * must be at least that matcher's pending groups + signals.  n_out[k] receives its number of groups.  The result is what n_matchers
+ * calls of rt_match_add produce.  Returns the first error (and leaves the matchers after the failing one's thread block untouched
+ * only on RT_E_INVALID / RT_E_CAPACITY, which are checked for every matcher before any is changed).
+ */
+/* rt_match_pending_count of every matcher of a set in one call (sizes the output of rt_match_add_many). */
+int rt_match_pending_count_many(rt_matcher *const *ms, size_t n_matchers, size_t *n_out);
+
+int rt_match_add_many(rt_matcher *const *ms, size_t n_matchers, const rt_match_signal *sigs, const size_t *sig_offsets,
+                      rt_matched *out, double *out_avgs, uint8_t *out_present, const size_t *out_offsets, int32_t n_devices_max,
+                      size_t *n_out);
+
 /* Copy of the open groups in list order (`_matched`), nothing is consumed. */
 int rt_match_pending(rt_matcher *m, rt_matched *out, double *out_avgs, uint8_t *out_present, size_t cap,
                      size_t *n_out);

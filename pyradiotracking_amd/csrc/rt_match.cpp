@@ -16,6 +16,7 @@
 #include "../../include/rt_analyze.h"
 #include "../../include/rt_match.h"
 #include "rt_core.h"
+#include "rt_hostpar.h"
 
 namespace {
 
@@ -222,6 +223,54 @@ int rt_match_add(rt_matcher *m, const rt_match_signal *sigs, size_t n, rt_matche
         }
     }
     *n_out = k;
+    return RT_OK;
+}
+
+int rt_match_pending_count_many(rt_matcher *const *ms, size_t n_matchers, size_t *n_out) {
+    if ((!ms || !n_out) && n_matchers) return RT_E_INVALID;
+    for (size_t k = 0; k < n_matchers; ++k) {
+        if (!ms[k]) return RT_E_INVALID;
+        n_out[k] = ms[k]->groups.size();
+    }
+    return RT_OK;
+}
+
+int rt_match_add_many(rt_matcher *const *ms, size_t n_matchers, const rt_match_signal *sigs, const size_t *sig_offsets,
+                      rt_matched *out, double *out_avgs, uint8_t *out_present, const size_t *out_offsets, int32_t n_devices_max,
+                      size_t *n_out) {
+    if ((!ms || !sig_offsets || !out_offsets || !n_out) && n_matchers) return RT_E_INVALID;
+    // everything that can be refused is checked for every matcher before any of them changes
+    for (size_t k = 0; k < n_matchers; ++k) {
+        rt_matcher *m = ms[k];
+        if (!m || sig_offsets[k + 1] < sig_offsets[k] || out_offsets[k + 1] < out_offsets[k] || m->cfg.n_devices > n_devices_max) return RT_E_INVALID;
+        const size_t n = sig_offsets[k + 1] - sig_offsets[k];
+        if ((!sigs && n) || ((out_avgs || out_present) && n_devices_max < 0)) return RT_E_INVALID;
+        if (out_offsets[k + 1] - out_offsets[k] < m->groups.size() + n) {
+            m->err = "rt_match_add_many: output capacity below pending groups + signals";
+            return RT_E_CAPACITY;
+        }
+    }
+    // a block = kPerBlock consecutive matchers (a station's share of a call is a few signals: one task per matcher would be all overhead)
+    constexpr size_t kPerBlock = 16;
+    const size_t n_blocks = (n_matchers + kPerBlock - 1) / kPerBlock;
+    std::vector<int> rcs(n_blocks, RT_OK);
+    rt::parallel_blocks(n_blocks, [&](size_t b) {
+        const size_t lo = b * kPerBlock, hi = std::min(n_matchers, lo + kPerBlock);
+        for (size_t k = lo; k < hi; ++k) {
+            const size_t o = out_offsets[k];
+            int rc;
+            try {
+                rc = rt_match_add(ms[k], sigs ? sigs + sig_offsets[k] : nullptr, sig_offsets[k + 1] - sig_offsets[k], out ? out + o : nullptr,
+                                  out_avgs ? out_avgs + o * (size_t)n_devices_max : nullptr, out_present ? out_present + o * (size_t)n_devices_max : nullptr,
+                                  out_offsets[k + 1] - o, &n_out[k]);
+            } catch (...) {
+                rc = RT_E_NOMEM;
+            }
+            if (rc != RT_OK && rcs[b] == RT_OK) rcs[b] = rc;
+        }
+    });
+    for (int rc : rcs)
+        if (rc != RT_OK) return rc;
     return RT_OK;
 }
 

@@ -28,6 +28,8 @@ MATCH_SYMBOLS = (
     "rt_match_destroy",
     "rt_match_reset",
     "rt_match_pending_count",
+    "rt_match_pending_count_many",
+    "rt_match_add_many",
     "rt_match_add",
     "rt_match_pending",
     "rt_match_has_member",
@@ -70,6 +72,8 @@ def _lib():
     lib.rt_match_pending_count.argtypes = [vp, C.POINTER(sz)]
     lib.rt_match_add.argtypes = [vp, vp, sz, vp, vp, vp, sz, C.POINTER(sz)]
     lib.rt_match_pending.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
+    lib.rt_match_add_many.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
+    lib.rt_match_pending_count_many.argtypes = [vp, sz, vp]
     lib.rt_match_has_member.argtypes = [vp, sz, vp]
     lib.rt_match_last_error.argtypes = [vp]
     lib.rt_match_last_error.restype = C.c_char_p
@@ -180,6 +184,63 @@ class NativeMatcher:
 
     def reset(self):
         self._check(self._lib.rt_match_reset(self._h))
+
+
+class MatcherFleet:
+    """Many stations' matchers driven together: one ``rt_matcher`` per station (the reference runs one ``SignalMatcher`` per
+    station process, match.py:21-50), one native call per batch of records (``rt_match_add_many``) with the stations dealt to the
+    library's host threads (``consume.set_host_threads``).  The matching rule is sequential inside a station and independent
+    between stations, so the result is exactly what one ``NativeMatcher.add`` per station gives."""
+
+    def __init__(self, n_stations: int, devices_per_station: int, timeout_s: float, time_diff_s: float, bandwidth_hz: float,
+                 duration_diff_ms: Optional[float] = None):
+        self._lib = _lib()
+        self.n_devices = int(devices_per_station)
+        self.matchers = [NativeMatcher(self.n_devices, timeout_s, time_diff_s, bandwidth_hz, duration_diff_ms) for _ in range(int(n_stations))]
+        self._handles = (C.c_void_p * max(1, len(self.matchers)))(*[m._h for m in self.matchers])
+
+    def __len__(self) -> int:
+        return len(self.matchers)
+
+    def close(self):
+        for m in self.matchers:
+            m.close()
+        self.matchers = []
+
+    def add(self, sigs: np.ndarray, station_offsets: np.ndarray):
+        """``sigs``: SIGNAL_DTYPE rows grouped by station -- station k's rows are ``sigs[station_offsets[k]:station_offsets[k + 1]]``,
+        in that station's arrival order, ``device`` = the column inside the station.  Returns ``(batch, group_offsets)``: all
+        stations' consumed groups back to back (``MatchedBatch``) and, per station, where its groups start."""
+        n_st = len(self.matchers)
+        sigs = np.ascontiguousarray(sigs, dtype=SIGNAL_DTYPE)
+        so = np.ascontiguousarray(station_offsets, dtype=np.uintp)
+        if so.shape != (n_st + 1,) or int(so[-1]) != len(sigs):
+            raise ValueError("station_offsets must hold one offset per station plus the end")
+        pend = np.zeros(max(1, n_st), dtype=np.uintp)
+        rc = self._lib.rt_match_pending_count_many(self._handles, n_st, pend.ctypes.data)
+        if rc != 0:
+            raise _native.NativeError(rc, "rt_match_pending_count_many failed")
+        caps = pend[:n_st].astype(np.int64) + np.diff(so.astype(np.int64))
+        oo = np.zeros(n_st + 1, dtype=np.uintp)
+        oo[1:] = np.cumsum(caps)
+        cap = max(1, int(oo[-1]))
+        nd = max(1, self.n_devices)
+        groups = np.zeros(cap, dtype=MATCHED_DTYPE)
+        avgs = np.full((cap, nd), np.nan, dtype=np.float64)
+        present = np.zeros((cap, nd), dtype=np.uint8)
+        n_out = np.zeros(max(1, n_st), dtype=np.uintp)
+        rc = self._lib.rt_match_add_many(self._handles, n_st, sigs.ctypes.data, so.ctypes.data, groups.ctypes.data, avgs.ctypes.data,
+                                         present.ctypes.data, oo.ctypes.data, self.n_devices, n_out.ctypes.data)
+        if rc != 0:
+            raise _native.NativeError(rc, "rt_match_add_many failed")
+        # compact: every station's groups sit at the start of its own share of the output
+        counts = n_out[:n_st].astype(np.int64)
+        go = np.zeros(n_st + 1, dtype=np.int64)
+        go[1:] = np.cumsum(counts)
+        # (row j of the compacted output = row oo[station of j] + (j - go[station of j]) of the padded one)
+        st_of = np.repeat(np.arange(n_st, dtype=np.int64), counts)
+        keep = oo[:n_st].astype(np.int64)[st_of] + (np.arange(int(go[-1]), dtype=np.int64) - go[:n_st][st_of])
+        return MatchedBatch(groups[keep], avgs[keep][:, : self.n_devices], present[keep][:, : self.n_devices]), go
 
 
 class SignalMatcher:

@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported(lib):
     for header in headers:
         for name in _declared_symbols(header):
             assert hasattr(raw, name), name
-    assert lib.rt_abi_version() == 5
+    assert lib.rt_abi_version() == 6
 
 
 def test_record_layout_matches_header():

@@ -342,3 +342,69 @@ def test_state_messages_format_like_the_reference():
     assert out.getvalue() == str(G["st_csv_file"])
     assert StateMessage("x", us_to_datetime(0), StateMessage.State.RUNNING).state is StateMessage.State(1)
     assert StateMessage("x", us_to_datetime(0), "2").state is StateMessage.State.STARTED
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_threaded_sinks_are_byte_identical_to_one_thread(threads):
+    """The native sinks deal blocks of 2 048 rows to `set_host_threads` threads and assemble the result in block order: CSV / JSON /
+    CBOR bytes, message offsets and the rows built from analysis records are the same for any number of threads -- and the rows are
+    what the per-signal Python conversion gives (timedelta rounding included)."""
+    import datetime
+
+    from pyradiotracking_amd import _native
+    from pyradiotracking_amd.analyze import _RecordDecoder
+    from pyradiotracking_amd.match import datetime_to_us
+
+    rng = np.random.default_rng(9)
+    n, S = 7001, 37  # (three blocks and a bit)
+    rec = np.zeros(n, dtype=_native.RECORD_DTYPE)
+    rec["stream"] = np.sort(rng.integers(0, S, n))
+    rec["fi"] = rng.integers(0, 256, n)
+    rec["start"] = rng.integers(-40, 1100, n)
+    rec["end"] = np.maximum(rec["start"], 0) + rng.integers(1, 60, n)
+    rec["max_p"] = rng.uniform(1e-10, 1e-6, n)
+    rec["mean_p"] = rec["max_p"] * rng.uniform(0.3, 1.0, n)
+    rec["row_mean"] = rng.uniform(1e-13, 1e-11, n)
+    rec["std_db"] = rng.uniform(0, 25, n)
+    rec["shadowed"] = rng.random(n) < 0.2
+    dec = _RecordDecoder(256, 300000, 150150000, list(rng.uniform(-3, 3, S)))
+    names = [f"sdr{i}" for i in range(S)]
+    ts0 = [datetime_to_us(datetime.datetime(2024, 1, 1, tzinfo=datetime.timezone.utc)) + 1000003 * i for i in range(S)]
+
+    def python_rows():
+        r = rec[rec["shadowed"] == 0]
+        t_start, duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = dec.decode(r)
+        us = datetime.timedelta(microseconds=1)
+        rows = np.zeros(len(r), dtype=rtc.SIGNAL_ROW_DTYPE)
+        rows["device"] = r["stream"]
+        rows["ts_us"] = np.asarray(ts0)[r["stream"]] + np.array([datetime.timedelta(seconds=float(v)) // us for v in t_start])
+        rows["duration_us"] = [datetime.timedelta(seconds=float(v)) // us for v in duration_s]
+        rows["frequency"] = frequency
+        for name, col in (("max_dbw", max_dbw), ("avg_dbw", avg_dbw), ("std_db", std_db), ("noise_dbw", noise_dbw), ("snr_db", snr_db)):
+            rows[name] = np.asarray(col, dtype=np.float64)
+        return rows
+
+    want_rows = python_rows()
+    rtc.set_host_threads(1)
+    one = {k: rtc.format_signals(k, want_rows, names) for k in ("csv", "json", "cbor")}
+    try:
+        assert rtc.set_host_threads(threads) == threads
+        rows = rtc.rows_from_analysis(rec, dec, ts0)
+        assert rows.tobytes() == want_rows.tobytes()
+        for k in ("csv", "json", "cbor"):
+            m = rtc.format_signals(k, rows, names)
+            assert m.data == one[k].data and np.array_equal(m.offsets, one[k].offsets), k
+        # the matched-signal messages alike
+        mr = np.zeros(5000, dtype=rtc.MATCHED_ROW_DTYPE)
+        mr["ts_us"], mr["duration_us"], mr["frequency"] = rows["ts_us"][:5000], rows["duration_us"][:5000], rows["frequency"][:5000]
+        avgs = rng.uniform(-90, -40, (5000, 4))
+        present = (rng.random((5000, 4)) < 0.7).astype(np.uint8)
+        rtc.set_host_threads(1)
+        ref = {k: rtc.format_matched(k, mr, avgs, present, names[:4]) for k in ("csv", "json", "cbor")}
+        rtc.set_host_threads(threads)
+        for k in ("csv", "json", "cbor"):
+            m = rtc.format_matched(k, mr, avgs, present, names[:4])
+            assert m.data == ref[k].data and np.array_equal(m.offsets, ref[k].offsets), k
+    finally:
+        rtc.set_host_threads(0)
+    assert len(one["csv"]) == len(want_rows) and one["csv"][0].endswith(b"\r\n")
