@@ -113,6 +113,13 @@ __device__ __forceinline__ bool bit_of(uint32_t lo, uint32_t hi, int r) { return
 #ifndef RT_W64_PREFETCH
 #define RT_W64_PREFETCH 1
 #endif
+// 1 (round 6) = quarter 2 of the NEXT segment is requested into registers as soon as a step's powers are taken -- the transform's 128
+// registers are dead from there on --, so that the next step asks for quarter 3 alone and its pass 1 waits for one late quarter instead
+// of two (stage stamps, round 4: 5.9 k + 1.8 k of a step's 21.5 k cycles went into pass 1 waiting for the second half).  0 = both
+// quarters at the head of their own step (diagnostic builds: the A/B).
+#ifndef RT_W64_Q2AHEAD
+#define RT_W64_Q2AHEAD 0  // (the product: see EXPERIMENTS.md, round 6 -- with the sixteen pairs carried over the loop edge hipcc spills 45 - 55 registers inside the step)
+#endif
 // (Tried and dropped: spreading a step's vector-memory instructions over its arithmetic -- quarter 3's loads behind quarter 0's
 // transform, the prefetch pieces two at a time between the twiddle rows -- because a wave that issues them in one run waits for
 // queue slots in between (38 cycles per load, 76 per LDS-DMA piece, profiles/r04_c_stage_stamps_*).  Either placement sends hipcc's
@@ -213,6 +220,15 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
             int k7 = 0;
             int seg = LISTED ? p.seg_list[(int64_t)s * T + e0] : ((c0 + c_len < T ? c0 + c_len : T) - 1);
             bool halo = false;
+            // RT_W64_Q2AHEAD: quarter 2 of a step's segment is requested by the step BEFORE (every step knows its successor: the chunk
+            // walks down, a listed pass reads its list one entry ahead, the segment below the chunk is asked for in any case) -- and
+            // for the item's first step here, so that the step loop has ONE place that defines these sixteen registers.
+            raw_t q2r[16];
+            if constexpr (RT_W64_Q2AHEAD != 0 && MODE != 3) {
+                const rsrc_t r0 = make_rsrc(stream_iq + (int64_t)seg * N, (uint32_t)(N * sizeof(raw_t)));
+#pragma unroll
+                for (int j = 0; j < 16; ++j) q2r[j] = buf_load_iq(r0, lane * (int)sizeof(raw_t), 64 * (2 + 4 * j) * (int)sizeof(raw_t), raw_t{});
+            }
             for (;;) {
                 RT_STAMP(0);  // loop control, the previous step's threshold test and emission
                 bits64 first_nxt{0u, 0u};  // MODE 5, chunk 0: the bins whose run through t = 0 reaches this segment; MODE 7: the cells to emit
@@ -237,12 +253,15 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                         w64_prefetch<raw_t>(r, area, lane);
                     }
                     pre_seg = -1;  // (this step's exchange writes over the area: what it held is gone unless the step asks for more)
-                    raw_t raw[32];  // quarters 2 and 3: element [16 (n0 - 2) + j]
+                    // quarters 2 and 3, sixteen registers each: element [j].  (Quarter 2 lives in the SAME sixteen registers whether the
+                    // step before requested it -- older than the loads below, in flight or here -- or this one does.)
+                    if constexpr (!(RT_W64_Q2AHEAD != 0 && MODE != 3)) {
 #pragma unroll
-                    for (int n0 = 2; n0 < 4; ++n0)
+                        for (int j = 0; j < 16; ++j) q2r[j] = buf_load_iq(r, lane * (int)sizeof(raw_t), 64 * (2 + 4 * j) * (int)sizeof(raw_t), raw_t{});
+                    }
+                    raw_t q3r[16];
 #pragma unroll
-                        for (int j = 0; j < 16; ++j)
-                            raw[16 * (n0 - 2) + j] = buf_load_iq(r, lane * (int)sizeof(raw_t), 64 * (n0 + 4 * j) * (int)sizeof(raw_t), raw_t{});
+                    for (int j = 0; j < 16; ++j) q3r[j] = buf_load_iq(r, lane * (int)sizeof(raw_t), 64 * (3 + 4 * j) * (int)sizeof(raw_t), raw_t{});
                     RT_STAMP(1);  // issue: a prefetch nobody made + the 32 loads of quarters 2 and 3
                     __builtin_amdgcn_sched_barrier(0);
                     // the sixteen LDS-DMA pieces are older than the 32 loads: all but the 32 youngest operations done = the area is filled
@@ -256,7 +275,7 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                     asm volatile("" : "+v"(lane_a));
                     const raw_t *pre = reinterpret_cast<const raw_t *>(area);
                     auto sample = [&](int n0, int j) -> cf {  // x[lane + 64 (n0 + 4 j)]
-                        return to_cf(n0 < 2 ? pre[(2 * j + n0) * 64 + lane_a] : raw[16 * (n0 - 2) + j]);
+                        return to_cf(n0 < 2 ? pre[(2 * j + n0) * 64 + lane_a] : n0 == 2 ? q2r[j] : q3r[j]);
                     };
                     if constexpr (MODE == 3) {
                         // traffic calibration: the scan's exact load stream, nothing else
@@ -389,8 +408,8 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                 // ---- the area is free: quarters 0 and 1 of the segment the next step will take, where this step can tell.  At a
                 // chunk's lowest segment that is the segment below it, needed only if a lowest cell turns out hot (half the chunks
                 // of config 5): asked for anyway, 16 KiB per chunk against the chunk's L x 32 KiB.
+                int nxt = -1;  // the segment the next step will (or may) take, where this step can tell
                 if (RT_W64_PREFETCH) {
-                    int nxt = -1;
                     if constexpr (LISTED) nxt = seg_after;
                     else if (!halo) nxt = (seg > c0) ? seg - 1 : ((EMIT && c0 > 0) ? c0 - 1 : -1);
                     if (nxt >= 0) {
@@ -443,7 +462,6 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                 float P[64];
 #pragma unroll
                 for (int r = 0; r < 64; ++r) P[r] = __builtin_fmaf(u[r].x, u[r].x, u[r].y * u[r].y);
-
                 if constexpr (SUMS) {
                     if (!halo) {
 #pragma unroll
@@ -580,6 +598,19 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                         }
                     }
                     next_hot = hot;
+                }
+
+                if constexpr (RT_W64_Q2AHEAD != 0 && MODE != 3) {
+                    // the step's powers are consumed: quarter 2 of the next step's segment into sixteen registers (requested right behind the powers --
+                    // ahead of the stores, the threshold test and the emission -- the sixteen pairs stayed live across that block and the
+                    // kernel spilled 64 registers inside the step)
+                    if (nxt >= 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const rsrc_t rn = make_rsrc(stream_iq + (int64_t)nxt * N, (uint32_t)(N * sizeof(raw_t)));
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) q2r[j] = buf_load_iq(rn, lane * (int)sizeof(raw_t), 64 * (2 + 4 * j) * (int)sizeof(raw_t), raw_t{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
 
 #ifdef RT_STAMPS
