@@ -275,7 +275,7 @@ void launch_stft_lin(rt_handle *h, const StftParams &p, int items, hipStream_t s
     const int blk = scan_block(h->R3);
     // workgroups a CU holds: three waves per SIMD by registers (four for the leaner uint8 / RT_WG4 instantiations), and at
     // nperseg 256 twelve one-wave workgroups by LDS whatever the registers allow
-    const int per_cu = std::min(((h->R3 <= RT_WG4_MAX_R3 || (U8 && h->R3 == 1)) ? 4 : 3) * (kBlock / blk), blk == 64 ? 12 : 4);
+    const int per_cu = scan_dma(h->R3, U8, h->QS) ? 2 : std::min(((h->R3 <= RT_WG4_MAX_R3 || (U8 && h->R3 == 1)) ? 4 : 3) * (kBlock / blk), blk == 64 ? 12 : 4);
     // (A/B on one box, whole path, profiles/r03_h_persistent_ab.txt: config 3 one lane 662 k -> 684 k MS/s, config 5 share +1 %)
     const bool persist = scan_persistent(h->R3, MODE);
     const int blocks = persist ? std::min(items, h->n_cu * per_cu) : items;

@@ -494,6 +494,16 @@ __host__ __device__ constexpr int scan_block(int R3) { return R3 <= RT_ONE_WAVE_
 // so "subtract the mean from every sample" (32 subtractions per lane and step, and the transform waiting for the
 // group-wide sum) becomes "subtract sum * W[k]/N from three output bins" (six fused multiply-adds, after pass 3).
 // The host picks LIN when the window qualifies (rt_create); other windows keep the subtract-first form.
+// Experiment (diagnostic builds, -DRT_EXP_DMA1024=1; round 6, the round-5 review's item 8): the complex64 kernels of nperseg 1024 take the
+// next segment through an LDS landing zone of 8 KiB per wave (eight `buffer_load_dwordx4 ... lds` instead of sixteen register loads, issued
+// as soon as the step's samples are out of the zone -- a whole transform ahead), at TWO workgroups per CU (the zones do not fit three
+// times) with up to 256 registers.  Measured against the product on one box: EXPERIMENTS.md, round 6.
+#ifndef RT_EXP_DMA1024
+#define RT_EXP_DMA1024 0
+#endif
+__host__ __device__ constexpr bool scan_dma(int r3, bool u8, int qs) { return RT_EXP_DMA1024 && r3 == 4 && !u8 && qs == 0; }
+__device__ void raw_buffer_load_lds_fwd(rsrc_t rsrc, __attribute__((address_space(3))) void *lds, int size, int voffset, int soffset, int offset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.lds");
 // QS (round 6): nperseg 128 / 64 / 32 = 16 QS, lane groups of QS = 8 / 4 / 2 lanes (R3 = 1 in every other respect: one wave-private
 // exchange, no barrier in the step loop, bin = lane + LG * register).  The transform is the 16 x QS form with the SMALL pass first:
 // lane a of a group holds the 16 / QS consecutive samples n' = (16 / QS) a + e of every sixteenth of the segment, x[n' + 16 m'] --
@@ -523,7 +533,7 @@ template <int R3, int MODE, bool U8 = false, bool LIN = false, int QS = 0>
 #ifndef RT_EXP_U8_PK
 #define RT_EXP_U8_PK 0
 #endif
-__global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
+__global__ __launch_bounds__(scan_block(R3), scan_dma(R3, U8, QS) ? 2 : (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 4 : 3)  // workgroups per CU = waves/SIMD: at most 128 / 168 VGPRs (left alone, hipcc takes 200 for nperseg 1024)
  void stft_scan(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     static_assert(QS == 0 || (R3 == 1 && (QS == 2 || QS == 4 || QS == 8)), "QS: lane groups of 2 / 4 / 8 lanes, R3 = 1");
@@ -542,12 +552,13 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // One LDS block carved by hand: at nperseg 256 the pieces add up to exactly 40 960 B, a quarter of a CU's LDS
     // (separate __shared__ arrays cannot have size zero, and their placeholders cost the fourth workgroup).
     constexpr bool W_IN_LDS = (R3 <= 8);  // N = 4096: the window comes from L2 as well (3 workgroups per CU)
-    constexpr bool T1_IN_LDS = (R3 <= 4);
+    constexpr bool T1_IN_LDS = (R3 <= 4) && !scan_dma(R3, U8, QS);  // (the landing-zone experiment: the factored form, 6 KiB less -- two workgroups' 78 KiB fit a CU)
     constexpr bool T1_FACTORED = !T1_IN_LDS;
     // (uint8 input at nperseg 256 does run at four workgroups per CU: 106 VGPRs, +3 %)
     // (nperseg 2048: 96 -- with 128 the block is 54 576 B, and LDS is handed out in 512-byte pieces: three workgroups
     // would need 164 352 of the CU's 163 840 B, so the kernel ran at two; profiles/r03_d_stage_stamps.txt)
-    constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 32 : (R3 == 8) ? 96 : kStageCap;  // candidate cells staged per wave before a flush
+    constexpr bool DMA = scan_dma(R3, U8, QS);
+    constexpr int kStage = (R3 <= RT_WG4_MAX_R3 || (U8 && R3 == 1 && !RT_EXP_U8_PK)) ? 32 : (R3 == 8) ? 96 : DMA ? 64 : kStageCap;  // candidate cells staged per wave before a flush
     constexpr size_t kXchB = sizeof(cf) * (BLK * ROW + GPW * GPAD);
     constexpr size_t kRedB = (LG > 64) ? sizeof(cf) * (BLK / 64) + 16 : 0;  // + the three tail_any words
     constexpr size_t kWB = W_IN_LDS ? sizeof(float4) * 4 * LG : 0;
@@ -567,7 +578,10 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
     // them).  Where a group lives inside one wave and the block still fits three times into a CU's LDS: nperseg <= 512.
     constexpr bool BITS_LDS = (MODE == 6) && R3 <= 2 && (QS == 0 || QS >= 4);  // (a lane stores the words of four lanes: groups of two keep the short stores)
     constexpr size_t kBitsB = BITS_LDS ? sizeof(uint16_t) * 4 * BLK : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB + kBitsB];
+    constexpr size_t kDmaB = DMA ? sizeof(cf) * N * (BLK / 64) : 0;  // a segment per wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds_block[kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB + kBitsB + kDmaB];
+    // (wave index in a scalar register: an LDS-DMA takes its destination from M0)
+    cf *const landing = reinterpret_cast<cf *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB + kBitsB) + (DMA ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * N : 0);
     uint16_t *const bits_lds = reinterpret_cast<uint16_t *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB + kThrB) + (BITS_LDS ? g_of(threadIdx.x, LG) * 4 * LG : 0);  // this group's [4 steps][LG]
     float4 *const thr_lds = reinterpret_cast<float4 *>(lds_block + kXchB + kRedB + kWB + kT1fB + kT1B + kT2B + kStageB);
     cf *const xch = reinterpret_cast<cf *>(lds_block);
@@ -850,8 +864,15 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
             // (sg < 0: the step below the chunk of a workgroup whose other lane group holds chunk 0)
             const rsrc_t r = make_rsrc(stream_iq + (int64_t)(sg < 0 ? 0 : sg) * N, (sg >= 0 && sg < T) ? (uint32_t)(N * sizeof(raw_t)) : 0u);
 #endif
+            if constexpr (DMA) {
+                // the wave's landing zone: piece j = 1 KiB of consecutive samples (a lane 16 bytes), eight instructions, no registers
 #pragma unroll
-            for (int m = 0; m < 16; ++m) nxt[m] = buf_load_iq(r, lt * (int)sizeof(raw_t), LG * m * (int)sizeof(raw_t), raw_t{});
+                for (int j = 0; j < 8; ++j)
+                    raw_buffer_load_lds_fwd(r, (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(landing) + 1024 * j), 16, (int)(threadIdx.x & 63) * 16, 1024 * j, 0, kAuxNT);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) nxt[m] = buf_load_iq(r, lt * (int)sizeof(raw_t), LG * m * (int)sizeof(raw_t), raw_t{});
+            }
         } else if ((MODE != 5 && MODE != 7) || group_need) {
             int sc = seg_req < seg_hi ? seg_req : seg_hi;
             sc = sc < 0 ? 0 : sc;  // (step L + 1 of a wave that also holds chunk 0)
@@ -906,10 +927,26 @@ __global__ __launch_bounds__(scan_block(R3), (R3 <= RT_WG4_MAX_R3 || (U8 && R3 =
         const bool active = chunk_ok && seg < T && seg >= 0;
 
         C v[16];
+        if constexpr (DMA) {
+            // the segment has landed (everything older than this point has: vmcnt(0)); its samples out of the zone, which is then free
+            // for the next segment's pieces
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_sched_barrier(0);
+            int lt_d = lt;
+            asm volatile("" : "+v"(lt_d));
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const cf x = to_cf(nxt[m]);
-            v[m] = make_c<C>(x.x, x.y);
+            for (int m = 0; m < 16; ++m) {
+                const cf x = landing[lt_d + LG * m];
+                v[m] = make_c<C>(x.x, x.y);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the reads have returned
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const cf x = to_cf(nxt[m]);
+                v[m] = make_c<C>(x.x, x.y);
+            }
         }
         const uint32_t need_seg = need | first_nxt;  // (first_nxt was requested for this step's segment)
         if constexpr (BITS_LDS) {
