@@ -684,6 +684,8 @@ def main():
                            "1/lanes of the streams and runs beside the other lanes' scan and detect kernels, which stretches it",
         "detect_kernel_ms": round(ms_detect / max(1, args.steps) / lanes, 4),
         "whole_path_frac": round(value * 1e6 / world * bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4),
+        "frac_note": "`frac` / `achieved` / `kernel_ms`: the dominant kernel's launch ALONE (what a one-lane kernel trace reproduces); `whole_path_frac`: the "
+                     "timed region itself -- `value` x 8 B per sample (per GPU) over the 8 TB/s peak, detection, fetch and launch gaps included",
     }
 
     if u8:
@@ -791,7 +793,8 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
     out["signal_objects_per_s"] = rate(lambda: decoder.signals(kept, device_names, ts0), len(kept))
     out["signal_batch_records_per_s"] = rate(lambda: decoder.signal_batch(kept, device_names, ts0), len(kept))
     # The native sinks work on arrays and, since round 6, on several cores (rt_host_set_threads; byte-identical output for any number).
-    # A step's records are few thousand: the sample is repeated to a batch a station fleet would hand over (>= 262 144 records).
+    # A step's records are few thousand: the sample is repeated to a batch a station fleet would hand over (>= 1 048 576 records; for
+    # the matcher every repetition a second later than the one before, or the copies would all fall into the first one's groups).
     # (the rank is pinned to its NUMA share: the sinks get the cores the job had, like the CPU baseline's workers)
     pinned_to = None
     try:
@@ -801,7 +804,7 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
     except (AttributeError, OSError):
         pinned_to = None
     try:
-        reps = max(1, -(-262144 // max(1, n)))
+        reps = max(1, -(-1048576 // max(1, n)))
         big = np.concatenate([rec] * reps) if reps > 1 else rec
         n_big = int((big["shadowed"] == 0).sum())
         out["sink_batch_records"] = n_big
@@ -817,6 +820,7 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
         nd = 4
         n_st = -(-len(device_names) // nd)
         rows = consume.rows_from_analysis(big, decoder, ts0_us)
+        rows["ts_us"] += (np.flatnonzero(big["shadowed"] == 0) // max(1, n)).astype(np.int64) * 1000000
         st = rows["device"] // nd
         order = np.lexsort((rows["ts_us"], st))
         msig = np.zeros(len(order), dtype=rtm.SIGNAL_DTYPE)

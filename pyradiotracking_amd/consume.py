@@ -84,18 +84,31 @@ def csvify(o):
 
 
 class Messages:
-    """``n`` serialised messages back to back: ``data`` (bytes) and ``offsets`` (n + 1)."""
+    """``n`` serialised messages back to back: ``data`` (bytes) and ``offsets`` (n + 1).  The native call's output buffer is kept
+    as it is (``buffer``: a uint8 array, usable wherever a bytes-like object is -- ``file.write``, ``socket.send``); ``data`` makes
+    the ``bytes`` object on first use (a copy of tens of megabytes for a few hundred thousand rows: not paid by consumers that
+    write the buffer out or take single messages)."""
 
-    __slots__ = ("data", "offsets")
+    __slots__ = ("buffer", "offsets", "_data")
 
-    def __init__(self, data: bytes, offsets: np.ndarray):
-        self.data, self.offsets = data, offsets
+    def __init__(self, data, offsets: np.ndarray):
+        if isinstance(data, (bytes, bytearray)):
+            self.buffer, self._data = np.frombuffer(data, dtype=np.uint8), bytes(data)
+        else:
+            self.buffer, self._data = data, None
+        self.offsets = offsets
+
+    @property
+    def data(self) -> bytes:
+        if self._data is None:
+            self._data = self.buffer.tobytes()
+        return self._data
 
     def __len__(self) -> int:
         return len(self.offsets) - 1
 
     def __getitem__(self, i: int) -> bytes:
-        return self.data[int(self.offsets[i]): int(self.offsets[i + 1])]
+        return self.buffer[int(self.offsets[i]): int(self.offsets[i + 1])].tobytes()
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -121,7 +134,7 @@ def _call(fn, n: int, guess: int, *args) -> Messages:
         rc = fn(*args, buf.ctypes.data, cap, offsets.ctypes.data, C.byref(need))
     if rc != 0:
         raise _native.NativeError(rc, "rt_format: invalid arguments")
-    return Messages(buf[: need.value].tobytes(), offsets)
+    return Messages(buf[: need.value], offsets)
 
 
 def format_signals(kind: str, rows: np.ndarray, device_names: Sequence[str]) -> Messages:
