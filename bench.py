@@ -66,7 +66,7 @@ OTHER_CONFIGS = [
     ("config5_share", dict(streams=1024, sample_rate=3200000, samples=3200000, nperseg=4096, window="hamming", trains=True, lanes=1,
                            what="BASELINE config 5, the 1 024-stream share one GPU of eight analyses (tag trains)")),
     ("default_geometry_noise_floor", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=256, window="hamming", trains=False, lanes=3,
-                                          noise_dbw=-88.0, settle=20,
+                                          noise_dbw=-88.0, steps=40, settle=20,
                                           what="the reference's defaults (300 kS/s, nperseg 256, -90 dBW, 8-40 ms) with the noise floor at -88 dBW, 2 dB OVER "
                                                "the threshold (a real RTL-SDR): AUTO reaches the exact run-length pre-filter")),
     ("config2_uint8", dict(streams=256, sample_rate=2048000, samples=2048000, nperseg=256, window="hamming", trains=False, lanes=3, input="u8",
@@ -79,6 +79,7 @@ OTHER_CONFIGS = [
                                                      "noise (-90.2 dBW per bin at 300 kS/s): AUTO reaches the exact run-length pre-filter")),
     # half the default nperseg -- a plausible station setting: a fused scan since round 6 (lane groups of eight lanes, csrc/rt_kernels.h: stft_scan<.., QS>)
     ("nperseg128_defaults", dict(streams=4096, sample_rate=300000, samples=300000, nperseg=128, window="hamming", trains=False, lanes=3,
+                                 steps=40, settle=10,  # (2-ms steps: ten of them are 20 ms, one hiccup of the box is a quarter of that)
                                  what="the reference's defaults at fft_nperseg 128: the fused scan with lane groups of eight lanes, sparse path")),
     # twice the largest size of the rounds before: a fused scan since round 6 as well (csrc/rt_scan_wg.h)
     ("nperseg8192", dict(streams=512, sample_rate=3200000, samples=3200000, nperseg=8192, window="hamming", trains=False, lanes=1,

@@ -2194,6 +2194,9 @@ def test_config2_full_size_properties():
         ("config3", 2400000, 1024, "hann", 2400000, 512, False),   # BASELINE configs[2]: 4096 streams on one GPU; 512 here
         ("config4", 2048000, 256, "hamming", 524288, 2048, False),  # configs[3] at the one-GPU buffer length, 1/16 of the streams
         ("config5", 3200000, 4096, "hamming", 3200000, 256, True),  # configs[4]: 1024 streams per GPU at 8 GPUs; 256 here, dense tag trains
+        # bench.py's other_configs lines on the round-6 kernels (16 x QS scan; one-workgroup transform), 1/8 of the streams
+        ("defaults128", 300000, 128, "hamming", 300000, 512, False),
+        ("nperseg8192", 3200000, 8192, "hamming", 3200000, 64, False),
     ],
 )
 def test_other_baseline_configs_full_geometry_properties(name, fs, nperseg, window, blen, n_streams, trains):

@@ -99,3 +99,29 @@ def rotated(R3, ROW=18):
 if __name__ == "__main__":
     for R3 in (1, 2, 4, 8, 16):
         report("rotated", R3, rotated(R3))
+
+
+def small(QS, pad):
+    """`small` section (round 6): nperseg 16 QS with lane groups of QS lanes (csrc/rt_kernels.h: stft_scan<.., QS>).  A group's rows:
+    QS rows of ROW float2 (ROW = 16 at QS = 2, else 18) + `pad` float2 per group; the write of register r goes to row r % QS,
+    column (r / QS) QS + lt; lane lt reads its row lt as eight b128.  Lane l of the wave is lane l % QS of group l / QS."""
+    ROW = 16 if QS == 2 else 18
+    stride = QS * ROW + pad
+    c_w = i_w = c_r = i_r = 0
+    for r in range(16):
+        addrs = [8 * ((l // QS) * stride + (r % QS) * ROW + (r // QS) * QS + l % QS) for l in range(64)]
+        a, b = write_b64(addrs)
+        c_w += a
+        i_w += b
+    for j in range(8):
+        addrs = [8 * ((l // QS) * stride + (l % QS) * ROW + 2 * j) for l in range(64)]
+        a, b = read_b128(addrs)
+        c_r += a
+        i_r += b
+    print(f"QS={QS} pad {pad:2d} (nperseg {16 * QS:3d})        write {c_w}/{i_w}  read {c_r}/{i_r}   total {c_w + c_r}/{i_w + i_r} = {(c_w + c_r) / (i_w + i_r):.2f}x")
+
+
+if __name__ == "__main__":
+    for QS in (2, 4, 8):
+        small(QS, QS)
+    small(8, 0)  # the uint8 instantiation at nperseg 128 (no pad: its block must stay within a quarter of a CU's LDS)
