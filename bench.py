@@ -115,6 +115,8 @@ def parse():
     ap.add_argument("--window", default=None)
     ap.add_argument("--mode", default="auto", choices=["auto", "dense", "sparse", "prefilter", "runfilter"])
     ap.add_argument("--segs-per-chunk", type=int, default=0)
+    ap.add_argument("--group-detect", choices=["auto", "on", "off"], default="auto",
+                    help="sparse detection by groups of candidate lists (detect_group): the library's rule (from 1 024 streams per handle on), or forced for A/B runs")
     ap.add_argument("--hot-capacity", type=int, default=0,
                     help="candidate cells kept per (stream, bin mod 16 bucket) and call (rt_config.hot_capacity; 0 = default: one bin row "
                          "times max(1, nperseg / 1024), at most 8192; up to 16384 fits the detection's LDS sort)")
@@ -517,6 +519,7 @@ def main():
             hot_capacity=args.hot_capacity,
             hip_stream=stream.cuda_stream if lanes <= 1 else None,
             lanes=lanes,
+            group_detect={"auto": None, "on": True, "off": False}[args.group_detect],
             **kw,
         )
 

@@ -129,6 +129,10 @@ typedef struct rt_config {
                                      detrend is applied to the transform instead (three bins), which is cheaper and
                                      equal within float32 round-off -- other windows and uint8 input (where a saturated
                                      segment cancels exactly in the reference) use the subtract-first form anyway */
+#define RT_FLAG_GROUP_DETECT 4u    /* sparse detection (analyze.py:330-452 on the candidate lists) with one wave per stream, or per quarter
+                                     of a stream's sixteen lists, instead of one per list -- the same records; the default from 1 024
+                                     streams per handle on, where the lists are many and short.  This flag: at any number of streams */
+#define RT_FLAG_NO_GROUP_DETECT 8u /* ... never */
 
 /*
  * One extracted plateau, before it becomes a Signal (analyze.py:442-449).

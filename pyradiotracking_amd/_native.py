@@ -27,6 +27,8 @@ RT_E_HOT_OVERFLOW = -8  # RT_MODE_SPARSE: a candidate list overflowed, the call 
 RT_MODE_AUTO, RT_MODE_DENSE, RT_MODE_SPARSE, RT_MODE_PREFILTER, RT_MODE_RUNFILTER = 0, 1, 2, 3, 4
 RT_FLAG_TIMING = 1
 RT_FLAG_NO_LIN_DETREND = 2  # subtract the segment mean before windowing even for hamming / hann / boxcar windows
+RT_FLAG_GROUP_DETECT = 4  # sparse detection by groups of candidate lists at any number of streams (default: from 1 024 streams per handle)
+RT_FLAG_NO_GROUP_DETECT = 8  # ... never
 
 SUPPORTED_NPERSEG = tuple(range(8, 8193)) + (16384,)  # 8 .. 8192 and 16384 (32 .. 4096 powers of two: the fused scans; everything else: general transforms, dense path)
 FUSED_NPERSEG = (256, 512, 1024, 2048, 4096)
@@ -256,6 +258,7 @@ class NativeAnalyzer:
         lanes: int = 1,
         subtract_first: bool = False,
         record_pool: int = 0,
+        group_detect: Optional[bool] = None,
     ):
         self._lib = load_library()
         self._handle = C.c_void_p()
@@ -279,7 +282,8 @@ class NativeAnalyzer:
         cfg.hot_capacity = hot_capacity
         cfg.record_capacity = record_capacity
         cfg.segs_per_chunk = segs_per_chunk
-        cfg.flags = (RT_FLAG_TIMING if timing else 0) | (RT_FLAG_NO_LIN_DETREND if subtract_first else 0)
+        cfg.flags = ((RT_FLAG_TIMING if timing else 0) | (RT_FLAG_NO_LIN_DETREND if subtract_first else 0)
+                     | (0 if group_detect is None else RT_FLAG_GROUP_DETECT if group_detect else RT_FLAG_NO_GROUP_DETECT))
         cfg.hip_stream = hip_stream
         cfg.lanes = int(lanes)
         cfg.record_pool = int(record_pool)

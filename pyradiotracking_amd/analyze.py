@@ -250,6 +250,7 @@ class BatchSignalAnalyzer:
         lanes: Union[int, str] = 1,
         subtract_first: bool = False,
         record_pool: int = 0,
+        group_detect: Optional[bool] = None,
         **kwargs,
     ):
         """``mode`` (``rt_config.mode``): ``"auto"`` (default) analyses on the fused sparse path and, when an input's noise
@@ -264,6 +265,10 @@ class BatchSignalAnalyzer:
         ``subtract_first``: apply SciPy's ``detrend='constant'`` in SciPy's order (segment mean subtracted before
         the window) even for hamming / hann / boxcar windows, where the kernels by default subtract ``mean * FFT(window)``
         from the three bins it touches instead (equal within float32 round-off, fewer operations).
+
+        ``group_detect`` (``RT_FLAG_GROUP_DETECT`` / ``RT_FLAG_NO_GROUP_DETECT``): sparse detection with one wave per stream or
+        quarter of a stream's sixteen candidate lists instead of one per list -- the same records; ``None`` (default) lets the
+        library decide (from 1 024 streams per handle on, where the lists are many and short).
 
         ``lanes`` > 1 (``rt_config.lanes``) splits the streams into that many contiguous groups, each
         analysed on its own HIP stream: the detection kernels and launch gaps of one group then overlap the
@@ -324,6 +329,7 @@ class BatchSignalAnalyzer:
             lanes=max(1, int(lanes)),
             subtract_first=bool(subtract_first),
             record_pool=int(record_pool),
+            group_detect=group_detect,
         )
         if per_stream_cal is not None:
             self.calibration_db = per_stream_cal
@@ -564,7 +570,7 @@ class SignalAnalyzer:
             gpu=gpu,
             mode=mode,
             # capacities of the native handle (no counterpart in the reference, whose lists are unbounded)
-            **{k: kwargs[k] for k in ("record_capacity", "record_pool", "hot_capacity") if k in kwargs},
+            **{k: kwargs[k] for k in ("record_capacity", "record_pool", "hot_capacity", "group_detect") if k in kwargs},
         )
         self._decoder = self._batch._decoder
 

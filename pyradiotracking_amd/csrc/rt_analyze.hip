@@ -35,6 +35,7 @@ using namespace rt;
 namespace {
 
 thread_local std::string g_create_error;
+constexpr uint32_t kFlagLaneOfLargeBatch = 0x40000000u;  // rt_config.flags of a lane's own handle (internal): the whole batch has >= 1 024 streams
 thread_local bool g_creating_lane = false;  // rt_create of a laned handle is creating one of its lanes
 
 constexpr int kSlots = 2;
@@ -61,6 +62,7 @@ struct CallCtx {
     int n_dense_streams = 0;  // streams of this call that were re-run dense on their own (AUTO, partial fall-back)
     bool pool_grown = false;  // the record pool was enlarged for this call and the call analysed again (fetch_one)
     int cap_grown = 0;        // times the handle's per-stream record capacity was enlarged for this call (fetch_one: grow_record_capacity)
+    int rec_cap_used = 0;     // the per-stream record capacity its kernels ran with (a call in flight while ANOTHER call grew the capacity was still truncated at the old one)
     bool thr_rerun = false;   // analysed again on RT_MODE_RUNFILTER with thresholds from its own row means (once per call)
     bool abs_counted = false; // a MODE 4 / 6 scan of this call left the slot's h_abs_hot
     bool level_settled = false;  // AUTO's level bookkeeping for this call is done (fetch_one passes over a call twice: size query / peek, then delivery)
@@ -150,6 +152,9 @@ struct rt_handle {
     Slot slot[kSlots];
 
     int hot_cap = 8192, rec_cap = 1024, cand_cap = 32;
+    bool group_detect = false;  // sparse detection of a whole stream by one wave (detect_group) is possible and wanted: many streams per launch ...
+    bool group_light = true;    // ... and the streams of the call fetched last held few candidate cells on average (fetch_one); a call's launch looks at this
+    bool group_forced = false;  // RT_FLAG_GROUP_DETECT: whatever the streams hold
     size_t lds_large = 0, lds_small = 0, lds_dense = 0;
 
     bool lin = false;      // constant detrend by linearity (cosine-sum window of order <= 1; rt_kernels.h: LIN)
@@ -544,7 +549,11 @@ DetectArgs make_detect_args(rt_handle *h, Slot &sl, int n_seg, int n_bins, int n
     a.hot = sl.d_hot;
     a.hot_count = sl.d_hot_count;
     a.hot_count_rw = sl.d_hot_count;
-    a.large_any = sl.d_hot_seen;  // (one word per stream of the array's S * 16)
+    a.large_any = sl.d_hot_seen;  // (one word per stream of the array's S * 16; behind them detect_group's work list, then its counter)
+    if (h->group_detect && (h->group_forced || h->group_light)) {
+        a.work_list = reinterpret_cast<int32_t *>(sl.d_hot_seen) + h->cfg.n_streams;
+        a.work_count = a.work_list + (size_t)h->cfg.n_streams * kQuarters;
+    }
     a.hot_total = sl.h_hot_total;
     a.lds_cells = next_pow2(std::max(h->hot_cap, 64));
     a.cand_cap = h->cand_cap;
@@ -614,6 +623,7 @@ void launch_scan(rt_handle *h, const StftParams &sp, int blocks, bool u8, hipStr
 // `own_means`: RT_MODE_RUNFILTER for a call whose per-bin thresholds have just failed their check -- the thresholds of
 // the re-run come from the row means the failed scan left (make_bin_thresholds_from_means).
 int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr, bool second_pass_only = false, bool own_means = false) {
+    sl.call.rec_cap_used = h->rec_cap;
     const CallCtx &c = sl.call;
     if (launched) *launched = false;
     if (h->general) {
@@ -840,8 +850,15 @@ int enqueue_analysis(rt_handle *h, Slot &sl, int mode, bool *launched = nullptr,
     if (dense) {
         launch_detect_dense(h, S, sd, a);
     } else {
-        const int waves = S * kBuckets;
-        hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
+        if (a.work_list) {
+            // thousands of streams with a few hundred cells each: a wave per stream (detect_group), the per-list waves only for the
+            // streams it leaves -- a looping grid that finds its work list empty as a rule
+            hipLaunchKernelGGL(detect_group, dim3((S + 3) / 4), dim3(256), h->lds_small, sd, a);
+            hipLaunchKernelGGL(detect_bucket_listed, dim3(std::min(S * kQuarters, 1024)), dim3(256), h->lds_small, sd, a);
+        } else {
+            const int waves = S * kBuckets;
+            hipLaunchKernelGGL(detect_bucket<false>, dim3((waves + 3) / 4), dim3(256), h->lds_small, sd, a);
+        }
         // (the large instantiation returns at once for a stream without a bucket over kSmallBucket cells; the per-bucket counters
         // are put back to zero by finalize_records)
         hipLaunchKernelGGL(detect_bucket<true>, dim3(S), dim3(256), h->lds_large, sd, a);  // one workgroup per stream: its 16 buckets in turn
@@ -1187,6 +1204,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             kc.lanes = 1;
             kc.segs_per_chunk = choose_chunk(*cfg, R3, QS, cfg->n_streams, (int)(cfg->max_samples / cfg->nperseg));  // the whole batch's choice
             kc.n_streams = p->kid_base[(size_t)k + 1] - p->kid_base[(size_t)k];
+            // (detection by groups of buckets is decided by the whole batch: the lanes' launches run side by side)
+            if (cfg->n_streams >= 1024) kc.flags |= (int32_t)kFlagLaneOfLargeBatch;
             rt_handle *kid = nullptr;
             g_creating_lane = true;
             const int rc = rt_create(&kc, &kid);
@@ -1305,6 +1324,19 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
     if (h->lds_large + 8 * 1024 > 160 * 1024) {
         delete h;
         return fail_create(RT_E_INVALID, "hot_capacity does not fit the 160 KiB LDS of a CU");
+    }
+    {
+        // Sparse detection by groups of buckets (detect_group) where a launch of one wave per (stream, bucket) would be many rounds of
+        // nearly empty waves: from 1 024 streams per handle on (below that the per-bucket waves fit the chip in a round or two and finish
+        // sooner than one wave per stream would).  Needs the group's row means beside its cells (nperseg <= 256) and (bin, t) + a
+        // 10-bit position in one word.  RT_FLAG_GROUP_DETECT / RT_FLAG_NO_GROUP_DETECT force it either way (tests, A/B runs).
+        int fbits = 0;
+        while ((1 << fbits) < h->N) ++fbits;
+        const bool can = !general && h->N <= kGroupBins && fbits + key_tbits(std::max(h->max_seg, 1)) + 10 <= 32;
+        const bool want = (cfg->flags & RT_FLAG_GROUP_DETECT) ? true : (cfg->flags & RT_FLAG_NO_GROUP_DETECT) ? false
+                          : cfg->n_streams >= 1024 || (g_creating_lane && (cfg->flags & kFlagLaneOfLargeBatch));
+        h->group_detect = can && want;
+        h->group_forced = (cfg->flags & RT_FLAG_GROUP_DETECT) != 0;
     }
 
     auto fail = [&](int code, const std::string &msg) {
@@ -1635,6 +1667,8 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_large));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_group), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
+    RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_bucket_listed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_small));
     RT_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)rec_lds_bytes(kDenseLdsRecords)));
 #undef RT_CREATE_HIP
@@ -2122,7 +2156,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     // A stream wanted more records than the handle's per-stream capacity holds (word 4): the capacity grows and the call is
     // analysed again, like a call that outgrew the pool -- the reference has no limit (analyze.py:449-450).  Up to three times per
     // call (a re-run on a higher level may find more).  rt_extract cannot (the caller's spectrogram is not kept).
-    if ((flags & kFlagRecOverflow) && !c.is_extract && c.n_seg > 0 && sl.h_counters[4] > (unsigned long long)h->rec_cap && c.cap_grown < 3) {
+    // (Measured against the capacity the call's kernels RAN with: with two calls in flight the first one's growth may already cover what
+    // the second one wanted -- its lists were still cut at the old capacity.)
+    if ((flags & kFlagRecOverflow) && !c.is_extract && c.n_seg > 0 && sl.h_counters[4] > (unsigned long long)c.rec_cap_used && c.cap_grown < 3) {
         if (grow_record_capacity(h, sl.h_counters[4]) == RT_OK) {
             ++c.cap_grown;
             for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
@@ -2153,6 +2189,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
   }
     if (c.mode_used != RT_MODE_DENSE && !c.is_extract && c.n_seg > 0)
         for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
+    // one wave per stream in the next calls' sparse detection while a stream holds half of what such a wave takes on average (heavier
+    // batches -- BASELINE config 4: 1 500 cells per stream -- are faster with the per-list waves: most of their streams would be left to them anyway)
+    if (c.mode_used != RT_MODE_DENSE && !c.is_extract && c.n_seg > 0) h->group_light = h->info.n_hot * 2 <= (int64_t)kGroupCells * h->cfg.n_streams;
     // (the exact pre-filter on input where it is not selective: see below)
     bool unselective = h->cfg.mode == RT_MODE_AUTO && c.mode_used == RT_MODE_RUNFILTER && !c.is_extract && c.n_seg > 0 && sl.h_seg_total &&
                        (int64_t)*sl.h_seg_total * 2 > (int64_t)h->cfg.n_streams * c.n_seg;

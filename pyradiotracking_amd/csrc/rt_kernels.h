@@ -1962,6 +1962,8 @@ struct DetectArgs {
                                //     unless the stream overflowed (the scan stops emitting for such a stream, its other lists are torn)
     const int32_t *seg_total;  // null, or the device word holding the number of segments the exact pre-filter's planner listed over the batch ...
     int32_t *host_seg_total;   // ... and the pinned host word the call's last finalize_records workgroup copies it to (how selective the level was: AUTO)
+    int32_t *work_list;        // null, or (detect_group) [S * kQuarters] the (stream, quarter) pairs left to the per-bucket waves ...
+    int32_t *work_count;       // ... and their number (zeroed by finalize_records)
     int32_t filtered;          // the candidate lists come from the run-length pre-filter (stft_scan MODE 5): a run whose
                                //     preceding cell is missing lies across the edge of the emitted chunks, is too short
                                //     to pass the duration gate and is dropped (without the filter that is an internal error)
@@ -2158,6 +2160,46 @@ __device__ __forceinline__ RunStats run_stats_wave(int n, Cell cell) {
     return r;
 }
 
+// The same statistics for 64 / W plateaus at once, W = 32 or 16 lanes each (round 6: a wave that holds a whole stream's lists has a
+// dozen or two plateaus to finish, most of them under 32 cells).  A plateau of at most W cells folded over its W lanes IS the 64-lane
+// fold of rt::run_stats: the lanes above W hold the identity there (0.0 + x, max(x, -inf), x | 0), so the steps that would add them
+// are left out and every group of W lanes runs the remaining steps on its own plateau -- bit for bit run_stats_wave's results.
+// n, cell: the lane's own plateau (the same in the W lanes of a group; n = 0: none, the result is not used).
+template <int W, class Cell>
+__device__ __forceinline__ RunStats run_stats_lanes(int n, Cell cell) {
+    static_assert(W == 32 || W == 16, "half or quarter waves");
+    const int k = (int)(threadIdx.x & (W - 1));
+    const bool has = k < n;
+    const float v = has ? cell(k) : 0.f;
+    const float dbv = has ? db10(v) : 0.f;
+    double ps = has ? 0.0 + (double)v : 0.0, pd = has ? 0.0 + (double)dbv : 0.0;
+    float pm = (has && v > -INFINITY) ? v : -INFINITY;
+    int any_nan = (has && v != v) ? 1 : 0;
+    const auto add64 = [](double x, double y) { return x + y; };
+    const auto maxf = [](float x, float y) { return y > x ? y : x; };
+    const auto ori = [](int x, int y) { return x | y; };
+    if constexpr (W == 32) {
+        ps = butterfly_step<16>(ps, add64);
+        pd = butterfly_step<16>(pd, add64);
+        pm = butterfly_step<16>(pm, maxf);
+        any_nan = butterfly_step<16>(any_nan, ori);
+    }
+    ps = butterfly_step<1>(butterfly_step<2>(butterfly_step<4>(butterfly_step<8>(ps, add64), add64), add64), add64);
+    pd = butterfly_step<1>(butterfly_step<2>(butterfly_step<4>(butterfly_step<8>(pd, add64), add64), add64), add64);
+    pm = butterfly_step<1>(butterfly_step<2>(butterfly_step<4>(butterfly_step<8>(pm, maxf), maxf), maxf), maxf);
+    any_nan = butterfly_step<1>(butterfly_step<2>(butterfly_step<4>(butterfly_step<8>(any_nan, ori), ori), ori), ori);
+    const double mean_db = pd / (double)n;
+    const double d = (double)dbv - mean_db;
+    double pa = has ? 0.0 + d * d : 0.0;
+    if constexpr (W == 32) pa = butterfly_step<16>(pa, add64);
+    pa = butterfly_step<1>(butterfly_step<2>(butterfly_step<4>(butterfly_step<8>(pa, add64), add64), add64), add64);
+    RunStats r;
+    r.max_p = any_nan ? NAN : pm;
+    r.mean_p = (float)(ps / (double)n);
+    r.std_db = (float)sqrt(pa / (double)n);
+    return r;
+}
+
 // Last step of a call's last kernel (finalize_records / detect_dense), thread 0 of every workgroup:
 // the workgroup that takes the last ticket copies the counter words to pinned host memory and
 // leaves them zero for the slot's next call -- no reset launch before a call, no copy after it.
@@ -2235,6 +2277,7 @@ __device__ __forceinline__ int settled_count(const DetectArgs &a, RecLds &l) {
 // sparse detection: one WAVE per (stream, bucket), bucket = bin & (kBuckets-1)
 // ---------------------------------------------------------------------------
 constexpr int kSmallBucket = 1024;  // buckets up to this many cells use the small-LDS instantiation
+constexpr int kQuarters = 4;        // detect_group: a wave takes a stream's buckets all together or a quarter of them
 constexpr int kCandCapMax = 64;     // plateaus a bucket wave stages in LDS before it finishes them (a.cand_cap <= this); no limit per bucket
 
 // Bitonic sort of 64*M (key, value) pairs held in registers, element i = m*64 + lane.
@@ -2457,6 +2500,148 @@ __device__ __forceinline__ void sort_bucket_bitmap(const uint2 *src, int n, int 
     }
 }
 
+#ifndef RT_DETECT_ABLATE
+#define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort, 4 = no run statistics, 5 = no hand-over of the records, 6 = stop before the runs are gated, 7 = (detect_group) stop after the row means
+#endif
+// The second half of a bucket wave's work, on a list that lies in LDS in (bin, t) order (keys = bin << tbits | t, vals = the cells'
+// powers; avg_of(bin) = the bin's row mean): predicate -> maximal runs -> gates -> statistics -> raw records of stream s.
+// Shared by the wave of one bucket (detect_bucket_one) and the wave of a group of buckets (detect_group).
+template <class AvgOf>
+__device__ __forceinline__ void detect_runs(const DetectArgs &a, const DetectParams &dp, const int s, const int n, uint32_t *keys, const float *vals,
+                                            rt_record *cand, const int lane, AvgOf avg_of) {
+    const int F = a.n_bins;
+    const int T = a.dp.n_seg;
+    const uint32_t tmask = (1u << a.tbits) - 1u;
+    // the predicate (analyze.py:370, 378) is evaluated where it is needed: one float division
+    auto is_above = [&](int i) -> bool {
+        const int bin = (int)(keys[i] >> a.tbits);
+        return cell_above(vals[i], avg_of(bin), dp.thr, dp.snr);
+    };
+
+    // Statistics of the staged plateaus (the whole wave per plateau, canonical order of rt::run_stats), then
+    // hand them to the stream's unordered list (finalize_records orders and filters).  Called whenever the
+    // staging area is full and once at the end: a bucket may hold any number of plateaus (dense tag trains at
+    // nperseg 4096 put hundreds into one), only the stream's record_capacity limits them.
+    auto drain = [&](int ncand) {
+        wave_sync();
+        for (int c = 0; c < ncand;) {
+            // the next plateaus four at a time on quarter waves (all of them <= 16 cells), two on half waves (<= 32), or one on the wave
+            const int left = ncand - c;
+            const auto len_of = [&](int j) -> int { return __builtin_amdgcn_readfirstlane(cand[c + j].end - cand[c + j].start); };
+            int per = 1;
+            if (left >= 2) {
+                const int l01 = max(len_of(0), len_of(1));
+                if (l01 <= 32) per = 2;
+                if (left >= 4 && l01 <= 16 && max(len_of(2), len_of(3)) <= 16) per = 4;
+            }
+            const int W = 64 / per;
+            const int g = lane / W;  // the lane's plateau of this pass
+            const int cm = c + g;
+            const int start = cand[cm].start, off = cand[cm].reserved, fi = cand[cm].fi, end = cand[cm].end;
+            PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
+            auto cell = [&](int k) -> float {
+                const int t = start + k;
+                return t < 0 ? prev(-t) : vals[off + t];
+            };
+            const RunStats st = (RT_DETECT_ABLATE == 4) ? RunStats{cell(0), cell(1), 0.f}
+                                : per == 4          ? run_stats_lanes<16>(end - start, cell)
+                                : per == 2          ? run_stats_lanes<32>(end - start, cell)
+                                                    : run_stats_wave(end - start, cell);
+            if ((lane & (W - 1)) == 0) {
+                cand[cm].max_p = st.max_p;
+                cand[cm].mean_p = st.mean_p;
+                cand[cm].std_db = st.std_db;
+                cand[cm].reserved = 0;
+            }
+            c += per;
+        }
+        wave_sync();
+        if (RT_DETECT_ABLATE == 5) return;
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&a.raw_count[s], ncand);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        for (int c = lane; c < ncand; c += 64) {
+            if (slot + c < a.rec_cap)
+                a.raw[(int64_t)s * a.rec_cap + slot + c] = cand[c];
+            else
+                atomicOr(&a.counters[2], kFlagRecOverflow);
+        }
+        wave_sync();  // the staging area is free again
+    };
+
+    // maximal runs of above-cells: a run's last cell learns the index of its first cell from
+    // an inclusive prefix-max over "index if run start else -1" (64 cells per step + carry)
+    int ncand = 0;       // wave-uniform
+    int carry = -1;      // wave-uniform: last run start seen in earlier steps
+    for (int base_i = 0; base_i < n; base_i += 64) {
+        const int i = base_i + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys[i] : 0u;
+        const int t = (int)(key & tmask);
+        const bool ab = valid && is_above(i);
+        const bool prev_adj = ab && i > 0 && t > 0 && keys[i - 1] == key - 1 && is_above(i - 1);
+        const bool next_adj = ab && (i + 1 < n) && (t + 1 < T) && keys[i + 1] == key + 1 && is_above(i + 1);
+        const bool is_start = ab && !prev_adj;
+        const bool is_end = ab && !next_adj;
+        int first = wave_scan_inclusive(is_start ? i : -1, -1, [](int x, int y) { return x > y ? x : y; });
+        first = first > carry ? first : carry;
+        carry = __builtin_amdgcn_readlane(first, 63);
+
+        bool keep = false;
+        int fi = 0, b = 0, e = 0, start = 0;
+        float av = 0.f;
+        if (RT_DETECT_ABLATE == 6) { if (__builtin_amdgcn_ballot_w64(is_end) == 12345ull) keys[0] = 1u; continue; }
+        if (is_end) {
+            const uint32_t key0 = keys[first];
+            fi = (int)(key >> a.tbits);
+            b = (int)(key0 & tmask);
+            e = t + 1;
+            if (b > 0 && (first == 0 || keys[first - 1] != key0 - 1)) {
+                // the cell before a run must have been emitted by the scan (T11)
+                if (!a.filtered) {
+                    atomicOr(&a.counters[2], kFlagInconsistent);
+                    if (a.stream_incons) a.stream_incons[s] = 1;
+                }
+            } else {
+                av = avg_of(fi);
+                PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
+                keep = gate_run(dp, b, e, av, prev, &start);
+            }
+        }
+        // stage the gated plateaus; when the staging area runs full, the staged ones are finished first
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
+        while (todo) {
+            if (ncand == a.cand_cap) {
+                drain(ncand);
+                ncand = 0;
+            }
+            const int room = a.cand_cap - ncand;
+            const bool mine = keep && ((todo >> lane) & 1ull);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0));
+            const bool now = mine && rank < room;
+            if (now) {
+                rt_record r;
+                r.stream = s;
+                r.fi = fi;
+                r.start = start;
+                r.end = e;
+                r.max_p = 0.f;
+                r.mean_p = 0.f;
+                r.std_db = 0.f;
+                r.row_mean = av;
+                r.shadowed = 0;
+                r.reserved = first - b;  // cell t of this bin sits at vals[reserved + t]
+                cand[ncand + rank] = r;
+            }
+            const unsigned long long done = __builtin_amdgcn_ballot_w64(now);
+            ncand += __builtin_popcountll(done);
+            todo &= ~done;
+        }
+    }
+    if (ncand) drain(ncand);
+}
+
+
 // All cells of a bin live in one bucket, so a wave can finish its bins alone:
 // row means -> sort by (bin, t) -> predicate -> maximal runs (paired by a
 // prefix-max scan, no sequential walks) -> gates -> statistics -> raw records.
@@ -2498,9 +2683,6 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
     const DetectParams dp = stream_params(a, s);
 
     // row means of the bucket's bins: np.mean(row) (analyze.py:375) from the scan's partial sums
-#ifndef RT_DETECT_ABLATE
-#define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort, 4 = no run statistics, 5 = no hand-over of the records, 6 = stop before the runs are gated
-#endif
     // Where a bucket holds many bins (nperseg >= 512: 32 ... 256 of them, each a sum over the stream's partial rows -- 11 at BASELINE
     // config 5, 19 at config 3) only the bins that OCCUR in the list get their mean, after the sort below (a dozen of 256 at config 5,
     // where the full table was four dependent rounds of loads per lane: detect_bucket 310 -> 228 us on the config-5 share, 345 -> 305
@@ -2586,117 +2768,7 @@ __device__ __forceinline__ void detect_bucket_one(const DetectArgs &a, const int
         if (wave != 0) return;  // no block-wide barrier below this point
     }
 
-    // the predicate (analyze.py:370, 378) is evaluated where it is needed: one float division
-    auto is_above = [&](int i) -> bool {
-        const int bin = (int)(keys[i] >> a.tbits);
-        return cell_above(vals[i], avg[bin / kBuckets], dp.thr, dp.snr);
-    };
-
-    // Statistics of the staged plateaus (the whole wave per plateau, canonical order of rt::run_stats), then
-    // hand them to the stream's unordered list (finalize_records orders and filters).  Called whenever the
-    // staging area is full and once at the end: a bucket may hold any number of plateaus (dense tag trains at
-    // nperseg 4096 put hundreds into one), only the stream's record_capacity limits them.
-    auto drain = [&](int ncand) {
-        wave_sync();
-        for (int c = 0; c < ncand; ++c) {
-            const int start = cand[c].start, off = cand[c].reserved, fi = cand[c].fi, end = cand[c].end;
-            PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
-            auto cell = [&](int k) -> float {
-                const int t = start + k;
-                return t < 0 ? prev(-t) : vals[off + t];
-            };
-            const RunStats st = (RT_DETECT_ABLATE == 4) ? RunStats{cell(0), cell(1), 0.f} : run_stats_wave(end - start, cell);
-            if (lane == 0) {
-                cand[c].max_p = st.max_p;
-                cand[c].mean_p = st.mean_p;
-                cand[c].std_db = st.std_db;
-                cand[c].reserved = 0;
-            }
-        }
-        wave_sync();
-        if (RT_DETECT_ABLATE == 5) return;
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&a.raw_count[s], ncand);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        for (int c = lane; c < ncand; c += 64) {
-            if (slot + c < a.rec_cap)
-                a.raw[(int64_t)s * a.rec_cap + slot + c] = cand[c];
-            else
-                atomicOr(&a.counters[2], kFlagRecOverflow);
-        }
-        wave_sync();  // the staging area is free again
-    };
-
-    // maximal runs of above-cells: a run's last cell learns the index of its first cell from
-    // an inclusive prefix-max over "index if run start else -1" (64 cells per step + carry)
-    int ncand = 0;       // wave-uniform
-    int carry = -1;      // wave-uniform: last run start seen in earlier steps
-    for (int base_i = 0; base_i < n; base_i += 64) {
-        const int i = base_i + lane;
-        const bool valid = i < n;
-        const uint32_t key = valid ? keys[i] : 0u;
-        const int t = (int)(key & tmask);
-        const bool ab = valid && is_above(i);
-        const bool prev_adj = ab && i > 0 && t > 0 && keys[i - 1] == key - 1 && is_above(i - 1);
-        const bool next_adj = ab && (i + 1 < n) && (t + 1 < T) && keys[i + 1] == key + 1 && is_above(i + 1);
-        const bool is_start = ab && !prev_adj;
-        const bool is_end = ab && !next_adj;
-        int first = wave_scan_inclusive(is_start ? i : -1, -1, [](int x, int y) { return x > y ? x : y; });
-        first = first > carry ? first : carry;
-        carry = __builtin_amdgcn_readlane(first, 63);
-
-        bool keep = false;
-        int fi = 0, b = 0, e = 0, start = 0;
-        float av = 0.f;
-        if (RT_DETECT_ABLATE == 6) { if (__builtin_amdgcn_ballot_w64(is_end) == 12345ull) keys[0] = 1u; continue; }
-        if (is_end) {
-            const uint32_t key0 = keys[first];
-            fi = (int)(key >> a.tbits);
-            b = (int)(key0 & tmask);
-            e = t + 1;
-            if (b > 0 && (first == 0 || keys[first - 1] != key0 - 1)) {
-                // the cell before a run must have been emitted by the scan (T11)
-                if (!a.filtered) {
-                    atomicOr(&a.counters[2], kFlagInconsistent);
-                    if (a.stream_incons) a.stream_incons[s] = 1;
-                }
-            } else {
-                av = avg[fi / kBuckets];
-                PrevCells prev{a.prev + ((int64_t)s * a.prev_cols + a.prev_cols) * F + fi, F};
-                keep = gate_run(dp, b, e, av, prev, &start);
-            }
-        }
-        // stage the gated plateaus; when the staging area runs full, the staged ones are finished first
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
-        while (todo) {
-            if (ncand == a.cand_cap) {
-                drain(ncand);
-                ncand = 0;
-            }
-            const int room = a.cand_cap - ncand;
-            const bool mine = keep && ((todo >> lane) & 1ull);
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0));
-            const bool now = mine && rank < room;
-            if (now) {
-                rt_record r;
-                r.stream = s;
-                r.fi = fi;
-                r.start = start;
-                r.end = e;
-                r.max_p = 0.f;
-                r.mean_p = 0.f;
-                r.std_db = 0.f;
-                r.row_mean = av;
-                r.shadowed = 0;
-                r.reserved = first - b;  // cell t of this bin sits at vals[reserved + t]
-                cand[ncand + rank] = r;
-            }
-            const unsigned long long done = __builtin_amdgcn_ballot_w64(now);
-            ncand += __builtin_popcountll(done);
-            todo &= ~done;
-        }
-    }
-    if (ncand) drain(ncand);
+    detect_runs(a, dp, s, n, keys, vals, cand, lane, [&](int bin) -> float { return avg[bin / kBuckets]; });
 }
 
 template <bool LARGE>
@@ -2719,6 +2791,154 @@ __global__ __launch_bounds__(256) void detect_bucket(const DetectArgs a) {
             detect_bucket_one<true>(a, (int)blockIdx.x * kBuckets + b, wave, lane, dyn_smem);
             __syncthreads();  // the next bucket reuses the workgroup's LDS
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sparse detection of a WHOLE STREAM by one wave (round 6).  With thousands of streams per launch and a few hundred candidate cells
+// per stream -- the reference's defaults -- a launch of one wave per (stream, list) is tens of thousands of waves of a dozen or two
+// cells each, every one paying the same chain of dependent round trips (counter -> list -> row sums -> record slot), sixteen rounds
+// of them per launch.  Here a wave takes all sixteen lists of its stream where they hold <= kGroupCells cells together: gathered
+// in ONE round trip (a cell's list found from the prefix of the counters), sorted together by (bin, t) -- the key carries the whole
+// bin -- and handed to the same detect_runs, which finishes the stream's plateaus two or four at a time.  Streams that hold more go
+// to a work list and to the per-list waves behind this launch (detect_bucket_listed), which also own the large lists and the overflow
+// flags: a stream that fits has neither.  Same records as the per-list form (the order of a stream's unordered list differs;
+// finalize_records orders it).  The host launches this form while the batch's streams are light on average (rt_analyze.hip).
+// (Measured and dropped: quarters of a stream's lists per wave for heavier streams -- BASELINE config 4, 1 500 cells per stream:
+// 3.76 against 3.16 ms of detection per step; profiles/r06_k_*.)
+// LDS of a wave, inside the small-bucket wave's 8 KiB: keys[kGroupCells] | vals[kGroupCells] | row means of up to 256 bins.
+// ---------------------------------------------------------------------------
+constexpr int kGroupCells = 896;
+constexpr int kGroupBins = 256;  // (kSmallBucket - kGroupCells) * 8 / 4
+
+// gather + sort: cell i of the group (i = m*64 + lane) is cell i - start(b) of bucket b, b = the number of buckets whose inclusive
+// prefix `ends[.]` is <= i; one word per cell ((bin, t) above the cell's position, as in sort_bucket_packed), the powers parked in LDS
+template <int M>
+__device__ __forceinline__ void sort_group_packed(const uint2 *hot_s, const int hot_cap, const uint32_t (&ends)[kBuckets], const int n, const int lane,
+                                                  uint32_t *keys, float *vals) {
+    constexpr int kIdxBits = 10;
+    uint32_t k[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const uint32_t i = (uint32_t)(m * 64 + lane);
+        uint32_t b = 0u, st = 0u;
+#pragma unroll
+        for (int j = 0; j < kBuckets; ++j) {
+            const bool ge = i >= ends[j];
+            b += ge ? 1u : 0u;
+            st = ge ? ends[j] : st;
+        }
+        uint32_t word = 0xFFFFFFFFu;
+        if (i < (uint32_t)n) {
+            const uint2 e = hot_s[(int64_t)b * hot_cap + (i - st)];
+            word = (e.x << kIdxBits) | i;
+            keys[i] = e.y;  // the power, parked until the order is known
+        }
+        k[m] = word;
+    }
+    wave_sync();
+    wave_bitonic_sort_u32<M>(k, lane);
+    float v[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) v[m] = (m * 64 + lane < n) ? __uint_as_float(keys[k[m] & ((1u << kIdxBits) - 1u)]) : 0.f;
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int i = m * 64 + lane;
+        if (i < n) {  // (nothing beyond n is read below; the areas behind kGroupCells belong to the row means)
+            keys[i] = k[m] >> kIdxBits;
+            vals[i] = v[m];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void detect_group(const DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int s = (int)blockIdx.x * 4 + wave;
+    if (s >= a.n_streams) return;
+    constexpr int QB = kBuckets / kQuarters;
+    const uint32_t cnt = lane < kBuckets ? a.hot_count[s * kBuckets + lane] : 0u;
+    uint32_t tot_all = 0u;
+    bool over_all = false;  // a list that overflowed (its counter says more than the list holds) is not read here
+#pragma unroll
+    for (int b = 0; b < kBuckets; ++b) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
+        tot_all += c;
+        over_all |= c > (uint32_t)a.hot_cap;
+    }
+    const bool whole = tot_all <= (uint32_t)kGroupCells && !over_all;
+    if (!whole) {
+        // (this stream's lists one by one, behind this launch: detect_bucket_listed; large lists and overflowed ones are in here)
+        if (lane < kQuarters) {
+            const int slot = atomicAdd(a.work_count, 1);
+            a.work_list[slot] = s * kQuarters + lane;
+        }
+        return;
+    }
+    (void)QB;
+    const int n = (int)tot_all;
+    if (n == 0) return;
+    // inclusive prefix of the group's counters (buckets outside the group count as empty): scalars
+    uint32_t ends[kBuckets];
+    {
+        uint32_t run = 0u;
+#pragma unroll
+        for (int b = 0; b < kBuckets; ++b) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, b);
+            run += c;
+            ends[b] = run;
+        }
+    }
+    const int F = a.n_bins;
+    const int T = a.dp.n_seg;
+    const int nbins_b = F / kBuckets;
+    const size_t wave_bytes = (size_t)kSmallBucket * 8 + (((size_t)nbins_b * 4 + 15) & ~(size_t)15) + sizeof(rt_record) * a.cand_cap;  // = detect_bucket<false>'s
+    unsigned char *base = dyn_smem + (size_t)wave * wave_bytes;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(base);
+    float *vals = reinterpret_cast<float *>(keys + kGroupCells);
+    float *avg = vals + kGroupCells;  // [F], F <= kGroupBins
+    rt_record *cand = reinterpret_cast<rt_record *>(base + (size_t)kSmallBucket * 8 + (((size_t)nbins_b * 4 + 15) & ~(size_t)15));
+    const DetectParams dp = stream_params(a, s);
+    const uint2 *hot_s = a.hot + (int64_t)s * kBuckets * a.hot_cap;
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    switch (n2) {
+        case 64: sort_group_packed<1>(hot_s, a.hot_cap, ends, n, lane, keys, vals); break;
+        case 128: sort_group_packed<2>(hot_s, a.hot_cap, ends, n, lane, keys, vals); break;
+        case 256: sort_group_packed<4>(hot_s, a.hot_cap, ends, n, lane, keys, vals); break;
+        case 512: sort_group_packed<8>(hot_s, a.hot_cap, ends, n, lane, keys, vals); break;
+        default: sort_group_packed<16>(hot_s, a.hot_cap, ends, n, lane, keys, vals); break;
+    }
+    wave_sync();
+    if (RT_DETECT_ABLATE == 3) return;
+    // row means of the bins that occur: the first cell of every bin computes its bin's (the list is in (bin, t) order)
+    for (int base_i = 0; base_i < n; base_i += 64) {
+        const int i = base_i + lane;
+        if (i < n) {
+            const int bin = (int)(keys[i] >> a.tbits);
+            if (i == 0 || (int)(keys[i - 1] >> a.tbits) != bin)
+                avg[bin] = (float)row_sum_from_partials(a.psum + (int64_t)s * a.chunks * F + bin, a.chunks, F) / (float)T;
+        }
+    }
+    wave_sync();
+    if (RT_DETECT_ABLATE == 7) return;
+    detect_runs(a, dp, s, n, keys, vals, cand, lane, [&](int bin) -> float { return avg[bin]; });
+}
+
+// Behind detect_group: the per-bucket waves for the quarters it left (their four buckets to the four waves of a workgroup), a grid
+// that loops over the work list -- empty as a rule.  (A kernel of its own: the loop around the inlined bucket wave costs registers
+// -- 137 against 98 -- and with them the fourth wave per SIMD of detect_bucket<false>.)
+__global__ __launch_bounds__(256) void detect_bucket_listed(const DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int n_work = __builtin_amdgcn_readfirstlane(*a.work_count);
+    for (int w = (int)blockIdx.x; w < n_work; w += (int)gridDim.x) {
+        const int e = __builtin_amdgcn_readfirstlane(a.work_list[w]);
+        detect_bucket_one<false>(a, (e / kQuarters) * kBuckets + (e % kQuarters) * (kBuckets / kQuarters) + wave, wave, lane, dyn_smem);
+        wave_sync();  // the next bucket reuses the wave's LDS
     }
 }
 
@@ -2760,6 +2980,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
             }
             a.hot_total[s] = (int32_t)tot;
             a.large_any[s] = 0u;
+            if (a.work_count && blockIdx.x == 0) *a.work_count = 0;  // (detect_group's work list: empty for the slot's next call)
         }
         const unsigned long long v = atomicAdd(&a.counters[0], (unsigned long long)n | (1ull << kTicketShift));
         const unsigned long long mask = (1ull << kTicketShift) - 1ull;

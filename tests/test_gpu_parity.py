@@ -163,16 +163,21 @@ def test_spectrogram_into_a_map_that_is_only_float_aligned():
 # pre-filter take its place there -- the reference's own output is the yardstick on every level)
 # (nperseg 300 -- n300_short -- runs Bluestein's transform, which lives on the dense path: AUTO goes there by itself; nperseg 128 and
 # 8192 -- n128_short, n8192_short -- are fused scans since round 6: sparse, AUTO (which stays sparse on this clean input) and dense)
+# ("sparse+groups" / "runfilter+groups": the detection by groups of candidate lists -- detect_group, the default from 1 024 streams per
+# handle on -- forced on these single streams, where the fused kernels allow it: nperseg <= 256)
 _IQ_CASE_MODES = [(n, m) for n in gu.iq_case_names()
-                  for m in (("auto", "runfilter", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith("n300")
-                            else ("sparse", "auto", "dense") if n.startswith(("n128", "n8192")) else ("sparse", "dense"))]
+                  for m in (("auto", "runfilter", "runfilter+groups", "dense") if n.startswith("floor_") else ("auto", "dense") if n.startswith("n300")
+                            else ("sparse", "sparse+groups", "auto", "dense") if n.startswith("n128") else ("sparse", "auto", "dense") if n.startswith("n8192")
+                            else ("sparse", "sparse+groups", "dense"))]
 
 
 @pytest.mark.parametrize("name,mode", _IQ_CASE_MODES)
 def test_golden_iq_case(name, mode):
     _need_gpu()
     meta, kwargs, buffers, ts_starts, expected = gu.iq_case(name)
-    an = SignalAnalyzer("0", sdr_callback_length=meta["buffer_len"], mode=mode, **kwargs)
+    grouped = mode.endswith("+groups")
+    mode = mode.split("+")[0]
+    an = SignalAnalyzer("0", sdr_callback_length=meta["buffer_len"], mode=mode, **({"group_detect": True} if grouped else {}), **kwargs)
     oa = oracle.OracleAnalyzer(device="0", **kwargs)
     for b, (buf, ts, exp) in enumerate(zip(buffers, ts_starts, expected)):
         an._batch.enqueue(buf.reshape(1, -1))
@@ -1128,6 +1133,103 @@ def test_record_capacity_grows_with_the_stream_that_needs_it(mode, lanes):
     b.enqueue(many)
     assert b.fetch_records().tobytes() == want[3].tobytes()
     assert not b.native.last_truncated
+    # two calls in flight that BOTH outgrow the capacity: the first one's growth already covers what the second wanted, whose lists
+    # were still cut at the old capacity when its kernels ran (round 6's soak, seed 63 case 26: delivered truncated) -- analysed again too
+    ref2 = _batch_for(kw, 3, blen, mode)
+    want2 = []
+    for x in (many, many):
+        ref2.enqueue(x)
+        want2.append(ref2.fetch_records())
+    b2 = _batch_for(kw, 3, blen, mode, record_capacity=cap, lanes=lanes)
+    b2.enqueue(many)
+    b2.enqueue(many)
+    for k in range(2):
+        assert b2.fetch_records().tobytes() == want2[k].tobytes(), k
+        assert not b2.native.last_truncated
+
+
+@pytest.mark.parametrize("nperseg,mode,lanes", [(256, "sparse", 1), (256, "auto", 2), (128, "sparse", 1), (64, "sparse", 2), (256, "runfilter", 1), (32, "sparse", 1)])
+def test_detection_by_groups_of_lists_equals_the_per_list_waves(nperseg, mode, lanes):
+    """detect_group (the default for light batches of 1 024 streams and more; forced here): a wave takes all sixteen candidate lists of
+    a stream where they hold <= 896 cells together and finishes the stream's plateaus two or four at a time; heavier streams, large
+    lists and overflowed ones are left to the per-list waves behind it.  Streams of every kind in one batch -- silent, a few pulses
+    (whole stream), two dozen, long tones (left to the per-list waves), one tone over the whole buffer (a list of more than 1 024
+    cells: the large instantiation) -- two buffers with look-back: byte-identical to the per-list form and equal to the oracle."""
+    _need_gpu()
+    fs = 2048000
+    n_seg = 1300
+    blen = n_seg * nperseg
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(nperseg)
+    hop_ms = nperseg / fs * 1e3
+    kw = dict(sample_rate=fs, fft_nperseg=nperseg, signal_min_duration_ms=4 * hop_ms, signal_max_duration_ms=2000.0)
+    amp = synth.amp_for_peak_dbw(-62.0, w, fs)
+
+    def tone(bin_, seg0, segs):
+        return synth.Pulse(seg0 * nperseg + nperseg // 3, segs * nperseg, bin_ * fs / nperseg, amp)
+
+    def stream(k, pulses, seed):
+        return synth.make_stream(synth.StreamSpec(2 * blen, fs, pulses), seed)
+
+    few = synth.random_pulses(rng, 2 * blen, fs, w, 3, dur_ms=(6 * hop_ms, 20 * hop_ms))
+    dozen = synth.random_pulses(rng, 2 * blen, fs, w, 24, dur_ms=(10 * hop_ms, 40 * hop_ms))
+    q = nperseg // 16 if nperseg >= 64 else 1
+    heavy = [tone(1 + 16 * j, 40 + 5 * j, 330) for j in range(min(3, max(1, q - 1)))] + [tone(1, n_seg + 100, 330), tone(17 % nperseg, n_seg + 90, 330)]
+    long_one = [tone(5, 20, 2 * n_seg - 60)] + synth.random_pulses(rng, 2 * blen, fs, w, 4, dur_ms=(6 * hop_ms, 20 * hop_ms))
+    across = [synth.Pulse(blen - 9 * nperseg, 21 * nperseg, 0.2 * fs, amp)]  # look-back into the first buffer
+    iq = np.stack([stream(0, [], 1), stream(1, few, 2), stream(2, dozen, 3), stream(3, heavy, 4), stream(4, long_one, 5), stream(5, few[:1] + across, 6)])
+    S = len(iq)
+    plain = _batch_for(kw, S, blen, mode, lanes=lanes, group_detect=False)
+    groups = _batch_for(kw, S, blen, mode, lanes=lanes, group_detect=True)
+    oas = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(S)]
+    for k in range(2):
+        x = np.ascontiguousarray(iq[:, k * blen:(k + 1) * blen])
+        for b in (plain, groups):
+            b.enqueue(x)
+        rec_p, rec_g = plain.fetch_records(), groups.fetch_records()
+        assert len(rec_g) > 30 and rec_g.tobytes() == rec_p.tobytes(), f"buffer {k}"
+        for s in range(S):
+            want, _ = oas[s].process(x[s], gu.TS0)
+            mine = rec_g[rec_g["stream"] == s]
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(v.fi, v.start, v.end) for v in want], f"buffer {k} stream {s}"
+    assert int((rec_g["start"] < 0).sum()) >= 1  # the run across the boundary was found with its look-back part
+
+
+def test_whole_stream_detection_follows_the_load_of_the_batch():
+    """The library's own rule: from 1 024 streams per handle on a wave takes a whole stream's candidate lists WHILE the batch is
+    light (the streams of the call fetched last held <= 448 cells on average), the per-list waves otherwise.  A batch of 1 024
+    streams at the reference's defaults whose load goes light -> heavy -> heavy -> light, two calls in flight: every buffer
+    byte-identical to a handle that never groups, sampled streams equal to the oracle."""
+    import torch
+
+    _need_gpu()
+    fs, nperseg, blen, S = 300000, 256, 150000, 1024
+    w = oracle.window_coefficients("hamming", nperseg)
+    kw = dict(sample_rate=fs)
+    bufs = [synth.make_batch_device(S, blen, fs, w, pulses_per_stream=pp, seed=90 + k) for k, pp in enumerate([(1, 3), (40, 60), (40, 60), (1, 3)])]
+    auto = _batch_for(kw, S, blen, "sparse")                       # (S >= 1 024: the rule applies)
+    never = _batch_for(kw, S, blen, "sparse", group_detect=False)
+    sampled = (0, 511, S - 1)
+    oas = {s: oracle.OracleAnalyzer(device=str(s), **kw) for s in sampled}
+    got = {id(auto): [], id(never): []}
+    for b in (auto, never):
+        b.enqueue(bufs[0])
+        for k in range(1, len(bufs)):
+            b.enqueue(bufs[k])  # two calls in flight
+            got[id(b)].append(b.fetch_records())
+        got[id(b)].append(b.fetch_records())
+    for k, iq in enumerate(bufs):
+        rec_a, rec_n = got[id(auto)][k], got[id(never)][k]
+        assert len(rec_a) > S // 2 and rec_a.tobytes() == rec_n.tobytes(), f"buffer {k}"
+        for s in sampled:
+            want, _ = oas[s].process(iq[s].cpu().numpy(), gu.TS0)
+            mine = rec_a[rec_a["stream"] == s]
+            assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(v.fi, v.start, v.end) for v in want], f"buffer {k} stream {s}"
+    # the load really crossed the rule's line both ways (records per stream as a stand-in for the cells)
+    n_rec = [len(r) / S for r in got[id(auto)]]
+    assert n_rec[0] < 12 and n_rec[1] > 30 and n_rec[2] > 30 and n_rec[3] < 12, n_rec
+    del bufs
+    torch.cuda.empty_cache()
 
 
 def test_thousands_of_plateaus_in_one_stream_equal_the_oracle():
