@@ -2501,7 +2501,7 @@ __device__ __forceinline__ void sort_bucket_bitmap(const uint2 *src, int n, int 
 }
 
 #ifndef RT_DETECT_ABLATE
-#define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort, 4 = no run statistics, 5 = no hand-over of the records, 6 = stop before the runs are gated, 7 = (detect_group) stop after the row means
+#define RT_DETECT_ABLATE 0  // diagnostic builds only: 1 = no row means, 2 = no sort, 3 = stop after the sort, 4 = no run statistics, 5 = no hand-over of the records, 6 = stop before the runs are gated, 7 = (detect_group) stop after the row means, 8 = (finalize_records) no per-stream words to host memory, 9 = (finalize_records) records to device memory instead of the host pool
 #endif
 // The second half of a bucket wave's work, on a list that lies in LDS in (bin, t) order (keys = bin << tbits | t, vals = the cells'
 // powers; avg_of(bin) = the bin's row mean): predicate -> maximal runs -> gates -> statistics -> raw records of stream s.
@@ -2959,6 +2959,19 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
     const int s = a.stream_list ? a.stream_list[blockIdx.x] : (int)blockIdx.x;  // (a list: the dense re-run of a few streams, detect_dense<true>)
     const int tid = threadIdx.x;
     int n = a.raw_count[s];
+    // last reader of the stream's sixteen candidate counters: their sum for the statistics, then zero for the slot's next call --
+    // sixteen lanes, one round trip (round 6: a loop in thread 0 was sixteen DEPENDENT round trips, the counters being read and
+    // written through the same array: 62 us per 4 096 streams before the first record was touched)
+    uint32_t hot_sum = 0u;
+    if (!a.stream_list && tid < 64) {
+        uint32_t c = 0u;
+        if (tid < kBuckets) {
+            c = a.hot_count[s * kBuckets + tid];
+            if (c) a.hot_count_rw[s * kBuckets + tid] = 0u;
+        }
+        const auto addu = [](uint32_t x, uint32_t y) { return x + y; };
+        hot_sum = butterfly_step<1>(butterfly_step<2>(butterfly_step<4>(butterfly_step<8>(c, addu), addu), addu), addu);  // (the row of sixteen lanes)
+    }
     const int wanted = n;
     if (n > a.rec_cap) n = a.rec_cap;  // overflow already flagged by the producer
     if (n < 0) n = 0;
@@ -2971,14 +2984,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
             atomicMax(&a.counters[4], (unsigned long long)wanted);
         }
         if (!a.stream_list) {
-            // last reader of the stream's candidate counters: their sum for the statistics, then zero for the slot's next call
-            uint32_t tot = 0;
-            for (int b = 0; b < kBuckets; ++b) {
-                const uint32_t c = a.hot_count[s * kBuckets + b];
-                tot += c;
-                if (c) a.hot_count_rw[s * kBuckets + b] = 0u;
-            }
-            a.hot_total[s] = (int32_t)tot;
+            if (RT_DETECT_ABLATE != 8) a.hot_total[s] = (int32_t)hot_sum;
             a.large_any[s] = 0u;
             if (a.work_count && blockIdx.x == 0) *a.work_count = 0;  // (detect_group's work list: empty for the slot's next call)
         }
@@ -2991,8 +2997,10 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
         fit = fit < 0 ? 0 : (fit > n ? n : fit);
         sh_base = fit > 0 ? base : -1;
         sh_fit = (int)fit;
-        a.rec_offset[s] = fit > 0 ? (int)base : 0;
-        a.rec_count[s] = (int)fit;
+        if (RT_DETECT_ABLATE != 8) {
+            a.rec_offset[s] = fit > 0 ? (int)base : 0;
+            a.rec_count[s] = (int)fit;
+        }
         if ((v >> kTicketShift) + 1ull == (unsigned long long)gridDim.x) {
             // every workgroup has added its records: publish the counter words, leave them zero for the slot's next call
             const unsigned long long total = __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask;
@@ -3052,7 +3060,7 @@ __global__ __launch_bounds__(256) void finalize_records(const DetectArgs a) {
         if (i < n) {
             mine.shadowed = shadow;
             mine.reserved = 0;
-            if (rank < n_fit) a.records[base + rank] = mine;
+            if (rank < n_fit) (RT_DETECT_ABLATE == 9 ? a.raw[(int64_t)s * a.rec_cap + rank] : a.records[base + rank]) = mine;
         }
     }
 }
