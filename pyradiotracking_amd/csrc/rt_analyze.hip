@@ -35,6 +35,15 @@ using namespace rt;
 namespace {
 
 thread_local std::string g_create_error;
+// (diagnostic builds: RT_TRACE_FETCH=1 prints every decision of fetch_one's re-run loop)
+#define RT_TRACE_FETCH(h, sl, what)                                                                                                          \
+    do {                                                                                                                                     \
+        if (RT_DIAG_ENV("RT_TRACE_FETCH"))                                                                                                   \
+            std::fprintf(stderr, "fetch seq %llu mode %d: %s | flags %llx records %llu wanted/stream %llu rec_cap %d (ran with %d) pool %lld grown %d/%d\n", \
+                         (unsigned long long)(sl).call.seq, (sl).call.mode_used, what, (unsigned long long)(sl).h_counters[2],                \
+                         (unsigned long long)(sl).h_counters[0], (unsigned long long)(sl).h_counters[4], (h)->rec_cap, (sl).call.rec_cap_used, \
+                         (long long)(sl).pool_cap, (sl).call.cap_grown, (int)(sl).call.pool_grown);                                          \
+    } while (0)
 constexpr uint32_t kFlagLaneOfLargeBatch = 0x40000000u;  // rt_config.flags of a lane's own handle (internal): the whole batch has >= 1 024 streams
 thread_local bool g_creating_lane = false;  // rt_create of a laned handle is creating one of its lanes
 
@@ -60,7 +69,7 @@ struct CallCtx {
     bool u8 = false;        // IQ is interleaved uint8 (RTL-SDR wire format)
     bool no_last = false;   // the slot's h_no_last flags apply (some stream was reset, rt_reset_stream)
     int n_dense_streams = 0;  // streams of this call that were re-run dense on their own (AUTO, partial fall-back)
-    bool pool_grown = false;  // the record pool was enlarged for this call and the call analysed again (fetch_one)
+    int pool_grown = 0;       // times the record pool was enlarged for this call and the call analysed again (fetch_one)
     int cap_grown = 0;        // times the handle's per-stream record capacity was enlarged for this call (fetch_one: grow_record_capacity)
     int rec_cap_used = 0;     // the per-stream record capacity its kernels ran with (a call in flight while ANOTHER call grew the capacity was still truncated at the old one)
     bool thr_rerun = false;   // analysed again on RT_MODE_RUNFILTER with thresholds from its own row means (once per call)
@@ -2070,7 +2079,9 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         }
     }
   for (;;) {  // (a second round only after the record pool had to grow)
+    RT_TRACE_FETCH(h, sl, "round");
     while ((flags & kFlagHotOverflow) && !c.is_extract && c.mode_used != RT_MODE_DENSE) {
+        RT_TRACE_FETCH(h, sl, "hot overflow");
         // which streams overflowed?  (the flags are consumed here, whatever happens next)  The scan stops emitting for a
         // stream once one of its lists has overflowed, so a "run without its preceding cell" in such a stream is not an
         // internal error; in any other stream it is.
@@ -2114,12 +2125,16 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
             // than the fixed ~1 ms of a dense re-run of a few streams -- one workgroup per stream in detect_dense)
             if (few) {
                 const unsigned long long other = flags & ~(kFlagHotOverflow | (incons_elsewhere ? 0ull : kFlagInconsistent));
+                const unsigned long long wanted_so_far = sl.h_counters[4];  // (a stream OUTSIDE the few may have outgrown its record capacity)
                 int rc = before_rerun(h, sl);
                 if (rc == RT_OK) rc = enqueue_partial_dense(h, sl, n_bad, sl.h_counters[0]);
                 if (rc == RT_OK) {
                     RT_HIP(h, hipEventSynchronize(sl.ev_done));
                     flags = other | sl.h_counters[2];
                     sl.h_counters[2] = flags;  // (the laned rt_fetch looks at this call twice: sizing, then delivery)
+                    // ... and what that stream wanted survives the partial run's own counter words: the record-overflow flag kept in `other`
+                    // without it was a truncated delivery (round 6's soak, seed 64 case 56)
+                    sl.h_counters[4] = std::max(sl.h_counters[4], wanted_so_far);
                     c.fell_back = true;
                     c.n_dense_streams = n_bad;
                     break;
@@ -2160,6 +2175,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     // the second one wanted -- its lists were still cut at the old capacity.)
     if ((flags & kFlagRecOverflow) && !c.is_extract && c.n_seg > 0 && sl.h_counters[4] > (unsigned long long)c.rec_cap_used && c.cap_grown < 3) {
         if (grow_record_capacity(h, sl.h_counters[4]) == RT_OK) {
+            RT_TRACE_FETCH(h, sl, "capacity grown");
             ++c.cap_grown;
             for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
             c.n_dense_streams = 0;
@@ -2172,9 +2188,10 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
         }
     }
     if ((flags & kFlagRecOverflow) && !c.is_extract && c.n_seg > 0 && sl.h_counters[0] > (unsigned long long)sl.pool_cap &&
-        sl.pool_cap < h->pool_max && !c.pool_grown) {
+        sl.pool_cap < h->pool_max && c.pool_grown < 3) {
         if (grow_pool(h, sl, (int64_t)std::min<unsigned long long>(sl.h_counters[0], (unsigned long long)h->pool_max)) == RT_OK) {
-            c.pool_grown = true;  // once per call
+            RT_TRACE_FETCH(h, sl, "pool grown");
+            ++c.pool_grown;  // (up to three times: a partial dense re-run finds more records in its streams than the run the pool was sized from counted)
             for (int s = 0; s < h->cfg.n_streams; ++s) sl.h_overflow[s] = sl.h_incons[s] = 0;
             c.n_dense_streams = 0;
             int rc = before_rerun(h, sl);
@@ -2187,6 +2204,7 @@ static int fetch_one(rt_handle *h, rt_record *out, size_t cap, size_t *n_out, bo
     }
     break;
   }
+    RT_TRACE_FETCH(h, sl, "settled");
     if (c.mode_used != RT_MODE_DENSE && !c.is_extract && c.n_seg > 0)
         for (int s = 0; s < h->cfg.n_streams; ++s) h->info.n_hot += sl.h_hot_total[s];
     // one wave per stream in the next calls' sparse detection while a stream holds half of what such a wave takes on average (heavier

@@ -1232,6 +1232,37 @@ def test_whole_stream_detection_follows_the_load_of_the_batch():
     torch.cuda.empty_cache()
 
 
+def test_record_capacity_grows_beside_a_partial_dense_rerun():
+    """AUTO re-runs a few noisy streams of many on the dense path (their candidate lists overflowed) and keeps the others' records.
+    A QUIET stream that outgrew its record capacity in the same call must still have the capacity grown for it: the partial
+    run publishes its own counter words, and what the quiet stream wanted was lost with the first run's -- the call was
+    delivered truncated (round 6's soak, seed 64 case 56)."""
+    _need_gpu()
+    fs, nperseg, blen, S = 2048000, 256, 600 * 256, 8
+    w = oracle.window_coefficients("hamming", nperseg)
+    rng = np.random.default_rng(21)
+    thr = -90.0
+    loud = float(np.sqrt(10.0 ** ((thr + 6.0) / 10.0) * fs / 2.0))  # a noise floor 6 dB over the threshold
+    streams = []
+    for s in range(S):
+        n_p = 30 if s == 2 else 3
+        pulses = synth.random_pulses(rng, blen, fs, w, n_p, dur_ms=(2, 4), keep_clear_tail=1024)
+        streams.append(synth.make_stream(synth.StreamSpec(blen, fs, pulses, noise_sigma=loud if s == 6 else synth.NOISE_SIGMA), 300 + s))
+    iq = np.stack(streams)
+    kw = dict(sample_rate=fs, signal_min_duration_ms=1.0)
+    ref = _batch_for(kw, S, blen, "auto")
+    small = _batch_for(kw, S, blen, "auto", record_capacity=16)
+    for k in range(2):
+        ref.enqueue(iq)
+        small.enqueue(iq)
+        want, got = ref.fetch_records(), small.fetch_records()
+        info = small.native.call_info()
+        assert info.n_dense_streams == 1 and info.fell_back == 1, (info.n_dense_streams, info.fell_back, info.mode_used)
+        assert not small.native.last_truncated
+        assert np.bincount(want["stream"], minlength=S)[2] > 16
+        assert got.tobytes() == want.tobytes(), k
+
+
 def test_thousands_of_plateaus_in_one_stream_equal_the_oracle():
     """More than 5 000 plateaus in ONE stream-buffer (nine tags keyed on and off every twelve hops for a second, a quiet SDR
     beside it): the handle's capacity of 1 024 records per stream grows to hold them, finalize_records ranks and shadows them
