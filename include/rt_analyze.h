@@ -131,7 +131,9 @@ typedef struct rt_config {
                                      segment cancels exactly in the reference) use the subtract-first form anyway */
 #define RT_FLAG_GROUP_DETECT 4u    /* sparse detection (analyze.py:330-452 on the candidate lists) with one wave per stream, or per quarter
                                      of a stream's sixteen lists, instead of one per list -- the same records; the default from 1 024
-                                     streams per handle on, where the lists are many and short.  This flag: at any number of streams */
+                                     streams per handle on, while the streams of the call fetched last held few candidate cells (<= 448 on
+                                     average).  This flag: at any number of streams, whatever they hold.  Only where the fused kernels have
+                                     the form (nperseg <= 256); ignored elsewhere */
 #define RT_FLAG_NO_GROUP_DETECT 8u /* ... never */
 
 /*
