@@ -1225,6 +1225,12 @@ def test_whole_stream_detection_follows_the_load_of_the_batch():
             want, _ = oas[s].process(iq[s].cpu().numpy(), gu.TS0)
             mine = rec_a[rec_a["stream"] == s]
             assert [(int(r["fi"]), int(r["start"]), int(r["end"])) for r in mine] == [(v.fi, v.start, v.end) for v in want], f"buffer {k} stream {s}"
+    # finalize_records with four streams per workgroup (batches of >= 1 024 streams) behind the dense extractor staged in global
+    # memory (a record capacity beyond its LDS staging): the same bytes
+    dense_big = _batch_for(kw, S, blen, "dense", record_capacity=4096)
+    dense_big.enqueue(bufs[0])
+    assert dense_big.fetch_records().tobytes() == got[id(auto)][0].tobytes()
+    dense_big.close()
     # the load really crossed the rule's line both ways (records per stream as a stand-in for the cells)
     n_rec = [len(r) / S for r in got[id(auto)]]
     assert n_rec[0] < 12 and n_rec[1] > 30 and n_rec[2] > 30 and n_rec[3] < 12, n_rec
