@@ -812,10 +812,12 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
         big = np.concatenate([rec] * reps) if reps > 1 else rec
         n_big = int((big["shadowed"] == 0).sum())
         out["sink_batch_records"] = n_big
+        out["sink_batch_records_in"] = int(len(big))  # (the shadow filter passes n_big of them: the rates below count rows OUT)
         consume.set_host_threads(1)
         out["csv_rows_per_s_one_thread"] = rate(lambda: consume.format_signals("csv", consume.rows_from_analysis(big, decoder, ts0_us), device_names), n_big)
         out["threads"] = consume.set_host_threads(0)
         out["csv_rows_per_s"] = rate(lambda: consume.format_signals("csv", consume.rows_from_analysis(big, decoder, ts0_us), device_names), n_big)
+        out["csv_records_in_per_s"] = round(out["csv_rows_per_s"] * len(big) / max(1, n_big), 1)
         out["json_documents_per_s"] = rate(lambda: consume.format_signals("json", consume.rows_from_analysis(big, decoder, ts0_us), device_names), n_big)
         # the matcher: stations of four consecutive streams (the reference: four antennas per station, one SignalMatcher per station
         # process, match.py:21-50), every station's signals in time order, all stations in one native call
@@ -856,7 +858,8 @@ def host_sinks(decoder, rec, device_names, records_per_s_produced):
     out["note"] = ("signal_objects_per_s: Signal objects built from the records that pass the shadow filter (the reference's signal_queue.put payload); "
                    "signal_batch_records_per_s: the same nine fields per record as a lazy sequence (SignalBatch: columns at once, a Signal object when an element is "
                    "asked for -- what BatchSignalAnalyzer.process_batch returns by default); csv_rows_per_s / json_documents_per_s: records to `;`-separated CSV rows / "
-                   "JSON documents through rows_from_analysis (rt_signal_rows_from_records) + rt_format_signals on `threads` host threads; matched_signals_per_s: "
+                   "JSON documents through rows_from_analysis (rt_signal_rows_from_records) + rt_format_signals on `threads` host threads, counted in rows OUT (the batch is "
+                   "sink_batch_records_in records of which the shadow filter passes sink_batch_records; csv_records_in_per_s: the same time per record IN); matched_signals_per_s: "
                    "the same signals through one SignalMatcher per station of four streams, all stations in one rt_match_add_many call")
     return out
 
