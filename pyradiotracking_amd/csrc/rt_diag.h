@@ -16,7 +16,7 @@
 #define RT_DIAG_ENV(name) std::getenv(name)
 #else
 #define RT_DIAG_ENV(name) (static_cast<const char *>(nullptr))
-#if defined(RT_STAMPS) || defined(RT_ABLATE) || defined(RT_DETECT_ABLATE) || defined(RT_W64_ABL) || defined(RT_WG_ABL) || defined(RT_EXP_DMA1024) || defined(RT_EXP_WG_NOFENCE) || defined(RT_EXP_NOBAR0) || defined(RT_EXP_NOBAR1) || \
+#if defined(RT_STAMPS) || defined(RT_ABLATE) || defined(RT_DETECT_ABLATE) || defined(RT_W64_ABL) || defined(RT_WG_ABL) || defined(RT_EXP_WG_HALF) || defined(RT_EXP_DMA1024) || defined(RT_EXP_WG_NOFENCE) || defined(RT_EXP_NOBAR0) || defined(RT_EXP_NOBAR1) || \
     defined(RT_EXP_ALIAS) || defined(RT_EXP_NOWIN) || defined(RT_EXP_PRIO) || defined(RT_ONE_WAVE_MAX_R3) || defined(RT_NO_PERSIST) ||                    \
     defined(RT_WG4_MAX_R3) || defined(RT_PK_R3_MASK) || defined(RT_BELOW_MAX_R3) || defined(RT_WAVE64_4096) || defined(RT_W64_PK) ||                       \
     defined(RT_W64_PREFETCH) || defined(RT_W64_Q2AHEAD) || defined(RT_EXP6) || defined(RT_EXP_U8_PK)

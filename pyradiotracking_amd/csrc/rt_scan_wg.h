@@ -46,8 +46,19 @@ constexpr int kWgStage = 128;  // candidate cells staged per wave before a flush
 #ifndef RT_WG_ABL
 #define RT_WG_ABL 0
 #endif
+// Experiment, diagnostic builds only (-DRT_EXP_WG_HALF=1; measured and left off: EXPERIMENTS.md round 6, entry 24): nperseg 8192 by
+// HALVES of the exchange -- rows k1 < 16 go through LDS first (pass B's pair e = 0 and, with pass C's pairs dealt (k1 mod 16, p) per
+// half, pass C need only those), then rows k1 >= 16 through the same 33 KiB: three workgroups per CU instead of two, the next
+// segment's samples requested into the registers each half's pass-A values leave.  Correct (the 8192 parity tests pass on it), but
+// three workgroups per CU are 168 registers per thread, and the row sums (32), the twiddle bases (10), the prefetched samples (64),
+// the other half's pass-A values (32) and a pair's sixteen (32) are 170 before any temporary: 154 registers in scratch, 12.3 against
+// 4.5 ms per 13 GB.
+#ifndef RT_EXP_WG_HALF
+#define RT_EXP_WG_HALF 0
+#endif
+__host__ __device__ constexpr bool wg_half(int blk) { return RT_EXP_WG_HALF != 0 && blk == 256; }
 __host__ __device__ constexpr int wg_row(int blk) { return blk + 2; }
-__host__ __device__ constexpr size_t wg_lds_bytes(int blk) { return sizeof(cf) * 32 * (size_t)wg_row(blk); }  // the exchange rows (dynamic LDS)
+__host__ __device__ constexpr size_t wg_lds_bytes(int blk) { return sizeof(cf) * (wg_half(blk) ? 16 : 32) * (size_t)wg_row(blk); }  // the exchange rows (dynamic LDS)
 __host__ __device__ constexpr int wg_block(int nperseg) { return nperseg / 32; }                              // 256 / 512 threads
 
 // v[k1] *= W_N^(t k1), k1 = 1 .. 31, from the five factors wb[i] = W_N^(t 2^i): a walk over the bits of k1, high to low, the
@@ -121,12 +132,13 @@ __device__ __forceinline__ void wg_emit(const StftParams &p, int s, int seg, con
 // cosine and sine), beta_j = 2 pi j / 32 (constants) -- two fused multiply-adds per sample instead of a table in registers: the table's
 // 32 registers, live from the request to the multiplication, were what made the kernel spill.  Other windows keep the table (from L2).
 template <int BLK, int MODE, bool U8, bool WCOS>
-__global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void stft_wg(const StftParams p) {
+__global__ __launch_bounds__(BLK, wg_half(BLK) ? 3 : (BLK == 256 ? 2 : 1)) void stft_wg(const StftParams p) {
     using raw_t = typename std::conditional<U8, iq_u8, cf>::type;
     static_assert(BLK == 256 || BLK == 512, "nperseg 8192 / 16384");
     static_assert(MODE == 0 || MODE == 1 || MODE == 2, "sparse, dense, spectrogram only");
     constexpr int N = 32 * BLK, R = BLK / 16, S1 = wg_row(BLK), NW = BLK / 64;
     constexpr bool EMIT = (MODE == 0), SUMS = (MODE != 2), SPEC = (MODE == 1 || MODE == 2);
+    constexpr bool HALF = wg_half(BLK);
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
     cf *const xs = reinterpret_cast<cf *>(wg_smem);  // [32][S1]
     __shared__ double red[2 * NW];
@@ -161,13 +173,18 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void stft_wg(const StftPar
     bool gave_up = false;   // wave-uniform: a list of this stream has overflowed
 
     raw_t nxt[32];
-    auto request = [&](int seg_req) {
+    // pieces j0 .. j0 + 15 of a segment (HALF: a half is requested where the registers of pass A's values of the same half are free)
+    auto request_half = [&](int seg_req, int j0) {
         const int sg = __builtin_amdgcn_readfirstlane(seg_req);
         // (a segment outside the buffer gets an empty descriptor: its loads return zeros)
         const raw_t *base = (RT_WG_ABL & 4) ? reinterpret_cast<const raw_t *>(p.iq) + (int64_t)(sg & 63) * N : stream_iq + (int64_t)(sg < 0 ? 0 : sg) * N;
         const rsrc_t r = make_rsrc(base, (sg >= 0 && sg < T) ? (uint32_t)(N * sizeof(raw_t)) : 0u);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) nxt[j] = buf_load_iq(r, tid * (int)sizeof(raw_t), BLK * j * (int)sizeof(raw_t), raw_t{});
+        for (int j = 0; j < 16; ++j) nxt[j0 + j] = buf_load_iq(r, tid * (int)sizeof(raw_t), BLK * (j0 + j) * (int)sizeof(raw_t), raw_t{});
+    };
+    auto request = [&](int seg_req) {
+        request_half(seg_req, 0);
+        request_half(seg_req, 16);
     };
     // the window in thread order, from L2: requested for the NEXT step once a step's last LDS reads are issued (its latency hides behind
     // the epilogue; at the head of the step it was exposed behind the samples': vector-memory operations return in order)
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void stft_wg(const StftPar
         }
         // WCOS: the next segment's samples are requested here, a whole transform ahead of their use (without the window table there are
         // registers for them beside pass A); with the table, behind exchange 1 (below)
-        if constexpr (WCOS) {
+        if constexpr (WCOS && !HALF) {
             __builtin_amdgcn_sched_barrier(0);
             if (i < n_steps) request(seg - 1);
         }
@@ -274,6 +291,87 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void stft_wg(const StftPar
             wg_twiddle<4, 0, true>(v, wq, cf{1.f, 0.f});
         }
         __builtin_amdgcn_sched_barrier(0);
+        const int tcol = seg - (T - p.tail_cols);
+        const bool to_tail = SUMS && !(RT_WG_ABL & 16) && !halo && tcol >= 0;
+        // (rows leave through buffer stores: one descriptor per row, ONE address register -- global stores 1 .. 2 KiB apart each want a
+        // 64-bit address of their own)
+        const rsrc_t rs_spec = make_rsrc(SPEC ? p.spec + ((int64_t)(p.spec_by_stream ? s : s_pos) * T + seg) * N : nullptr, SPEC ? (uint32_t)(N * sizeof(float)) : 0u);
+        const rsrc_t rs_tail = make_rsrc(to_tail ? p.tail + ((int64_t)s * p.tail_cols + tcol) * N : nullptr, to_tail ? (uint32_t)(N * sizeof(float)) : 0u);
+        uint32_t any_hot = 0u;
+      if constexpr (HALF) {
+        // The exchanges by halves: rows k1 = 16 h .. 16 h + 15 through 16 rows of LDS.  Pass B's pair of half h is (k1 = 16 h + tid / 16,
+        // d = tid % 16) -- the whole-segment form's pair e = h --, pass C's is (k1 = 16 h + tid % 16, p = tid / 16): register q of the half
+        // holds bin 16 h + tid % 16 + 32 (tid / 16) + 512 q, sixteen consecutive bins per sixteen lanes.
+        const int bin_t = (tid & 15) + 32 * (tid >> 4);  // the thread's bin of half 0, q = 0
+        const float4 *const t2 = reinterpret_cast<const float4 *>(tw2_lds + (tid % R) * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (h == 1) __syncthreads();  // (pass C of half 0 has read its rows)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xs[k * S1 + tid] = v[16 * h + k];
+            // the next segment's pieces 16 h .. 16 h + 15 into the registers this half's values have just left
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < n_steps) request_half(seg - 1, 16 * h);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            {
+                cf *const col = xs + (tid / R) * S1 + (tid % R);
+                cf u[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) u[c] = col[R * c];
+                dft16(u);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 t = t2[kk];
+                    if (kk) u[2 * kk] = cmul(u[2 * kk], cf{t.x, t.y});
+                    u[2 * kk + 1] = cmul(u[2 * kk + 1], cf{t.z, t.w});
+                }
+#pragma unroll
+                for (int pp = 0; pp < 16; ++pp) col[R * pp] = u[pp];
+            }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 *row = reinterpret_cast<const float4 *>(xs + (tid & 15) * S1 + R * (tid >> 4));
+            cf u[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 q4 = row[j];
+                u[2 * j] = cf{q4.x, q4.y};
+                u[2 * j + 1] = cf{q4.z, q4.w};
+            }
+            // (the step's last LDS reads are issued: the next step's window -- its latency hides behind this epilogue)
+            if (h == 1 && i < n_steps) request_window();
+            dft16(u);
+            float Pp[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = 16 * h + q;  // the result register: bin 16 h + bin_t + 512 q
+                Pp[q] = __builtin_fmaf(u[q].x, u[q].x, u[q].y * u[q].y);
+                if constexpr (SUMS && !(RT_WG_ABL & 16)) {
+                    if (!halo) acc[r] += Pp[q];
+                }
+                if constexpr (SPEC) raw_buffer_store_f1(Pp[q], rs_spec, bin_t * 4, (16 * h + 512 * q) * 4, 0);
+                if constexpr (SUMS) {
+                    if (to_tail) raw_buffer_store_f1(Pp[q], rs_tail, bin_t * 4, (16 * h + 512 * q) * 4, 0);
+                }
+            }
+            if constexpr (EMIT && !(RT_WG_ABL & 8)) {
+                float mxp = __builtin_fmaxf(Pp[0], Pp[1]);
+#pragma unroll
+                for (int q = 2; q < 16; ++q) mxp = __builtin_fmaxf(mxp, Pp[q]);
+                uint32_t hot = 0;
+                if (!(mxp < thr)) {
+#pragma unroll
+                    for (int q = 15; q >= 0; --q) hot = (hot << 1) | ((Pp[q] < thr) ? 0u : 1u);
+                }
+                const uint32_t emit = halo ? (next_hot[h] & ~hot) : (hot | next_hot[h]);
+                wg_emit<16>(p, s, seg, Pp, emit, 16 * h + bin_t, 512, stg, stg_n, gave_up);
+                next_hot[h] = hot;
+                any_hot |= hot;
+            }
+        }
+      } else {
         // exchange 1: row k1, column t
 #pragma unroll
         for (int k1 = 0; k1 < 32; ++k1) xs[k1 * S1 + tid] = v[k1];
@@ -313,13 +411,6 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void stft_wg(const StftPar
         __syncthreads();
         // pass C, a (k1, p) pair at a time: its R values lie side by side; |X|^2 (scipy _spectral_py.py:2126-2128); the pair's powers are
         // consumed as they come -- row sums, map, tail column, threshold test and emission -- so that no more than one pair's are live
-        const int tcol = seg - (T - p.tail_cols);
-        const bool to_tail = SUMS && !(RT_WG_ABL & 16) && !halo && tcol >= 0;
-        // (rows leave through buffer stores: one descriptor per row, ONE address register -- global stores 1 .. 2 KiB apart each want a
-        // 64-bit address of their own)
-        const rsrc_t rs_spec = make_rsrc(SPEC ? p.spec + ((int64_t)(p.spec_by_stream ? s : s_pos) * T + seg) * N : nullptr, SPEC ? (uint32_t)(N * sizeof(float)) : 0u);
-        const rsrc_t rs_tail = make_rsrc(to_tail ? p.tail + ((int64_t)s * p.tail_cols + tcol) * N : nullptr, to_tail ? (uint32_t)(N * sizeof(float)) : 0u);
-        uint32_t any_hot = 0u;
 #pragma unroll
         for (int e = 0; e < PAIRS; ++e) {
 #ifndef RT_EXP_WG_NOFENCE
@@ -369,6 +460,7 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void stft_wg(const StftPar
                 any_hot |= hot;
             }
         }
+      }
         // (the rows are rewritten behind the next step's first barrier)
         if constexpr (EMIT && !(RT_WG_ABL & 8)) {
             if (i == L) {
@@ -386,8 +478,14 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void stft_wg(const StftPar
     }
     if constexpr (SUMS) {
         const rsrc_t rp = make_rsrc(p.psum + ((int64_t)s * p.blocks_per_stream + cb) * N, (uint32_t)(N * sizeof(float)));
+        if constexpr (HALF) {
+            const int bin_t = (tid & 15) + 32 * (tid >> 4);
 #pragma unroll
-        for (int r = 0; r < 32; ++r) raw_buffer_store_f1(acc[r], rp, tid * 4, BLK * r * 4, 0);
+            for (int r = 0; r < 32; ++r) raw_buffer_store_f1(acc[r], rp, bin_t * 4, (16 * (r / 16) + 512 * (r % 16)) * 4, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) raw_buffer_store_f1(acc[r], rp, tid * 4, BLK * r * 4, 0);
+        }
     }
 }
 
