@@ -92,7 +92,13 @@ int rt_signal_rows_from_records(const rt_record *rec, size_t n, int32_t nperseg,
                                 const float *noise_dbw, const float *snr_db, rt_signal_row *out);
 
 /*
- * Threads the host-side sinks (rt_format_*, rt_signal_rows_from_records, rt_match_add_many) use per call: n > 0 exactly n, 0 =
+ * The records a consumer sees -- those with `shadowed == 0` (analyze.py:248-251: the reference hands only the filtered list on), in
+ * their order -- copied to `out` (room for n records); *n_kept = their number.  On `rt_host_set_threads` threads.
+ */
+int rt_records_keep_unshadowed(const rt_record *rec, size_t n, rt_record *out, size_t *n_kept);
+
+/*
+ * Threads the host-side sinks (rt_format_*, rt_signal_rows_from_records, rt_records_keep_unshadowed, rt_match_add_many) use per call: n > 0 exactly n, 0 =
  * automatic (the machine's hardware threads, at most 32).  Process-wide; returns the number in force.  The output of every sink is
  * byte for byte the same for any number of threads (blocks of rows / whole matchers per thread, assembled in order).
  */

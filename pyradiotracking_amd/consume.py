@@ -33,7 +33,8 @@ from .match import MatchedBatch, datetime_to_us
 FORMAT_CSV, FORMAT_JSON, FORMAT_CBOR = 0, 1, 2
 _KINDS = {"csv": FORMAT_CSV, "json": FORMAT_JSON, "cbor": FORMAT_CBOR}
 
-FORMAT_SYMBOLS = ("rt_format_signals", "rt_format_matched", "rt_format_float_repr", "rt_signal_rows_from_records", "rt_host_set_threads")
+FORMAT_SYMBOLS = ("rt_format_signals", "rt_format_matched", "rt_format_float_repr", "rt_signal_rows_from_records", "rt_records_keep_unshadowed",
+                  "rt_host_set_threads")
 
 # include/rt_format.h: rt_signal_row (72 B), rt_matched_row (24 B)
 SIGNAL_ROW_DTYPE = np.dtype(
@@ -56,6 +57,8 @@ def _lib():
     lib.rt_format_matched.argtypes = [C.c_int32, vp, vp, vp, sz, vp, C.c_int32, vp, sz, vp, C.POINTER(sz)]
     lib.rt_format_float_repr.argtypes = [C.c_double, C.c_char_p]
     lib.rt_signal_rows_from_records.argtypes = [vp, sz, C.c_int32, C.c_double, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    lib.rt_records_keep_unshadowed.restype = C.c_int
+    lib.rt_records_keep_unshadowed.argtypes = [vp, sz, vp, C.POINTER(sz)]
     lib.rt_host_set_threads.argtypes = [C.c_int32]
     for name in FORMAT_SYMBOLS:
         getattr(lib, name)
@@ -181,11 +184,25 @@ def signal_rows(signals: Iterable[Signal], device_names: List[str]) -> np.ndarra
     return rows
 
 
+def keep_unshadowed(rec: np.ndarray) -> np.ndarray:
+    """``rec[rec["shadowed"] == 0]`` (what the reference hands to its consumers, analyze.py:248-251) on the host threads
+    (``rt_records_keep_unshadowed``): NumPy's boolean mask over a million 40-byte records was a third of the records -> CSV path."""
+    rec = np.ascontiguousarray(rec, dtype=_native.RECORD_DTYPE)
+    if len(rec) < 4096:
+        return np.ascontiguousarray(rec[rec["shadowed"] == 0])
+    out = np.empty(len(rec), dtype=_native.RECORD_DTYPE)
+    n = C.c_size_t(0)
+    rc = _lib().rt_records_keep_unshadowed(rec.ctypes.data, len(rec), out.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise _native.NativeError(rc, "rt_records_keep_unshadowed: invalid arguments")
+    return out[: n.value]
+
+
 def rows_from_analysis(rec: np.ndarray, decoder, ts_start_us: Sequence[int]) -> np.ndarray:
     """rt_record array of one analysis call -> SIGNAL_ROW_DTYPE (device = stream index), vectorised:
     the conversion of ``analyze._RecordDecoder`` without a Python object per signal.  Shadowed records
     are dropped (the reference never hands them to a consumer, analyze.py:248-251)."""
-    r = np.ascontiguousarray(rec[rec["shadowed"] == 0])
+    r = keep_unshadowed(rec)
     rows = np.empty(len(r), dtype=SIGNAL_ROW_DTYPE)
     if not len(r):
         return rows

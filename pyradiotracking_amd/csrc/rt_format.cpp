@@ -473,6 +473,31 @@ int rt_signal_rows_from_records(const rt_record *rec, size_t n, int32_t nperseg,
     return RT_OK;
 }
 
+// The records a consumer sees: the ones the shadow filter passes (analyze.py:248-251), in their order, copied to `out` (room for n) --
+// `rec[rec["shadowed"] == 0]` on the host threads: blocks count, a prefix over the blocks places them, blocks copy.
+int rt_records_keep_unshadowed(const rt_record *rec, size_t n, rt_record *out, size_t *n_kept) {
+    if ((!rec || !out) && n) return RT_E_INVALID;
+    if (!n_kept) return RT_E_INVALID;
+    constexpr size_t kBlock = 16384;
+    const size_t n_blocks = (n + kBlock - 1) / kBlock;
+    std::vector<size_t> at(n_blocks + 1, 0);
+    rt::parallel_blocks(n_blocks, [&](size_t b) {
+        const size_t lo = b * kBlock, hi = std::min(n, lo + kBlock);
+        size_t c = 0;
+        for (size_t i = lo; i < hi; ++i) c += rec[i].shadowed == 0;
+        at[b + 1] = c;
+    });
+    for (size_t b = 0; b < n_blocks; ++b) at[b + 1] += at[b];
+    rt::parallel_blocks(n_blocks, [&](size_t b) {
+        const size_t lo = b * kBlock, hi = std::min(n, lo + kBlock);
+        rt_record *o = out + at[b];
+        for (size_t i = lo; i < hi; ++i)
+            if (rec[i].shadowed == 0) *o++ = rec[i];
+    });
+    *n_kept = at[n_blocks];
+    return RT_OK;
+}
+
 int rt_host_set_threads(int32_t n) {
     rt::host_threads_setting().store(n < 0 ? 0 : (int)n);
     return rt::host_threads_for((size_t)1 << 30);

@@ -344,6 +344,30 @@ def test_state_messages_format_like_the_reference():
     assert StateMessage("x", us_to_datetime(0), "2").state is StateMessage.State.STARTED
 
 
+@pytest.mark.parametrize("n", [0, 1, 4095, 4096, 70001])
+@pytest.mark.parametrize("threads", [1, 5])
+def test_keep_unshadowed_is_the_boolean_mask(n, threads):
+    """``consume.keep_unshadowed`` (``rt_records_keep_unshadowed``: blocks count, a prefix places them, blocks copy -- on the host
+    threads) returns ``rec[rec["shadowed"] == 0]``, the records the reference hands to its consumers (analyze.py:248-251)."""
+    from pyradiotracking_amd import _native
+
+    rng = np.random.default_rng(n + threads)
+    rec = np.zeros(n, dtype=_native.RECORD_DTYPE)
+    rec["stream"] = rng.integers(0, 9, n)
+    rec["fi"] = rng.integers(0, 256, n)
+    rec["start"] = rng.integers(-5, 900, n)
+    rec["end"] = rec["start"] + rng.integers(1, 50, n)
+    rec["max_p"] = rng.uniform(1e-9, 1e-6, n).astype(np.float32)
+    rec["shadowed"] = rng.random(n) < 0.6
+    rtc.set_host_threads(threads)
+    try:
+        got = rtc.keep_unshadowed(rec)
+    finally:
+        rtc.set_host_threads(0)
+    want = rec[rec["shadowed"] == 0]
+    assert got.dtype == want.dtype and got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("threads", [1, 3, 8])
 def test_threaded_sinks_are_byte_identical_to_one_thread(threads):
     """The native sinks deal blocks of 2 048 rows to `set_host_threads` threads and assemble the result in block order: CSV / JSON /
