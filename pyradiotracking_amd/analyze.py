@@ -84,14 +84,17 @@ class _RecordDecoder:
         # element k of  arange(N/2, B - N/2 + 1, N) / float(fs)   (_spectral_py.py:2136)
         return (self.nperseg / 2 + np.asarray(k, dtype=np.float64) * self.nperseg) / float(self.sample_rate)
 
-    def decode(self, rec: np.ndarray, freqs: Optional[np.ndarray] = None):
+    def decode(self, rec: np.ndarray, freqs: Optional[np.ndarray] = None, times: bool = True):
         """Signal field columns of ``rec``; ``freqs`` replaces the analyzer's own frequency axis (caller-supplied
-        spectrograms may have any number of bins, ``extract_signals``)."""
-        start = rec["start"].astype(np.int64)
-        end = rec["end"].astype(np.int64)
-        t_end = self.times(end)
-        t_start = np.where(start < 0, -self.times(np.abs(start)), self.times(np.maximum(start, 0)))
-        duration_s = t_end - t_start
+        spectrograms may have any number of bins, ``extract_signals``).  ``times=False``: without start time and duration
+        (``None`` in their places -- the native row builder derives them from the cell coordinates itself)."""
+        t_start = duration_s = None
+        if times:
+            start = rec["start"].astype(np.int64)
+            end = rec["end"].astype(np.int64)
+            t_end = self.times(end)
+            t_start = np.where(start < 0, -self.times(np.abs(start)), self.times(np.maximum(start, 0)))
+            duration_s = t_end - t_start
         cal = self.calibration_db
         if np.ndim(cal):
             # float32 dB figure minus a Python float is a float32 subtraction (NEP 50): the same bits as

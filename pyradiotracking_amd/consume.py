@@ -209,7 +209,7 @@ def rows_from_analysis(rec: np.ndarray, decoder, ts_start_us: Sequence[int]) -> 
     # frequency and the five float32 dB figures by the decoder's NumPy expressions (the reference's own: their last digit is printed);
     # start time and duration from the cell coordinates in the library (rt_signal_rows_from_records: the reference's float64
     # expressions and timedelta's rounding, on the host threads)
-    _t_start, _duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = decoder.decode(r)
+    _t_start, _duration_s, frequency, max_dbw, avg_dbw, std_db, noise_dbw, snr_db = decoder.decode(r, times=False)
     cols = [np.ascontiguousarray(np.broadcast_to(c, len(r)), dtype=np.float32) for c in (max_dbw, avg_dbw, std_db, noise_dbw, snr_db)]
     frequency = np.ascontiguousarray(frequency, dtype=np.float64)
     ts0 = np.ascontiguousarray(ts_start_us, dtype=np.int64)
