@@ -1171,7 +1171,7 @@ def test_detection_by_groups_of_lists_equals_the_per_list_waves(nperseg, mode, l
     def stream(k, pulses, seed):
         return synth.make_stream(synth.StreamSpec(2 * blen, fs, pulses), seed)
 
-    few = synth.random_pulses(rng, 2 * blen, fs, w, 3, dur_ms=(6 * hop_ms, 20 * hop_ms))
+    few = synth.random_pulses(rng, 2 * blen, fs, w, 14, dur_ms=(5 * hop_ms, 12 * hop_ms))  # (short: four plateaus per pass on quarter waves)
     dozen = synth.random_pulses(rng, 2 * blen, fs, w, 24, dur_ms=(10 * hop_ms, 40 * hop_ms))
     q = nperseg // 16 if nperseg >= 64 else 1
     heavy = [tone(1 + 16 * j, 40 + 5 * j, 330) for j in range(min(3, max(1, q - 1)))] + [tone(1, n_seg + 100, 330), tone(17 % nperseg, n_seg + 90, 330)]
@@ -1181,13 +1181,18 @@ def test_detection_by_groups_of_lists_equals_the_per_list_waves(nperseg, mode, l
     S = len(iq)
     plain = _batch_for(kw, S, blen, mode, lanes=lanes, group_detect=False)
     groups = _batch_for(kw, S, blen, mode, lanes=lanes, group_detect=True)
+    # the dense extractor finishes every plateau on a whole wave (run_stats_wave): the sparse waves' statistics of two / four plateaus per
+    # pass on half / quarter waves must give the same BITS (the short pulses of streams 1, 2 and 5 are the four-at-a-time case)
+    dense = _batch_for(kw, S, blen, "dense")
     oas = [oracle.OracleAnalyzer(device=str(s), **kw) for s in range(S)]
     for k in range(2):
         x = np.ascontiguousarray(iq[:, k * blen:(k + 1) * blen])
-        for b in (plain, groups):
+        for b in (plain, groups, dense):
             b.enqueue(x)
-        rec_p, rec_g = plain.fetch_records(), groups.fetch_records()
+        rec_p, rec_g, rec_d = plain.fetch_records(), groups.fetch_records(), dense.fetch_records()
         assert len(rec_g) > 30 and rec_g.tobytes() == rec_p.tobytes(), f"buffer {k}"
+        assert rec_g.tobytes() == rec_d.tobytes(), f"buffer {k}: sparse against dense"
+        assert int(((rec_g["end"] - rec_g["start"]) <= 16).sum()) >= 8  # (plateaus short enough for quarter waves exist)
         for s in range(S):
             want, _ = oas[s].process(x[s], gu.TS0)
             mine = rec_g[rec_g["stream"] == s]
