@@ -1619,6 +1619,7 @@ int rt_create(const rt_config *cfg, rt_handle **out) {
             const size_t cells = (size_t)S * std::max(h->max_seg, 1) * LG;
             RT_CREATE_HIP(hipMalloc(&sl.d_cell_hot, cells * sizeof(uint16_t)));
             RT_CREATE_HIP(hipMalloc(&sl.d_cell_need, cells * sizeof(uint16_t)));
+            RT_CREATE_HIP(hipMemset(sl.d_cell_need, 0, cells * sizeof(uint16_t)));  // (all zeros between calls: plan_runs writes only the words that keep anything)
             RT_CREATE_HIP(hipMalloc(&sl.d_chunk_min, std::max<size_t>(psum_bytes, 4)));  // (a row per work item, like psum)
             RT_CREATE_HIP(hipMalloc(&sl.d_thr_bin, (size_t)S * N * sizeof(float)));
             RT_CREATE_HIP(hipMalloc(&sl.d_thr_nat, (size_t)S * N * sizeof(float)));

@@ -546,6 +546,10 @@ __global__ __launch_bounds__(kW64Block, 1) void stft_scan64(const StftParams p) 
                     if constexpr (EMIT) {
                         // a cell is kept if it is a candidate itself or directly precedes one (T11)
                         const bits64 need_seg = need | first_nxt;
+                        if constexpr (LISTED) {
+                            // consumed: back to zero (the planner writes only the words that keep anything, rt_kernels.h: plan_runs)
+                            if (first_nxt.lo | first_nxt.hi) store_bits(const_cast<uint16_t *>(p.cell_need), ((int64_t)s * T + seg) * 64 + lane, bits64{0u, 0u});
+                        }
                         const bits64 emit = LISTED ? need_seg : (halo ? (next_hot & ~hot) : (hot | next_hot)) & need_seg;
                         if (!(RT_W64_ABL & 32) && !gave_up && __builtin_amdgcn_ballot_w64(any(emit)) != 0ull) {  // wave-uniform, rare
                             // Candidates are staged per wave in LDS and flushed with ONE returned atomic per bucket and
